@@ -1,0 +1,146 @@
+"""`communicate <field>`: duplicate- and ghost-layer exchange between the blocks of the decomposition,
+and the scalar all-reduce that follows every reduction loop.
+
+Reference: IR_CommunicateFunction.compileBody (Compiler/src/exastencils/communication/ir/
+IR_CommunicateFunction.scala:412-471): duplicate layers first -- per axis, own UPPER duplicate plane to
+the '+' neighbour, received into the LOWER plane from the '-' neighbour (comm_batchCommunication) --
+then ghost layers per axis in both directions, tangential extent GLB..GRE so that edge/corner ghosts
+become valid with 6 neighbours only (comm_syncGhostData; ranges IR_PackInfoDuplicate.scala:15-39,
+IR_PackInfoGhost.scala:13-60); pack -> send / recv -> unpack (:194-219); MPI_Allreduce after reduction
+loops (parallelization/api/mpi/MPI_Reduction.scala:100-126).
+
+Transport here: torch.distributed point-to-point batches -- backend "nccl" is RCCL (one process per
+GPU; each pair of GPUs has its own xGMI link, so the three axis exchanges of a 2x2x2 decomposition use
+three different links), backend "gloo" on CPU for the multi-process tests.  Packing is done by the
+kernel layer (`ops.pack/unpack`) into persistent buffers; nothing is staged through the host.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+from .domain import RectDomain
+from .field import Field
+
+
+class Communicator:
+    def __init__(self, domain: RectDomain, ops, group=None):
+        self.domain, self.ops, self.group = domain, ops, group
+        self.dist = None
+        if domain.world_size > 1:
+            import torch.distributed as dist
+
+            if not dist.is_initialized():
+                raise RuntimeError("a decomposition with %d blocks needs torch.distributed to be initialised" % domain.world_size)
+            if dist.get_world_size(group) != domain.world_size:
+                raise RuntimeError("world size %d != number of blocks %d" % (dist.get_world_size(group), domain.world_size))
+            if dist.get_rank(group) != domain.rank:
+                raise RuntimeError("rank mismatch between torch.distributed and the domain")
+            self.dist = dist
+        self._bufs: Dict[Tuple, object] = {}
+        self.stats = {"messages": 0, "bytes": 0}
+
+    # -- buffers -----------------------------------------------------------------------------------
+    def _buf(self, key, n: int):
+        b = self._bufs.get(key)
+        if b is None or b.numel() != n:
+            b = self.ops.new_array(n)
+            self._bufs[key] = b
+        return b
+
+    # -- index ranges ------------------------------------------------------------------------------
+    @staticmethod
+    def dup_ranges(layout, nd: int, d: int):
+        """(send box, recv box): send DRB..DRE (own upper dup) / recv DLB..DLE, tangential DLB..DRE."""
+        sb, se, rb, re_ = [0, 0, 0], [1, 1, 1], [0, 0, 0], [1, 1, 1]
+        for t in range(nd):
+            if t == d:
+                sb[t], se[t] = layout.idx("DRB", t), layout.idx("DRE", t)
+                rb[t], re_[t] = layout.idx("DLB", t), layout.idx("DLE", t)
+            else:
+                sb[t], se[t] = layout.idx("DLB", t), layout.idx("DRE", t)
+                rb[t], re_[t] = sb[t], se[t]
+        return (sb, se), (rb, re_)
+
+    @staticmethod
+    def ghost_ranges(layout, nd: int, d: int, side: int):
+        """Boxes for the exchange with the neighbour on `side` of axis d: what I send there (my first/last
+        inner planes) and where I receive what it sends me (my ghost planes on that side)."""
+        g = layout.ghost[d]
+        sb, se, rb, re_ = [0, 0, 0], [1, 1, 1], [0, 0, 0], [1, 1, 1]
+        for t in range(nd):
+            if t == d:
+                if side < 0:
+                    sb[t], se[t] = layout.idx("IB", t), layout.idx("IB", t) + g
+                    rb[t], re_[t] = layout.idx("GLE", t) - g, layout.idx("GLE", t)
+                else:
+                    sb[t], se[t] = layout.idx("IE", t) - g, layout.idx("IE", t)
+                    rb[t], re_[t] = layout.idx("GRB", t), layout.idx("GRB", t) + g
+            else:
+                sb[t], se[t] = layout.idx("GLB", t), layout.idx("GRE", t)
+                rb[t], re_[t] = sb[t], se[t]
+        return (sb, se), (rb, re_)
+
+    @staticmethod
+    def _count(box) -> int:
+        n = 1
+        for t in range(3):
+            n *= max(0, box[1][t] - box[0][t])
+        return n
+
+    # -- exch<Field>_<level>(slot) ----------------------------------------------------------------
+    def exchange(self, f: Field, slot: Optional[int] = None, what: str = "all"):
+        if self.dist is None:
+            return   # single block, non-periodic: no neighbours, the generated exch function is empty
+        lay, dom, nd = f.layout, self.domain, self.domain.nd
+        x = f.data(slot)
+        if what in ("all", "dup") and lay.communicates_dup and max(lay.dup) > 0:
+            for d in range(nd):
+                plus, minus = dom.neighbor(d, +1), dom.neighbor(d, -1)
+                sbox, rbox = self.dup_ranges(lay, nd, d)
+                sends, recvs = [], []
+                if plus is not None:
+                    sends.append((plus, sbox, ("dup", f.name, f.level, d, "s")))
+                if minus is not None:
+                    recvs.append((minus, rbox, ("dup", f.name, f.level, d, "r")))
+                self._phase(f, x, sends, recvs)
+        if what in ("all", "ghost") and lay.communicates_ghost and max(lay.ghost) > 0:
+            for d in range(nd):
+                sends, recvs = [], []
+                for side in (-1, +1):
+                    peer = dom.neighbor(d, side)
+                    if peer is None:
+                        continue
+                    sbox, rbox = self.ghost_ranges(lay, nd, d, side)
+                    sends.append((peer, sbox, ("ghost", f.name, f.level, d, side, "s")))
+                    recvs.append((peer, rbox, ("ghost", f.name, f.level, d, side, "r")))
+                self._phase(f, x, sends, recvs)
+
+    def _phase(self, f: Field, x, sends: List, recvs: List):
+        """pack -> isend ; irecv -> wait -> unpack for one axis (IR_CommunicateFunction.scala:194-219)."""
+        if not sends and not recvs:
+            return
+        dist, ops = self.dist, self.ops
+        p2p, rbufs = [], []
+        for peer, box, key in recvs:
+            buf = self._buf(key, self._count(box))
+            rbufs.append((buf, box))
+            p2p.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+        for peer, box, key in sends:
+            buf = self._buf(key, self._count(box))
+            ops.pack(f.lc, x, buf, box[0], box[1])
+            p2p.append(dist.P2POp(dist.isend, buf, peer, self.group))
+            self.stats["messages"] += 1
+            self.stats["bytes"] += 8 * buf.numel()
+        for w in dist.batch_isend_irecv(p2p):
+            w.wait()
+        for buf, box in rbufs:
+            ops.unpack(f.lc, x, buf, box[0], box[1])
+
+    # -- reductions across blocks -------------------------------------------------------------------
+    def allreduce(self, t, op: str = "sum"):
+        """MPI_Allreduce(MPI_IN_PLACE, &x, 1, MPI_DOUBLE, op) on a device scalar."""
+        if self.dist is None:
+            return t
+        rop = self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX
+        self.dist.all_reduce(t, op=rop, group=self.group)
+        return t

@@ -1,0 +1,122 @@
+// Shared host/device helpers of libexamg (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/examg.h"
+
+namespace examg {
+
+// Flattened layout facts a kernel needs: strides and the offset of iterator (0,0,0).
+struct LayoutDev {
+  int tot0, tot1, tot2;
+  int ref0, ref1, ref2;
+  long long s1, s2;    // strides of dim 1, dim 2 (dim 0 stride = 1)
+  long long size;      // doubles per (scalar) field
+  long long origin;    // linear index of iterator (0,0,0)
+};
+
+static inline int lay_tot(const examg_layout_t *l, int d) {
+  return l->pad_l[d] + l->ghost_l[d] + l->dup_l[d] + l->inner[d] + l->dup_r[d] + l->ghost_r[d] + l->pad_r[d];
+}
+
+static inline LayoutDev make_layout(const examg_layout_t *l) {
+  LayoutDev d;
+  d.tot0 = lay_tot(l, 0);
+  d.tot1 = lay_tot(l, 1);
+  d.tot2 = lay_tot(l, 2);
+  d.ref0 = l->pad_l[0] + l->ghost_l[0];
+  d.ref1 = l->pad_l[1] + l->ghost_l[1];
+  d.ref2 = l->pad_l[2] + l->ghost_l[2];
+  d.s1 = d.tot0;
+  d.s2 = (long long)d.tot0 * d.tot1;
+  d.size = d.s2 * d.tot2;
+  d.origin = d.ref0 + d.s1 * d.ref1 + d.s2 * d.ref2;
+  return d;
+}
+
+__host__ __device__ static inline long long lidx(const LayoutDev &l, int i0, int i1, int i2) {
+  return l.origin + i0 + l.s1 * i1 + l.s2 * i2;
+}
+
+// iterator-coordinate box
+struct Box {
+  int b0, b1, b2, e0, e1, e2;
+  __host__ __device__ int n0() const { return e0 - b0; }
+  __host__ __device__ int n1() const { return e1 - b1; }
+  __host__ __device__ int n2() const { return e2 - b2; }
+  __host__ __device__ long long count() const {
+    return (n0() <= 0 || n1() <= 0 || n2() <= 0) ? 0 : (long long)n0() * n1() * n2();
+  }
+};
+
+static inline Box make_box(const int32_t *begin, const int32_t *end) {
+  Box b{begin[0], begin[1], begin[2], end[0], end[1], end[2]};
+  return b;
+}
+
+// Does the box (grown by `halo` points, in iterator coords) stay inside the allocation?
+static inline bool box_inside(const examg_layout_t *l, const Box &b, int halo) {
+  const int bb[3] = {b.b0, b.b1, b.b2}, ee[3] = {b.e0, b.e1, b.e2};
+  for (int d = 0; d < 3; ++d) {
+    const int ref = l->pad_l[d] + l->ghost_l[d];
+    const int h = (d < l->nd) ? halo : 0;
+    if (ee[d] <= bb[d]) continue;
+    if (bb[d] - h + ref < 0) return false;
+    if (ee[d] + h + ref > lay_tot(l, d)) return false;
+  }
+  return true;
+}
+
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+
+#define EXAMG_CHECK_LAUNCH(name)                                   \
+  do {                                                             \
+    hipError_t _e = hipGetLastError();                             \
+    if (_e != hipSuccess) return examg::check_hip(_e, name);       \
+  } while (0)
+
+// Same analytic functions as oracle/examg_oracle.c:orc_eval_fn (expression trees as written in the
+// reference programs; device libm may differ from glibc in the last ulp for cos/sin/exp/sinh).
+__device__ static inline double eval_fn(int fn, const double *p, double x, double y, double z) {
+  const double PI = 3.14159265358979323846;
+  switch (fn) {
+    case EXAMG_FN_ZERO: return 0.0;
+    case EXAMG_FN_POLY3D: return ((x * x) - ((0.5 * y) * y)) - ((0.5 * z) * z);
+    case EXAMG_FN_TRIG2D_SOL: return cos(PI * x) - sin((2.0 * PI) * y);
+    case EXAMG_FN_TRIG2D_RHS: return (PI * PI) * cos(PI * x) - ((4.0 * (PI * PI)) * sin((2.0 * PI) * y));
+    case EXAMG_FN_KAPPA_POLY: return p[0] * (((x - (x * x)) * (y - (y * y))) * (z - (z * z)));
+    case EXAMG_FN_KAPPA_RHS:
+      return (2.0 * p[0]) *
+             ((((x - (x * x)) * (y - (y * y))) + ((x - (x * x)) * (z - (z * z)))) + ((y - (y * y)) * (z - (z * z))));
+    case EXAMG_FN_KAPPA_EXPSOL: return 1.0 - exp((-1.0 * p[0]) * (((x - (x * x)) * (y - (y * y))) * (z - (z * z))));
+    case EXAMG_FN_KAPPA_COEF: return exp(p[0] * (((x - (x * x)) * (y - (y * y))) * (z - (z * z))));
+    case EXAMG_FN_TRIG3D_SOL: return (sin(PI * x) * sin(PI * y)) * sinh((sqrt(2.0) * PI) * z);
+    case EXAMG_FN_SIN3: return (sin(PI * x) * sin(PI * y)) * sin(PI * z);
+    case EXAMG_FN_KAPPA_POLY2D: return p[0] * ((x - (x * x)) * (y - (y * y)));
+    case EXAMG_FN_KAPPA_RHS2D: return (2.0 * p[0]) * ((x - (x * x)) + (y - (y * y)));
+    case EXAMG_FN_KAPPA_EXPSOL2D: return 1.0 - exp((-1.0 * p[0]) * ((x - (x * x)) * (y - (y * y))));
+    case EXAMG_FN_KAPPA_COEF2D: return exp(p[0] * ((x - (x * x)) * (y - (y * y))));
+    default: return __builtin_nan("");
+  }
+}
+
+struct Params4 {
+  double v[4];
+};
+struct Geom {
+  double pb0, pb1, pb2, h0, h1, h2;
+};
+static inline Geom make_geom(const examg_geom_t *g) {
+  return Geom{g->pos_begin[0], g->pos_begin[1], g->pos_begin[2], g->h[0], g->h[1], g->h[2]};
+}
+static inline Params4 make_params(const double *p) {
+  Params4 q{{0, 0, 0, 0}};
+  if (p) for (int i = 0; i < 4; ++i) q.v[i] = p[i];
+  return q;
+}
+
+}  // namespace examg

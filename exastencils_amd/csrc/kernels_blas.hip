@@ -1,0 +1,409 @@
+// BLAS-1 loops, reductions, Dirichlet boundary handling, halo pack/unpack, library plumbing (gfx950).
+//
+// Reference loops: Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:113-119 (ResNorm), :160-198
+// (CG vector updates), :226-229 (Solution@coarser = 0); apply bc:
+// Compiler/src/exastencils/boundary/ir/IR_ApplyBCFunction.scala:53-104 (the reference launches
+// one kernel per face -- here one launch covers all faces); pack/unpack:
+// communication/ir/IR_NoInterpPacking.scala:53-83; reductions: the reference writes one term per
+// point to a scratch array and launches log2(n) halving kernels
+// (parallelization/api/cuda/CUDA_Reduction.scala:84-131, CUDA_KernelFunctions.scala:112-238) -- here a
+// two-stage fixed-tree reduction (wave shuffle -> LDS -> one partial per workgroup -> one workgroup).
+#include <stdarg.h>
+
+#include "examg_common.h"
+
+namespace examg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_hip(hipError_t e, const char *what) {
+  if (e == hipSuccess) return 0;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return 2;
+}
+
+static inline dim3 grid_for(long long total, int cap = 8192) {
+  long long nb = (total + 255) / 256;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  return dim3((unsigned)nb);
+}
+
+__device__ __forceinline__ void unflatten(const Box &box, long long t, int &i0, int &i1, int &i2) {
+  const int n0 = box.n0(), n1 = box.n1();
+  i0 = box.b0 + (int)(t % n0);
+  const long long row = t / n0;
+  i1 = box.b1 + (int)(row % n1);
+  i2 = box.b2 + (int)(row / n1);
+}
+
+__global__ void __launch_bounds__(256) k_set(LayoutDev l, double *x, double v, Box box) {
+  const long long total = box.count();
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i0, i1, i2;
+    unflatten(box, t, i0, i1, i2);
+    x[lidx(l, i0, i1, i2)] = v;
+  }
+}
+
+// form: 0 => a*x   1 => x (copy)   2 => y + a*x   3 => x + b*y   4 => a*x + b*y
+// DEV: 0 none, 1 => a = sign * num/den, 2 => b = num/den (read from device memory)
+template <int DEV>
+__global__ void __launch_bounds__(256)
+k_axpby(LayoutDev lx, const double *x, LayoutDev ly, double *y, double a, double b, int form, double sign,
+        const double *num, const double *den, Box box) {
+  if (DEV == 1) a = sign * (*num / *den);
+  if (DEV == 2) b = *num / *den;
+  const long long total = box.count();
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i0, i1, i2;
+    unflatten(box, t, i0, i1, i2);
+    const double xv = x[lidx(lx, i0, i1, i2)];
+    const long long k = lidx(ly, i0, i1, i2);
+    double r;
+    switch (form) {
+      case 0: r = a * xv; break;
+      case 1: r = xv; break;
+      case 2: r = y[k] + a * xv; break;
+      case 3: r = xv + b * y[k]; break;
+      default: r = a * xv + b * y[k]; break;
+    }
+    y[k] = r;
+  }
+}
+
+// ---- reductions -------------------------------------------------------------------------------
+constexpr int RED_BLOCK = 256;
+constexpr int RED_MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = v + __shfl_down(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+  return v;
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ double block_reduce(double v) {
+  __shared__ double sm[RED_BLOCK / 64];
+  v = IS_MAX ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) sm[wv] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    r = sm[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = IS_MAX ? fmax(r, sm[i]) : r + sm[i];
+  }
+  __syncthreads();
+  return r;  // valid in thread 0
+}
+
+__global__ void __launch_bounds__(RED_BLOCK)
+k_dot_partial(LayoutDev lx, const double *__restrict__ x, LayoutDev ly, const double *__restrict__ y, Box box, double *part) {
+  const long long total = box.count();
+  double s = 0.0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i0, i1, i2;
+    unflatten(box, t, i0, i1, i2);
+    s = s + x[lidx(lx, i0, i1, i2)] * y[lidx(ly, i0, i1, i2)];
+  }
+  const double r = block_reduce<false>(s);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+__global__ void __launch_bounds__(RED_BLOCK)
+k_maxerr_partial(LayoutDev l, const double *__restrict__ x, Geom g, int fn, Params4 p, Box box, double *part) {
+  const long long total = box.count();
+  double m = 0.0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i0, i1, i2;
+    unflatten(box, t, i0, i1, i2);
+    const double px = i0 * g.h0 + g.pb0, py = i1 * g.h1 + g.pb1, pz = i2 * g.h2 + g.pb2;
+    m = fmax(m, fabs(x[lidx(l, i0, i1, i2)] - eval_fn(fn, p.v, px, py, pz)));
+  }
+  const double r = block_reduce<true>(m);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+template <bool IS_MAX>
+__global__ void __launch_bounds__(RED_BLOCK) k_reduce_final(const double *part, int n, double *result) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s = IS_MAX ? fmax(s, part[i]) : s + part[i];
+  const double r = block_reduce<IS_MAX>(s);
+  if (threadIdx.x == 0) *result = r;
+}
+
+// ---- analytic fills ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fill_fn(LayoutDev l, double *x, Geom g, int fn, Params4 p, Box box) {
+  const long long total = box.count();
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i0, i1, i2;
+    unflatten(box, t, i0, i1, i2);
+    const double px = i0 * g.h0 + g.pb0, py = i1 * g.h1 + g.pb1, pz = i2 * g.h2 + g.pb2;
+    x[lidx(l, i0, i1, i2)] = eval_fn(fn, p.v, px, py, pz);
+  }
+}
+
+struct FaceBoxes {
+  Box box[6];
+  long long start[7];  // prefix sums of counts
+  int n;
+};
+
+__global__ void __launch_bounds__(256) k_apply_dirichlet(LayoutDev l, double *x, Geom g, int fn, Params4 p, FaceBoxes fb) {
+  const long long total = fb.start[fb.n];
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int f = 0;
+    while (f + 1 < fb.n && t >= fb.start[f + 1]) ++f;
+    int i0, i1, i2;
+    unflatten(fb.box[f], t - fb.start[f], i0, i1, i2);
+    const double px = i0 * g.h0 + g.pb0, py = i1 * g.h1 + g.pb1, pz = i2 * g.h2 + g.pb2;
+    x[lidx(l, i0, i1, i2)] = eval_fn(fn, p.v, px, py, pz);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_init_varcoeff(LayoutDev lc, double *cf, Geom g, int fn, Params4 p, Box box, int nd) {
+  const long long total = box.count();
+  const long long plane = lc.size;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i0, i1, i2;
+    unflatten(box, t, i0, i1, i2);
+    const double x = i0 * g.h0 + g.pb0, y = i1 * g.h1 + g.pb1, z = i2 * g.h2 + g.pb2;
+    const double hx = g.h0, hy = g.h1, hz = g.h2;
+    const double axp = eval_fn(fn, p.v, x + (0.5 * hx), y, z), axm = eval_fn(fn, p.v, x - (0.5 * hx), y, z);
+    const double ayp = eval_fn(fn, p.v, x, y + (0.5 * hy), z), aym = eval_fn(fn, p.v, x, y - (0.5 * hy), z);
+    const long long k = lidx(lc, i0, i1, i2);
+    if (nd == 3) {
+      const double azp = eval_fn(fn, p.v, x, y, z + (0.5 * hz)), azm = eval_fn(fn, p.v, x, y, z - (0.5 * hz));
+      cf[k + 0 * plane] = (((axp + axm) / (hx * hx)) + ((ayp + aym) / (hy * hy))) + ((azp + azm) / (hz * hz));
+      cf[k + 1 * plane] = (-1.0 * axp) / (hx * hx);
+      cf[k + 2 * plane] = (-1.0 * axm) / (hx * hx);
+      cf[k + 3 * plane] = (-1.0 * ayp) / (hy * hy);
+      cf[k + 4 * plane] = (-1.0 * aym) / (hy * hy);
+      cf[k + 5 * plane] = (-1.0 * azp) / (hz * hz);
+      cf[k + 6 * plane] = (-1.0 * azm) / (hz * hz);
+    } else {
+      cf[k + 0 * plane] = ((axp + axm) / (hx * hx)) + ((ayp + aym) / (hy * hy));
+      cf[k + 1 * plane] = (-1.0 * axp) / (hx * hx);
+      cf[k + 2 * plane] = (-1.0 * axm) / (hx * hx);
+      cf[k + 3 * plane] = (-1.0 * ayp) / (hy * hy);
+      cf[k + 4 * plane] = (-1.0 * aym) / (hy * hy);
+    }
+  }
+}
+
+// ---- halo pack / unpack ---------------------------------------------------------------------
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_pack(LayoutDev l, double *x, double *buf, Box box) {
+  const long long total = box.count();
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i0, i1, i2;
+    unflatten(box, t, i0, i1, i2);
+    if (PACK) buf[t] = x[lidx(l, i0, i1, i2)];
+    else x[lidx(l, i0, i1, i2)] = buf[t];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fill_random(double *x, long long n, unsigned long long seed) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned long long zz = seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(i + 1);
+    zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBULL;
+    zz = zz ^ (zz >> 31);
+    x[i] = (double)(zz >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+  }
+}
+
+}  // namespace examg
+
+using namespace examg;
+
+extern "C" int examg_version(void) { return 100; }
+extern "C" const char *examg_last_error(void) { return g_err; }
+extern "C" int examg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int examg_set(const examg_layout_t *l_, double *x, double v, const int32_t *begin, const int32_t *end,
+                         examg_stream_t stream) {
+  if (!l_ || !x || !begin || !end) { set_error("examg_set: null argument"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (!box_inside(l_, box, 0)) { set_error("examg_set: box leaves the allocation"); return 1; }
+  hipLaunchKernelGGL(k_set, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(l_), x, v, box);
+  EXAMG_CHECK_LAUNCH("k_set");
+  return 0;
+}
+
+static int axpby_impl(const examg_layout_t *lx_, const double *x, const examg_layout_t *ly_, double *y, double a, double b,
+                      int dev, double sign, const double *num, const double *den, const int32_t *begin,
+                      const int32_t *end, examg_stream_t stream) {
+  if (!lx_ || !x || !ly_ || !y || !begin || !end) { set_error("examg_axpby: null argument"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (!box_inside(lx_, box, 0) || !box_inside(ly_, box, 0)) { set_error("examg_axpby: box leaves an allocation"); return 1; }
+  int form;
+  if (dev == 1) form = (b == 1.0) ? 2 : ((b == 0.0) ? 0 : 4);
+  else if (dev == 2) form = (a == 1.0) ? 3 : 4;
+  else if (b == 0.0) form = (a == 1.0) ? 1 : 0;
+  else if (b == 1.0) form = 2;
+  else if (a == 1.0) form = 3;
+  else form = 4;
+  const LayoutDev lx = make_layout(lx_), ly = make_layout(ly_);
+  hipStream_t s = (hipStream_t)stream;
+  if (dev == 0) hipLaunchKernelGGL((k_axpby<0>), grid_for(box.count()), dim3(256), 0, s, lx, x, ly, y, a, b, form, sign, num, den, box);
+  else if (dev == 1) hipLaunchKernelGGL((k_axpby<1>), grid_for(box.count()), dim3(256), 0, s, lx, x, ly, y, a, b, form, sign, num, den, box);
+  else hipLaunchKernelGGL((k_axpby<2>), grid_for(box.count()), dim3(256), 0, s, lx, x, ly, y, a, b, form, sign, num, den, box);
+  EXAMG_CHECK_LAUNCH("k_axpby");
+  return 0;
+}
+
+extern "C" int examg_axpby(const examg_layout_t *lx, const double *x, const examg_layout_t *ly, double *y, double a,
+                           double b, const int32_t *begin, const int32_t *end, examg_stream_t stream) {
+  return axpby_impl(lx, x, ly, y, a, b, 0, 1.0, nullptr, nullptr, begin, end, stream);
+}
+
+extern "C" int examg_axpby_dev(const examg_layout_t *lx, const double *x, const examg_layout_t *ly, double *y, double a,
+                               double b, int which, double sign, const double *num, const double *den,
+                               const int32_t *begin, const int32_t *end, examg_stream_t stream) {
+  if (!num || !den) { set_error("examg_axpby_dev: null scalar pointer"); return 1; }
+  if (which != 0 && which != 1) { set_error("examg_axpby_dev: which must be 0 or 1"); return 1; }
+  return axpby_impl(lx, x, ly, y, a, b, which + 1, sign, num, den, begin, end, stream);
+}
+
+extern "C" size_t examg_reduce_work_bytes(void) { return (size_t)RED_MAX_BLOCKS * sizeof(double); }
+
+static int red_blocks(long long total) {
+  long long nb = (total + RED_BLOCK * 4 - 1) / (RED_BLOCK * 4);
+  if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" int examg_dot(const examg_layout_t *lx_, const double *x, const examg_layout_t *ly_, const double *y,
+                         const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream) {
+  if (!lx_ || !x || !ly_ || !y || !begin || !end || !result || !work) { set_error("examg_dot: null argument"); return 1; }
+  const Box box = make_box(begin, end);
+  hipStream_t s = (hipStream_t)stream;
+  if (box.count() == 0) return check_hip(hipMemsetAsync(result, 0, sizeof(double), s), "examg_dot memset");
+  if (!box_inside(lx_, box, 0) || !box_inside(ly_, box, 0)) { set_error("examg_dot: box leaves an allocation"); return 1; }
+  const int nb = red_blocks(box.count());
+  hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(RED_BLOCK), 0, s, make_layout(lx_), x, make_layout(ly_), y, box, (double *)work);
+  hipLaunchKernelGGL((k_reduce_final<false>), dim3(1), dim3(RED_BLOCK), 0, s, (const double *)work, nb, result);
+  EXAMG_CHECK_LAUNCH("k_dot");
+  return 0;
+}
+
+extern "C" int examg_max_err_fn(const examg_layout_t *l_, const double *x, const examg_geom_t *g, int fn,
+                                const double *params, const int32_t *begin, const int32_t *end, double *result,
+                                void *work, examg_stream_t stream) {
+  if (!l_ || !x || !g || !begin || !end || !result || !work) { set_error("examg_max_err_fn: null argument"); return 1; }
+  const Box box = make_box(begin, end);
+  hipStream_t s = (hipStream_t)stream;
+  if (box.count() == 0) return check_hip(hipMemsetAsync(result, 0, sizeof(double), s), "examg_max_err_fn memset");
+  if (!box_inside(l_, box, 0)) { set_error("examg_max_err_fn: box leaves the allocation"); return 1; }
+  const int nb = red_blocks(box.count());
+  hipLaunchKernelGGL(k_maxerr_partial, dim3(nb), dim3(RED_BLOCK), 0, s, make_layout(l_), x, make_geom(g), fn, make_params(params), box, (double *)work);
+  hipLaunchKernelGGL((k_reduce_final<true>), dim3(1), dim3(RED_BLOCK), 0, s, (const double *)work, nb, result);
+  EXAMG_CHECK_LAUNCH("k_maxerr");
+  return 0;
+}
+
+extern "C" int examg_fill_fn(const examg_layout_t *l_, double *x, const examg_geom_t *g, int fn, const double *params,
+                             const int32_t *begin, const int32_t *end, examg_stream_t stream) {
+  if (!l_ || !x || !g || !begin || !end) { set_error("examg_fill_fn: null argument"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (!box_inside(l_, box, 0)) { set_error("examg_fill_fn: box leaves the allocation"); return 1; }
+  hipLaunchKernelGGL(k_fill_fn, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(l_), x, make_geom(g), fn, make_params(params), box);
+  EXAMG_CHECK_LAUNCH("k_fill_fn");
+  return 0;
+}
+
+extern "C" int examg_apply_dirichlet(const examg_layout_t *l, double *x, const examg_geom_t *g, int fn,
+                                     const double *params, uint32_t face_mask, examg_stream_t stream) {
+  if (!l || !x || !g) { set_error("examg_apply_dirichlet: null argument"); return 1; }
+  FaceBoxes fb;
+  fb.n = 0;
+  fb.start[0] = 0;
+  for (int d = 0; d < l->nd; ++d)
+    for (int side = 0; side < 2; ++side) {
+      if (!(face_mask & (1u << (2 * d + side)))) continue;
+      int b[3] = {0, 0, 0}, e[3] = {1, 1, 1};
+      for (int t = 0; t < l->nd; ++t) {
+        if (t == d) {
+          if (side == 0) { b[t] = 0; e[t] = l->dup_l[t]; }                       // DLB..DLE
+          else { b[t] = l->dup_l[t] + l->inner[t]; e[t] = b[t] + l->dup_r[t]; }  // DRB..DRE
+        } else {
+          b[t] = -l->ghost_l[t];                                                 // GLB..GRE
+          e[t] = l->dup_l[t] + l->inner[t] + l->dup_r[t] + l->ghost_r[t];
+        }
+      }
+      Box bx{b[0], b[1], b[2], e[0], e[1], e[2]};
+      if (bx.count() == 0) continue;
+      fb.box[fb.n] = bx;
+      fb.start[fb.n + 1] = fb.start[fb.n] + bx.count();
+      ++fb.n;
+    }
+  if (fb.n == 0) return 0;
+  hipLaunchKernelGGL(k_apply_dirichlet, grid_for(fb.start[fb.n], 2048), dim3(256), 0, (hipStream_t)stream, make_layout(l), x, make_geom(g), fn, make_params(params), fb);
+  EXAMG_CHECK_LAUNCH("k_apply_dirichlet");
+  return 0;
+}
+
+extern "C" int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,
+                                    const double *params, const int32_t *begin, const int32_t *end,
+                                    examg_stream_t stream) {
+  if (!lc || !cfield || !g || !begin || !end) { set_error("examg_init_varcoeff7: null argument"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (!box_inside(lc, box, 0)) { set_error("examg_init_varcoeff7: box leaves the allocation"); return 1; }
+  hipLaunchKernelGGL(k_init_varcoeff, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(lc), cfield, make_geom(g), coef_fn, make_params(params), box, lc->nd);
+  EXAMG_CHECK_LAUNCH("k_init_varcoeff");
+  return 0;
+}
+
+extern "C" int examg_pack(const examg_layout_t *l, const double *x, double *buf, const int32_t *begin,
+                          const int32_t *end, examg_stream_t stream) {
+  if (!l || !x || !buf || !begin || !end) { set_error("examg_pack: null argument"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (!box_inside(l, box, 0)) { set_error("examg_pack: box leaves the allocation"); return 1; }
+  hipLaunchKernelGGL((k_pack<true>), grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(l), const_cast<double *>(x), buf, box);
+  EXAMG_CHECK_LAUNCH("k_pack");
+  return 0;
+}
+
+extern "C" int examg_unpack(const examg_layout_t *l, double *x, const double *buf, const int32_t *begin,
+                            const int32_t *end, examg_stream_t stream) {
+  if (!l || !x || !buf || !begin || !end) { set_error("examg_unpack: null argument"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (!box_inside(l, box, 0)) { set_error("examg_unpack: box leaves the allocation"); return 1; }
+  hipLaunchKernelGGL((k_pack<false>), grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(l), x, const_cast<double *>(buf), box);
+  EXAMG_CHECK_LAUNCH("k_unpack");
+  return 0;
+}
+
+extern "C" int examg_fill_random(double *x, int64_t n, uint64_t seed, examg_stream_t stream) {
+  if (!x) { set_error("examg_fill_random: null argument"); return 1; }
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_fill_random, grid_for(n), dim3(256), 0, (hipStream_t)stream, x, (long long)n, (unsigned long long)seed);
+  EXAMG_CHECK_LAUNCH("k_fill_random");
+  return 0;
+}

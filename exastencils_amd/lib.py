@@ -1,0 +1,109 @@
+"""ctypes binding of libexamg.so (the C ABI declared in include/examg.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).
+No fallback: a missing library raises ImportError-like RuntimeError at load().
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libexamg.so")
+MAXE = 27
+
+
+class LayoutC(C.Structure):
+    _fields_ = [("nd", C.c_int32)] + [
+        (n, C.c_int32 * 3) for n in ("pad_l", "ghost_l", "dup_l", "inner", "dup_r", "ghost_r", "pad_r")
+    ]
+
+
+class StencilC(C.Structure):
+    _fields_ = [
+        ("nent", C.c_int32),
+        ("diag", C.c_int32),
+        ("off", (C.c_int32 * 3) * MAXE),
+        ("coef", C.c_double * MAXE),
+        ("cfield", C.c_void_p),
+        ("clayout", LayoutC),
+    ]
+
+
+class GeomC(C.Structure):
+    _fields_ = [("pos_begin", C.c_double * 3), ("h", C.c_double * 3)]
+
+
+class ExamgError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/examg.h declares
+SYMBOLS = [
+    "examg_version", "examg_last_error", "examg_device_count", "examg_stencil_op", "examg_jacobi",
+    "examg_rbgs_colour", "examg_residual", "examg_rbgs_sweep_fused", "examg_restrict", "examg_prolong_add",
+    "examg_set", "examg_axpby", "examg_axpby_dev", "examg_reduce_work_bytes", "examg_dot", "examg_max_err_fn",
+    "examg_fill_fn", "examg_apply_dirichlet", "examg_init_varcoeff7", "examg_pack", "examg_unpack",
+    "examg_cg_coarse", "examg_fill_random",
+]
+
+
+def load():
+    """Load libexamg.so and declare the prototypes.  Raises if the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExamgError(
+            "libexamg.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int32)
+    lp, sp, gp, dp = C.POINTER(LayoutC), C.POINTER(StencilC), C.POINTER(GeomC), C.POINTER(C.c_double)
+    L.examg_version.restype = C.c_int
+    L.examg_last_error.restype = C.c_char_p
+    L.examg_device_count.restype = C.c_int
+    L.examg_stencil_op.argtypes = [C.c_int, lp, vp, lp, vp, lp, vp, sp, C.c_double, C.c_int, ip, ip, vp]
+    L.examg_jacobi.argtypes = [lp, vp, vp, lp, vp, sp, C.c_double, ip, ip, vp]
+    L.examg_rbgs_colour.argtypes = [lp, vp, lp, vp, sp, C.c_double, C.c_int, ip, ip, vp]
+    L.examg_residual.argtypes = [lp, vp, lp, vp, lp, vp, sp, ip, ip, vp]
+    L.examg_rbgs_sweep_fused.argtypes = [lp, vp, vp, lp, vp, sp, C.c_double, C.c_int, ip, ip, vp]
+    L.examg_restrict.argtypes = [lp, vp, lp, vp, C.c_double, ip, ip, vp]
+    L.examg_prolong_add.argtypes = [lp, vp, lp, vp, ip, ip, vp]
+    L.examg_set.argtypes = [lp, vp, C.c_double, ip, ip, vp]
+    L.examg_axpby.argtypes = [lp, vp, lp, vp, C.c_double, C.c_double, ip, ip, vp]
+    L.examg_axpby_dev.argtypes = [lp, vp, lp, vp, C.c_double, C.c_double, C.c_int, C.c_double, vp, vp, ip, ip, vp]
+    L.examg_reduce_work_bytes.restype = C.c_size_t
+    L.examg_dot.argtypes = [lp, vp, lp, vp, ip, ip, vp, vp, vp]
+    L.examg_max_err_fn.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp, vp, vp]
+    L.examg_fill_fn.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp]
+    L.examg_apply_dirichlet.argtypes = [lp, vp, gp, C.c_int, dp, C.c_uint32, vp]
+    L.examg_init_varcoeff7.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp]
+    L.examg_pack.argtypes = [lp, vp, vp, ip, ip, vp]
+    L.examg_unpack.argtypes = [lp, vp, vp, ip, ip, vp]
+    L.examg_cg_coarse.argtypes = [lp, vp, lp, vp, lp, vp, lp, vp, lp, vp, sp, gp, C.c_uint32, C.c_int, C.c_double, ip, ip, vp, vp]
+    L.examg_fill_random.argtypes = [vp, C.c_int64, C.c_uint64, vp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+        if name not in ("examg_version", "examg_last_error", "examg_device_count", "examg_reduce_work_bytes"):
+            fn.restype = C.c_int
+    L.examg_debug_force_generic.argtypes = [C.c_int]
+    L.examg_debug_force_generic.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise ExamgError("%s failed (%d): %s" % (what or "libexamg call", rc, load().examg_last_error().decode()))
+
+
+def ivec(v):
+    return (C.c_int32 * 3)(*[int(x) for x in v])
+
+
+def dvec4(v):
+    v = list(v) + [0.0] * (4 - len(v))
+    return (C.c_double * 4)(*v[:4])

@@ -1,0 +1,140 @@
+"""Kernel-call layer: one method per emitted-loop kind, forwarding to the C ABI of libexamg.so.
+
+PyTorch is plumbing here: device memory (float64 tensors), the current HIP stream (so launches can be
+captured by torch.cuda.graph and timed by events on that stream) and torch.distributed.  All
+arithmetic happens in the HIP kernels; there is no CPU fallback -- constructing HipOps without the
+built library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+from . import lib as _lib
+from .field import Stencil
+from .lib import ExamgError, check, dvec4, ivec
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self, device: Optional[int] = None):
+        import torch
+
+        self.torch = torch
+        self.L = _lib.load()   # raises if libexamg.so is missing
+        if not torch.cuda.is_available():
+            raise ExamgError("HipOps needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        if self.L.examg_device_count() < 1:
+            raise ExamgError("libexamg sees no HIP device")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._work = torch.empty(int(self.L.examg_reduce_work_bytes()) // 8, dtype=torch.float64, device=self.device)
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def new_array(self, n: int):
+        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+
+    def new_scalar(self):
+        return self.torch.zeros(1, dtype=self.torch.float64, device=self.device)
+
+    @staticmethod
+    def ptr(t) -> int:
+        return t.data_ptr()
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def to_host(self, t):
+        return t.detach().cpu().numpy()
+
+    def from_host(self, a):
+        return self.torch.from_numpy(a).to(self.device)
+
+    # -- stencil loops ----------------------------------------------------------------------------
+    def stencil_op(self, mode: int, lu, u, lf, rhs, ld, dst, st: Stencil, w: float, colour: int, begin, end):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_stencil_op(mode, C.byref(lu), self.ptr(u), C.byref(lf) if lf is not None else None,
+                                      self.ptr(rhs) if rhs is not None else None, C.byref(ld), self.ptr(dst),
+                                      C.byref(sc), float(w), int(colour), ivec(begin), ivec(end), self._stream()),
+              "examg_stencil_op")
+
+    def rbgs_sweep_fused(self, lu, u_in, u_out, lf, rhs, st: Stencil, w: float, first: int, begin, end):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_rbgs_sweep_fused(C.byref(lu), self.ptr(u_in), self.ptr(u_out), C.byref(lf), self.ptr(rhs),
+                                            C.byref(sc), float(w), int(first), ivec(begin), ivec(end), self._stream()),
+              "examg_rbgs_sweep_fused")
+
+    # -- inter-grid -------------------------------------------------------------------------------
+    def restrict(self, lfine, rf, lc, fc, scale: float, begin, end):
+        check(self.L.examg_restrict(C.byref(lfine), self.ptr(rf), C.byref(lc), self.ptr(fc), float(scale), ivec(begin),
+                                    ivec(end), self._stream()), "examg_restrict")
+
+    def prolong_add(self, lc, uc, lfine, uf, begin, end):
+        check(self.L.examg_prolong_add(C.byref(lc), self.ptr(uc), C.byref(lfine), self.ptr(uf), ivec(begin), ivec(end),
+                                       self._stream()), "examg_prolong_add")
+
+    # -- BLAS-1 -----------------------------------------------------------------------------------
+    def set(self, l, x, v: float, begin, end):
+        check(self.L.examg_set(C.byref(l), self.ptr(x), float(v), ivec(begin), ivec(end), self._stream()), "examg_set")
+
+    def axpby(self, lx, x, ly, y, a: float, b: float, begin, end):
+        check(self.L.examg_axpby(C.byref(lx), self.ptr(x), C.byref(ly), self.ptr(y), float(a), float(b), ivec(begin),
+                                 ivec(end), self._stream()), "examg_axpby")
+
+    def axpby_dev(self, lx, x, ly, y, a: float, b: float, which: int, sign: float, num, den, begin, end):
+        check(self.L.examg_axpby_dev(C.byref(lx), self.ptr(x), C.byref(ly), self.ptr(y), float(a), float(b), int(which),
+                                     float(sign), self.ptr(num), self.ptr(den), ivec(begin), ivec(end), self._stream()),
+              "examg_axpby_dev")
+
+    # -- reductions (result stays on the device) ---------------------------------------------------
+    def dot(self, lx, x, ly, y, begin, end, out=None):
+        out = self.new_scalar() if out is None else out
+        check(self.L.examg_dot(C.byref(lx), self.ptr(x), C.byref(ly), self.ptr(y), ivec(begin), ivec(end), self.ptr(out),
+                               self.ptr(self._work), self._stream()), "examg_dot")
+        return out
+
+    def max_err_fn(self, l, x, geom, fn: int, params: Sequence[float], begin, end, out=None):
+        out = self.new_scalar() if out is None else out
+        check(self.L.examg_max_err_fn(C.byref(l), self.ptr(x), C.byref(geom), int(fn), dvec4(params), ivec(begin),
+                                      ivec(end), self.ptr(out), self.ptr(self._work), self._stream()), "examg_max_err_fn")
+        return out
+
+    def scalar_value(self, t) -> float:
+        """Host value of a device scalar (the reference's 8-byte D2H copy after a reduction)."""
+        return float(t.item())
+
+    # -- boundary / init ----------------------------------------------------------------------------
+    def fill_fn(self, l, x, geom, fn: int, params: Sequence[float], begin, end):
+        check(self.L.examg_fill_fn(C.byref(l), self.ptr(x), C.byref(geom), int(fn), dvec4(params), ivec(begin), ivec(end),
+                                   self._stream()), "examg_fill_fn")
+
+    def apply_dirichlet(self, l, x, geom, fn: int, params: Sequence[float], face_mask: int):
+        check(self.L.examg_apply_dirichlet(C.byref(l), self.ptr(x), C.byref(geom), int(fn), dvec4(params), int(face_mask),
+                                           self._stream()), "examg_apply_dirichlet")
+
+    def init_varcoeff7(self, lc, cf, geom, coef_fn: int, params: Sequence[float], begin, end):
+        check(self.L.examg_init_varcoeff7(C.byref(lc), self.ptr(cf), C.byref(geom), int(coef_fn), dvec4(params),
+                                          ivec(begin), ivec(end), self._stream()), "examg_init_varcoeff7")
+
+    # -- halo ------------------------------------------------------------------------------------------
+    def pack(self, l, x, buf, begin, end):
+        check(self.L.examg_pack(C.byref(l), self.ptr(x), self.ptr(buf), ivec(begin), ivec(end), self._stream()), "examg_pack")
+
+    def unpack(self, l, x, buf, begin, end):
+        check(self.L.examg_unpack(C.byref(l), self.ptr(x), self.ptr(buf), ivec(begin), ivec(end), self._stream()),
+              "examg_unpack")
+
+    # -- coarse solve ---------------------------------------------------------------------------------
+    def cg_coarse(self, lu, sol, lf, rhs, lr, res, lp, p, lq, ap, st: Stencil, geom, face_mask: int, max_it: int,
+                  rel_tol: float, begin, end, info):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_cg_coarse(C.byref(lu), self.ptr(sol), C.byref(lf), self.ptr(rhs), C.byref(lr), self.ptr(res),
+                                     C.byref(lp), self.ptr(p), C.byref(lq), self.ptr(ap), C.byref(sc), C.byref(geom),
+                                     int(face_mask), int(max_it), float(rel_tol), ivec(begin), ivec(end), self.ptr(info),
+                                     self._stream()), "examg_cg_coarse")
+
+    def fill_random(self, x, seed: int):
+        check(self.L.examg_fill_random(self.ptr(x), int(x.numel()), int(seed), self._stream()), "examg_fill_random")

@@ -1,0 +1,530 @@
+"""Host-side mirror of the generated multigrid programs: the functions the reference generator emits
+into User/User_<fn>.cpp (mgCycle_<lvl>, Solve_<lvl>, ResNorm_<lvl>, ...), written against the kernel
+layer (`ops`) and `communicate` / `apply bc` exactly where the ExaSlang-4 programs have them.
+
+  SolverFromL4  Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4 (= Examples/Poisson/3D_FD_Poisson_fromL4.exa4)
+                and Examples/Poisson/2D_FD_Poisson_fromL4.exa4: RBGS V(3,3), CG coarse solve.
+  SolverFromL3  Testing/Smoothers/{Jac,RBGS}.exa4, Testing/CommBasic/PureMPI.exa4,
+                Testing/SISC/3D_{Const,Var}Coeff.exa4, Testing/FMG/3D_*.exa4: slotted Jacobi (or RBGS),
+                UpResidual / Restriction / Correction / VCycle / FMG functions.
+
+Every loop is a libexamg kernel launch on the current HIP stream; reductions stay on the device until
+the program needs the number on the host (`repeat until` conditions, prints).  On a single block the
+coarse-grid CG runs as one persistent kernel (examg_cg_coarse), which makes a whole V-cycle free of
+host round trips, so it can be captured into a hipGraph (`capture_cycle`).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+from .comm import Communicator
+from .domain import RectDomain
+from .field import (FN_POLY3D, FN_ZERO, Field, Stencil, laplace_fd, laplace_unit, stencil_field_offsets)
+from .layout import FieldLayout
+
+APPLY, RESIDUAL, SMOOTH = 0, 1, 2
+
+
+def reduced_prec(x: float) -> str:
+    """printWithReducedPrec (Compiler/src/exastencils/util/ir/IR_ResolvePrintWithReducedPrec.scala:50-71):
+    std::cout at precision 4, fewer digits towards the 1e-12 zero threshold (config/Knowledge.scala:293-305)."""
+    if x <= 1.0e-12:
+        return "EFFECTIVELY ZERO"
+    if x <= 1.0e-11:
+        prec = 1
+    elif x <= 9.999999999999999e-11:
+        prec = 2
+    elif x <= 9.999999999999999e-10:
+        prec = 3
+    else:
+        prec = 4
+    return "%.*g" % (prec, x)
+
+
+class _Program:
+    """Shared plumbing: domain, kernel layer, communicator, the three statement kinds."""
+
+    def __init__(self, nd: int, min_level: int, max_level: int, frag_len, ops, domain: Optional[RectDomain], comm):
+        if ops is None:
+            from .ops import HipOps
+
+            ops = HipOps()          # raises without libexamg.so / GPU: no fallback
+        self.ops = ops
+        self.domain = domain or RectDomain(nd, (1, 1, 1), 0, frag_len)
+        self.comm = comm or Communicator(self.domain, ops)
+        self.nd, self.min_level, self.max_level = nd, min_level, max_level
+        self.levels = list(range(min_level, max_level + 1))
+        self.log: List[str] = []
+        self.res_history: List[float] = []
+        self.err_history: List[float] = []
+        self.cg_iters: List[int] = []
+        self._graphs: Dict = {}
+
+    # `loop over <field>` bounds
+    def bounds(self, f: Field, reduction: bool = False):
+        return self.domain.loop_bounds(f.layout, reduction)
+
+    # `communicate [dup|ghost of] <field>`  ->  exch<Field>_<level>(slot)
+    def communicate(self, f: Field, slot: Optional[int] = None, what: str = "all"):
+        self.comm.exchange(f, slot, what)
+
+    # `apply bc to <field>`  ->  applyBCs<Field>_<level>(slot)
+    def apply_bc(self, f: Field, slot: Optional[int] = None):
+        if f.bc_fn is None:
+            return
+        mask = self.domain.face_mask()
+        if mask:
+            self.ops.apply_dirichlet(f.lc, f.data(slot), self.domain.geom(f.level), f.bc_fn, f.bc_params, mask)
+
+    def _dot_host(self, x: Field, y: Field, over: Field, xslot=None, yslot=None) -> float:
+        b, e = self.bounds(over, reduction=True)
+        t = self.ops.dot(x.lc, x.data(xslot), y.lc, y.data(yslot), b, e)
+        return self.ops.scalar_value(self.comm.allreduce(t, "sum"))
+
+    def _single_block(self) -> bool:
+        return self.domain.world_size == 1
+
+
+# =================================================================================================
+# Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4
+# =================================================================================================
+
+
+@dataclass
+class ConfigL4:
+    nd: int = 3
+    min_level: int = 2
+    max_level: int = 9
+    frag_len: Tuple[int, int, int] = (1, 1, 1)
+    omega: float = 0.8
+    n_smooth: int = 3
+    tol: float = 1.0e-6
+    max_it: int = 100
+    cg_max: int = 128
+    cg_tol: float = 0.001
+    bc_fn: int = FN_POLY3D
+    rhs_fn: Optional[int] = None
+    sol_fn: Optional[int] = None
+    align: int = 0
+    fused_coarse: bool = True     # single block: mgCycle@coarsest as one persistent kernel
+    fused_rbgs: bool = False      # one-pass red-black sweep (out of place, pointer swap)
+
+
+class SolverFromL4(_Program):
+    def __init__(self, cfg: ConfigL4, ops=None, domain: Optional[RectDomain] = None, comm=None):
+        super().__init__(cfg.nd, cfg.min_level, cfg.max_level, cfg.frag_len, ops, domain, comm)
+        self.cfg = cfg
+        nd, dom, ops = cfg.nd, self.domain, self.ops
+        lo, hi = cfg.min_level, cfg.max_level
+        self.Solution: Dict[int, Field] = {}
+        self.RHS: Dict[int, Field] = {}
+        self.Residual: Dict[int, Field] = {}
+        self.Laplace: Dict[int, Stencil] = {}
+        self._sol_alt: Dict[int, object] = {}
+        for l in self.levels:
+            nc = dom.ncells(l)
+            with_comm = FieldLayout.node(nd, nc, 1, True, True, cfg.align)     # Layout NodeWithComm (...exa4:13-16)
+            no_ghost = FieldLayout.node(nd, nc, 0, True, False, cfg.align)     # Layout NodeNoGhost  (...exa4:18-21)
+            self.Solution[l] = Field("Solution", l, with_comm, ops, 1, cfg.bc_fn if l == hi else FN_ZERO)   # :24-25
+            self.RHS[l] = Field("RHS", l, no_ghost, ops, 1, None)                                           # :27
+            self.Residual[l] = Field("Residual", l, no_ghost if l == lo else with_comm, ops, 1, FN_ZERO)    # :29-30
+            self.Laplace[l] = laplace_fd(nd, dom.h(l), "mp", "pow")                                         # :39-47
+            if cfg.fused_rbgs and l != lo:
+                self._sol_alt[l] = ops.new_array(with_comm.size)
+        nc = dom.ncells(lo)
+        self.cgTmp0 = Field("cgTmp0", lo, FieldLayout.node(nd, nc, 1, True, True, cfg.align), ops, 1, FN_ZERO)   # :32
+        self.cgTmp1 = Field("cgTmp1", lo, FieldLayout.node(nd, nc, 0, True, False, cfg.align), ops, 1, None)     # :33
+        self._cg_info = ops.new_array(4)
+
+    # Function ResNorm@(coarsest and finest) : Real  (...exa4:113-119)
+    def ResNorm(self, l: int) -> float:
+        return math.sqrt(self._dot_host(self.Residual[l], self.Residual[l], self.Residual[l]))
+
+    def _update_residual(self, l: int):
+        S, R = self.Solution[l], self.Residual[l]
+        self.communicate(S)
+        b, e = self.bounds(R)
+        self.ops.stencil_op(RESIDUAL, S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), R.lc, R.data(), self.Laplace[l],
+                            0.0, -1, b, e)
+        self.apply_bc(R)
+
+    # Function Application (...exa4:251-277): init part
+    def setup(self):
+        cfg, hi = self.cfg, self.cfg.max_level
+        if cfg.rhs_fn is not None:      # InitRHS@finest (Examples/Poisson/2D_FD_Poisson_fromL4.exa4:231-235)
+            f = self.RHS[hi]
+            b, e = self.bounds(f)
+            self.ops.fill_fn(f.lc, f.data(), self.domain.geom(hi), cfg.rhs_fn, (), b, e)
+        self.apply_bc(self.Solution[hi])
+
+    # Function Solve@finest (...exa4:121-150)
+    def Solve(self, use_graph: bool = False) -> int:
+        cfg, hi = self.cfg, self.cfg.max_level
+        self._update_residual(hi)
+        initRes = self.ResNorm(hi)
+        curRes = initRes
+        self.res_history.append(initRes)
+        self.log.append(reduced_prec(initRes))
+        curIt = 0
+        while not (curIt >= cfg.max_it or curRes <= cfg.tol * initRes):
+            curIt += 1
+            if use_graph:
+                self.replay_cycle()
+            else:
+                self.mgCycle(hi)
+            if cfg.sol_fn is not None:  # PrintError@finest (2-D example :83-95)
+                S = self.Solution[hi]
+                b, e = self.bounds(S)
+                t = self.ops.max_err_fn(S.lc, S.data(), self.domain.geom(hi), cfg.sol_fn, (), b, e)
+                err = self.ops.scalar_value(self.comm.allreduce(t, "max"))
+                self.err_history.append(err)
+                self.log.append(reduced_prec(err))
+            self._update_residual(hi)
+            curRes = self.ResNorm(hi)
+            self.res_history.append(curRes)
+            self.log.append(reduced_prec(curRes))
+        self.iterations = curIt
+        return curIt
+
+    # repeat 3 times { color with { (i0+i1+i2) % 2, communicate; loop over Solution {...}; apply bc } }  (:204-213)
+    def _smooth(self, l: int):
+        S, F, A = self.Solution[l], self.RHS[l], self.Laplace[l]
+        w = self.cfg.omega / A.diag           # `0.8 / diag(Laplace)`, folded to a literal by the generator
+        b, e = self.bounds(S)
+        if self.cfg.fused_rbgs and self._single_block():
+            # one pass per sweep; the exchange is empty on one block and `apply bc` re-writes values that the
+            # sweep copies through unchanged, so the two half sweeps fuse without changing any bit
+            for _ in range(self.cfg.n_smooth):
+                alt = self._sol_alt[l]
+                self.ops.rbgs_sweep_fused(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e)
+                self._sol_alt[l], S.slots[0] = S.slots[0], alt
+            return
+        for _ in range(self.cfg.n_smooth):
+            for colour in (0, 1):
+                self.communicate(S)
+                self.ops.stencil_op(SMOOTH, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, w, colour, b, e)
+                self.apply_bc(S)
+
+    # Function mgCycle@(all but coarsest) (...exa4:203-249)
+    def mgCycle(self, l: int):
+        if l == self.cfg.min_level:
+            return self.mgCycle_coarsest(l)
+        ops = self.ops
+        self._smooth(l)
+        self._update_residual(l)
+        R, Fc = self.Residual[l], self.RHS[l - 1]
+        self.communicate(R)
+        b, e = self.bounds(Fc)
+        ops.restrict(R.lc, R.data(), Fc.lc, Fc.data(), 1.0, b, e)
+        Sc, S = self.Solution[l - 1], self.Solution[l]
+        b, e = self.bounds(Sc)
+        ops.set(Sc.lc, Sc.data(), 0.0, b, e)
+        self.apply_bc(Sc)
+        self.mgCycle(l - 1)
+        self.communicate(Sc)
+        b, e = self.bounds(S)
+        ops.prolong_add(Sc.lc, Sc.data(), S.lc, S.data(), b, e)
+        self.apply_bc(S)
+        self._smooth(l)
+
+    # Function mgCycle@coarsest (...exa4:152-201)
+    def mgCycle_coarsest(self, l: int):
+        ops, A = self.ops, self.Laplace[l]
+        Sol, Res, F, p_, Ap = self.Solution[l], self.Residual[l], self.RHS[l], self.cgTmp0, self.cgTmp1
+        if self.cfg.fused_coarse and self._single_block():
+            b, e = self.bounds(Sol)
+            ops.cg_coarse(Sol.lc, Sol.data(), F.lc, F.data(), Res.lc, Res.data(), p_.lc, p_.data(), Ap.lc, Ap.data(), A,
+                          self.domain.geom(l), self.domain.face_mask(), self.cfg.cg_max, self.cfg.cg_tol, b, e, self._cg_info)
+            return
+        self._update_residual(l)
+        curRes = self.ResNorm(l)
+        initRes = curRes
+        b, e = self.bounds(p_)
+        ops.axpby(Res.lc, Res.data(), p_.lc, p_.data(), 1.0, 0.0, b, e)        # cgTmp0 = Residual
+        self.apply_bc(p_)
+        for step in range(self.cfg.cg_max):
+            self.communicate(p_)
+            b, e = self.bounds(Ap)
+            ops.stencil_op(APPLY, p_.lc, p_.data(), None, None, Ap.lc, Ap.data(), A, 0.0, -1, b, e)
+            alphaNom = self._dot_host(Res, Res, Res)
+            alphaDenom = self._dot_host(p_, Ap, p_)
+            alpha = alphaNom / alphaDenom if alphaDenom != 0.0 else float("nan")
+            b, e = self.bounds(Sol)
+            ops.axpby(p_.lc, p_.data(), Sol.lc, Sol.data(), alpha, 1.0, b, e)  # Solution += alpha * cgTmp0
+            self.apply_bc(Sol)
+            b, e = self.bounds(Res)
+            ops.axpby(Ap.lc, Ap.data(), Res.lc, Res.data(), -alpha, 1.0, b, e)  # Residual -= alpha * cgTmp1
+            self.apply_bc(Res)
+            nextRes = self.ResNorm(l)
+            if nextRes <= self.cfg.cg_tol * initRes:
+                self.cg_iters.append(step + 1)
+                return
+            beta = (nextRes * nextRes) / (curRes * curRes)
+            b, e = self.bounds(p_)
+            ops.axpby(Res.lc, Res.data(), p_.lc, p_.data(), 1.0, beta, b, e)   # cgTmp0 = Residual + beta * cgTmp0
+            self.apply_bc(p_)
+            curRes = nextRes
+        self.cg_iters.append(self.cfg.cg_max)
+        self.log.append("Maximum number of cgs iterations (%d) was exceeded" % self.cfg.cg_max)
+
+    # -- hipGraph capture of one V-cycle (single block, fused coarse solve: no host round trips) ----
+    def capture_cycle(self):
+        if not (self._single_block() and self.cfg.fused_coarse):
+            raise RuntimeError("graph capture needs a single block and the fused coarse solve")
+        torch = self.ops.torch
+        hi = self.cfg.max_level
+        n_swaps = self.cfg.n_smooth * 2 if self.cfg.fused_rbgs else 0
+        if n_swaps % 2:
+            raise RuntimeError("graph capture with the fused sweep needs an even number of pointer swaps per cycle")
+        s = torch.cuda.Stream(self.ops.device)
+        s.wait_stream(torch.cuda.current_stream(self.ops.device))
+        with torch.cuda.stream(s):
+            self.mgCycle(hi)      # warm-up outside capture (lazy allocations)
+        torch.cuda.current_stream(self.ops.device).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.mgCycle(hi)
+        self._graphs["cycle"] = g
+        return g
+
+    def replay_cycle(self):
+        self._graphs["cycle"].replay()
+
+
+# =================================================================================================
+# Testing/Smoothers/Jac.exa4 and relatives
+# =================================================================================================
+
+
+@dataclass
+class ConfigL3:
+    nd: int = 3
+    min_level: int = 0
+    max_level: int = 4
+    frag_len: Tuple[int, int, int] = (1, 1, 1)
+    smoother: str = "jacobi"            # 'jacobi' (2 slots) | 'rbgs'
+    omega: float = 0.8
+    n_smooth: int = 3
+    stencil: str = "unit"               # 'unit' | 'scaled' | 'varcoeff'
+    restrict_scale: float = 4.0
+    tol: float = 1.0e-5
+    max_it: int = 100
+    cg_max: int = 512
+    cg_tol: float = 0.001
+    bc_fn: int = FN_POLY3D
+    rhs_fn: Optional[int] = None
+    sol_fn: Optional[int] = None
+    coef_fn: Optional[int] = None
+    kappa: float = 10.0
+    fmg: bool = False
+    align: int = 0
+
+
+class SolverFromL3(_Program):
+    def __init__(self, cfg: ConfigL3, ops=None, domain: Optional[RectDomain] = None, comm=None):
+        super().__init__(cfg.nd, cfg.min_level, cfg.max_level, cfg.frag_len, ops, domain, comm)
+        self.cfg = cfg
+        nd, dom, ops = cfg.nd, self.domain, self.ops
+        lo, hi = cfg.min_level, cfg.max_level
+        nslots = 2 if cfg.smoother == "jacobi" else 1
+        prm = (cfg.kappa,)
+        self.Solution: Dict[int, Field] = {}
+        self.RHS: Dict[int, Field] = {}
+        self.Residual: Dict[int, Field] = {}
+        self.Laplace: Dict[int, Stencil] = {}
+        for l in self.levels:
+            nc = dom.ncells(l)
+            basic = FieldLayout.node(nd, nc, 1, True, True, cfg.align)       # BasicComm / CommFullTempBlockable
+            nocomm = FieldLayout.node(nd, nc, 0, False, False, cfg.align)    # NoComm / CommPartTempBlockable / NoCommSF
+            self.Solution[l] = Field("Solution", l, basic, ops, nslots, cfg.bc_fn if l == hi else FN_ZERO, prm)
+            self.RHS[l] = Field("RHS", l, nocomm, ops, 1, None)
+            self.Residual[l] = Field("Residual", l, basic, ops, 1, FN_ZERO)
+            if cfg.stencil == "unit":
+                self.Laplace[l] = laplace_unit(nd)
+            elif cfg.stencil == "scaled":
+                self.Laplace[l] = laplace_fd(nd, dom.h(l), "pm", "mul")
+            else:   # InitLaplace@l (Testing/SISC/3D_VarCoeff.exa4:206-217)
+                cf = ops.new_array((2 * nd + 1) * nocomm.size)
+                b, e = dom.loop_bounds(nocomm)
+                ops.init_varcoeff7(nocomm.c_struct(), cf, dom.geom(l), cfg.coef_fn, prm, b, e)
+                self.Laplace[l] = Stencil(stencil_field_offsets(nd), [], cf, nocomm)
+        nc = dom.ncells(lo)
+        self.VecP = Field("VecP", lo, FieldLayout.node(nd, nc, 1, True, True, cfg.align), ops, 1, FN_ZERO)
+        self.VecGradP = Field("VecGradP", lo, FieldLayout.node(nd, nc, 0, False, False, cfg.align), ops, 1, None)
+
+    def _w(self, l: int) -> float:
+        if self.cfg.stencil == "varcoeff":
+            return self.cfg.omega                       # kernel forms (1.0 / diag) * omega per point
+        return (1.0 / self.Laplace[l].diag) * self.cfg.omega
+
+    # Function UpResidual@all
+    def UpResidual(self, l: int):
+        S, R, F = self.Solution[l], self.Residual[l], self.RHS[l]
+        self.communicate(S, S.active)
+        b, e = self.bounds(R)
+        self.ops.stencil_op(RESIDUAL, S.lc, S.data(), F.lc, F.data(), R.lc, R.data(), self.Laplace[l], 0.0, -1, b, e)
+
+    # Function NormResidual_0@(finest, coarsest) : Real
+    def NormResidual(self, l: int) -> float:
+        R = self.Residual[l]
+        return math.sqrt(self._dot_host(R, R, R))
+
+    # Function NormError_0@finest : Real
+    def NormError(self, l: int) -> float:
+        S = self.Solution[l]
+        b, e = self.bounds(S, reduction=True)
+        t = self.ops.max_err_fn(S.lc, S.data(), self.domain.geom(l), self.cfg.sol_fn, (self.cfg.kappa,), b, e)
+        return self.ops.scalar_value(self.comm.allreduce(t, "max"))
+
+    # Function Smoother@((coarsest + 1) to finest)
+    def Smoother(self, l: int):
+        S, F, A = self.Solution[l], self.RHS[l], self.Laplace[l]
+        b, e = self.bounds(S)
+        if self.cfg.smoother == "jacobi":       # Testing/Smoothers/Jac.exa4:125-131
+            self.communicate(S, S.active, "ghost")
+            self.ops.stencil_op(SMOOTH, S.lc, S.data(S.active), F.lc, F.data(), S.lc, S.data(S.next), A, self._w(l), -1, b, e)
+            S.advance()
+        else:                                   # Testing/Smoothers/RBGS.exa4:125-133
+            for colour in (0, 1):
+                self.communicate(S, S.active)
+                self.ops.stencil_op(SMOOTH, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, self._w(l), colour, b, e)
+
+    # Function Restriction / Correction / SetSolution
+    def Restriction(self, l: int):
+        R, Fc = self.Residual[l], self.RHS[l - 1]
+        self.communicate(R, None, "ghost")
+        b, e = self.bounds(Fc)
+        self.ops.restrict(R.lc, R.data(), Fc.lc, Fc.data(), self.cfg.restrict_scale, b, e)
+
+    def Correction(self, l: int):
+        Sc, S = self.Solution[l - 1], self.Solution[l]
+        self.communicate(Sc, Sc.active, "ghost")
+        b, e = self.bounds(S)
+        self.ops.prolong_add(Sc.lc, Sc.data(), S.lc, S.data(), b, e)
+
+    def SetSolution(self, l: int, v: float):
+        S = self.Solution[l]
+        b, e = self.bounds(S)
+        self.ops.set(S.lc, S.data(), v, b, e)
+
+    # Function VCycle@((coarsest + 1) to finest)
+    def VCycle(self, l: int):
+        if l == self.cfg.min_level:
+            return self.VCycle_0(l)
+        for _ in range(self.cfg.n_smooth):
+            self.Smoother(l)
+        self.UpResidual(l)
+        self.Restriction(l)
+        self.SetSolution(l - 1, 0.0)
+        self.VCycle(l - 1)
+        self.Correction(l)
+        for _ in range(self.cfg.n_smooth):
+            self.Smoother(l)
+
+    # Function VCycle_0@coarsest (Testing/Smoothers/Jac.exa4:75-109)
+    def VCycle_0(self, l: int):
+        ops, A = self.ops, self.Laplace[l]
+        S, R, P, GP = self.Solution[l], self.Residual[l], self.VecP, self.VecGradP
+        self.UpResidual(l)
+        self.communicate(R)
+        res = self.NormResidual(l)
+        initialRes = res
+        b, e = self.bounds(P)
+        ops.axpby(R.lc, R.data(), P.lc, P.data(), 1.0, 0.0, b, e)
+        for step in range(self.cfg.cg_max):
+            self.communicate(P)
+            b, e = self.bounds(P)
+            ops.stencil_op(APPLY, P.lc, P.data(), None, None, GP.lc, GP.data(), A, 0.0, -1, b, e)
+            alphaDenom = self._dot_host(P, GP, P)
+            alpha = (res * res) / alphaDenom if alphaDenom != 0.0 else float("nan")
+            b, e = self.bounds(S)
+            ops.axpby(P.lc, P.data(), S.lc, S.data(), alpha, 1.0, b, e)
+            ops.axpby(GP.lc, GP.data(), R.lc, R.data(), -alpha, 1.0, b, e)
+            nextRes = self.NormResidual(l)
+            if nextRes <= self.cfg.cg_tol * initialRes:
+                self.cg_iters.append(step + 1)
+                return
+            beta = (nextRes * nextRes) / (res * res)
+            b, e = self.bounds(P)
+            ops.axpby(R.lc, R.data(), P.lc, P.data(), 1.0, beta, b, e)
+            res = nextRes
+        self.cg_iters.append(self.cfg.cg_max)
+        self.log.append("Maximum number of cgs iterations (%d) was exceeded" % self.cfg.cg_max)
+
+    # -- FMG (Testing/FMG/3D_Trigonometric.exa4:189-242) -------------------------------------------
+    def SetFuncDir(self, l: int):
+        """`loop over Solution<s> only dup [dir] on boundary`: duplicate plane of each physical face, DLB..DRE
+        tangentially (baseExt/ir/IR_LoopOverPointsInOneFragment.scala:57-70)."""
+        S, lay, dom = self.Solution[l], self.Solution[l].layout, self.domain
+        for d in range(dom.nd):
+            for side in (-1, 1):
+                if dom.neighbor(d, side) is not None:
+                    continue
+                b, e = [0, 0, 0], [1, 1, 1]
+                for t in range(dom.nd):
+                    if t == d:
+                        b[t], e[t] = (lay.idx("DLB", t), lay.idx("DLE", t)) if side < 0 else (lay.idx("DRB", t), lay.idx("DRE", t))
+                    else:
+                        b[t], e[t] = lay.idx("DLB", t), lay.idx("DRE", t)
+                for s_ in range(S.num_slots):
+                    self.ops.fill_fn(S.lc, S.data(s_), dom.geom(l), self.cfg.bc_fn, (self.cfg.kappa,), b, e)
+
+    def InitRHS(self, l: int):
+        F = self.RHS[l]
+        b, e = self.bounds(F)
+        if self.cfg.rhs_fn is not None:
+            self.ops.fill_fn(F.lc, F.data(), self.domain.geom(l), self.cfg.rhs_fn, (self.cfg.kappa,), b, e)
+        else:
+            self.ops.set(F.lc, F.data(), 0.0, b, e)
+
+    def ResetBC(self, l: int):
+        for s_ in range(self.Solution[l].num_slots):
+            self.apply_bc(self.Solution[l], s_)
+
+    def FMG(self, l: int):
+        self.SetFuncDir(l)
+        self.InitRHS(l)
+        self.VCycle(l)
+        self.Correction(l + 1)
+        self.ResetBC(l)
+        if l != self.cfg.max_level - 1:
+            self.FMG(l + 1)
+
+    # Function Application: init part
+    def setup(self):
+        cfg, hi = self.cfg, self.cfg.max_level
+        if cfg.rhs_fn is not None:
+            self.InitRHS(hi)
+        for l in self.levels:
+            for s_ in range(self.Solution[l].num_slots):
+                self.apply_bc(self.Solution[l], s_)
+        self.apply_bc(self.VecP)
+
+    # Function Solve
+    def Solve(self) -> int:
+        cfg, hi = self.cfg, self.cfg.max_level
+        self.UpResidual(hi)
+        resStart = self.NormResidual(hi)
+        res = resStart
+        self.res_history.append(res)
+        self.log.append(reduced_prec(res))
+        if cfg.fmg:
+            self.FMG(cfg.min_level)
+        numIt = 0
+        while not (res < cfg.tol * resStart or numIt >= cfg.max_it):
+            numIt += 1
+            self.VCycle(hi)
+            self.UpResidual(hi)
+            res = self.NormResidual(hi)
+            self.res_history.append(res)
+            if cfg.sol_fn is not None:
+                err = self.NormError(hi)
+                self.err_history.append(err)
+                self.log.append(reduced_prec(err))
+            else:
+                self.log.append(reduced_prec(res))
+        self.log.append(str(numIt))
+        self.iterations = numIt
+        return numIt

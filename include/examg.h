@@ -1,0 +1,205 @@
+/*
+ * examg.h -- C ABI of libexamg: the MI355X (gfx950) multigrid hot path that drops in where
+ * ExaStencils' generated CUDA kernel wrappers sit.
+ *
+ * What this replaces.  For every device-eligible `loop over` the reference generator prints
+ *     extern "C" void <fn>_k<NNN>_wrapper(<pass-through args>[, double* reductionTmp])
+ * into Kernel/Kernel_<fn>_k<NNN>.cu (Compiler/src/exastencils/parallelization/api/cuda/
+ * CUDA_Kernel.scala:546-632, naming CUDA_KernelFunctions.scala:78-110, call site
+ * CUDA_ExtractDeviceCode.scala:262-280), called from generated host functions mgCycle_<lvl>(),
+ * Solve_<lvl>() on process-global device arrays fieldDeviceData_<F>[lvl][slot]
+ * (cuda/CUDA_Memory.scala:121-141) laid out as IR_FieldLayout prescribes
+ * (field/ir/IR_FieldLayout.scala:30-129).  The <NNN> numbering is an artefact of strategy order,
+ * so this header defines one *semantic* entry point per kind of emitted loop; INTEGRATION.md shows
+ * the one-line `_wrapper` shims a maintainer adds to bind them.
+ *
+ * Conventions (same as the generated code):
+ *   - all pointers are DEVICE pointers owned by the caller (setupBuffers()/destroyGlobals(),
+ *     globals/ir/IR_AddInternalVariables.scala:115-182); nothing here allocates or frees;
+ *   - fields are raw double arrays in the reference layout, x fastest
+ *     (baseExt/ir/IR_Linearization.scala:27-36); `examg_layout_t` carries the per-dimension
+ *     pad|ghost|dup|inner|dup|ghost|pad counts, referenceOffset = pad_l + ghost_l;
+ *   - loop bounds `begin`/`end` are in iterator coordinates (0 = lower duplicate node), half-open,
+ *     exactly the `_cu_begin_d`/`_cu_end_d` kernel arguments (cuda/CUDA_Kernel.scala:364-393) that
+ *     baseExt/ir/IR_LoopOverPointsInOneFragment.scala:84-101 computes; unused dims use [0,1);
+ *   - `stream` is a hipStream_t (cuda/CUDA_Stream.scala:96-202); launches are asynchronous and
+ *     capturable into a hipGraph; no call synchronises the device;
+ *   - return value: 0 on success, non-zero on error with a message in examg_last_error().
+ *     (The reference wrappers are void and print+exit on error, cuda/CUDA_Error.scala; the
+ *     reference-named shims in INTEGRATION.md reproduce that on top of these.)
+ *   - arithmetic: fp64, each statement evaluated in the order the generator prints it
+ *     (stencil entries folded left to right, stencil/ir/IR_StencilConvolution.scala:65-68),
+ *     no FMA contraction -- point-wise results are bit-identical to the CPU path.
+ */
+#ifndef EXAMG_H
+#define EXAMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXAMG_MAX_ENTRIES 27
+
+/* field/ir/IR_FieldLayout.scala:103-129 (IR_FieldLayoutPerDim). Unused dims: inner = 1, rest 0. */
+typedef struct examg_layout {
+  int32_t nd;
+  int32_t pad_l[3], ghost_l[3], dup_l[3], inner[3], dup_r[3], ghost_r[3], pad_r[3];
+} examg_layout_t;
+
+/* operator/ir/IR_Stencil.scala:34-211 (constant coefficients, entry order significant) or a
+ * stencil field whose entry index is the slowest array dimension
+ * (stencil/ir/IR_StencilConvolution.scala:73-95): cfield[k * size(clayout) + linear(clayout, i)]. */
+typedef struct examg_stencil {
+  int32_t nent;
+  int32_t diag; /* index of the (0,0,0) entry, `diag(A)` */
+  int32_t off[EXAMG_MAX_ENTRIES][3];
+  double coef[EXAMG_MAX_ENTRIES];
+  const double *cfield; /* device pointer or NULL */
+  examg_layout_t clayout;
+} examg_stencil_t;
+
+/* Uniform node grid of one fragment at one level: position = index * h + pos_begin
+ * (grid/ir/IR_VF_NodePosition.scala:109-111, domain/ir/IR_DomainFromAABB.scala:31-40). */
+typedef struct examg_geom {
+  double pos_begin[3];
+  double h[3];
+} examg_geom_t;
+
+typedef void *examg_stream_t; /* hipStream_t */
+
+/* `params` arguments below: HOST pointer to 4 doubles (params[0] = kappa of the SISC/FMG
+ * programs' `Globals { Val kappa }`), or NULL for all-zero. */
+
+/* stencil loop kinds */
+enum { EXAMG_APPLY = 0, EXAMG_RESIDUAL = 1, EXAMG_SMOOTH = 2 };
+
+/* analytic functions of the reference programs (boundary values, RHS, exact solutions,
+ * coefficient profiles); ids shared with oracle/examg_oracle.c */
+enum {
+  EXAMG_FN_ZERO = 0,
+  EXAMG_FN_POLY3D = 1,       /* x^2 - y^2/2 - z^2/2        Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:25 */
+  EXAMG_FN_TRIG2D_SOL = 2,   /* cos(pi x) - sin(2 pi y)     Examples/Poisson/2D_FD_Poisson_fromL4.exa4:26 */
+  EXAMG_FN_TRIG2D_RHS = 3,   /* pi^2 cos(pi x) - 4 pi^2 sin(2 pi y)   ...exa4:233 */
+  EXAMG_FN_KAPPA_POLY = 4,   /* kappa (x-x^2)(y-y^2)(z-z^2)           Testing/SISC/3D_ConstCoeff.exa4:43 */
+  EXAMG_FN_KAPPA_RHS = 5,    /* Testing/SISC/3D_VarCoeff.exa4 InitRHS */
+  EXAMG_FN_KAPPA_EXPSOL = 6, /* 1 - exp(-kappa (..))                  Testing/SISC/3D_VarCoeff.exa4:48 */
+  EXAMG_FN_KAPPA_COEF = 7,   /* exp(kappa (..))                       Testing/SISC/3D_VarCoeff.exa4 getCoefficient */
+  EXAMG_FN_TRIG3D_SOL = 8,   /* sin(pi x) sin(pi y) sinh(sqrt2 pi z)  Testing/FMG/3D_Trigonometric.exa4:43 */
+  EXAMG_FN_SIN3 = 9,
+  EXAMG_FN_KAPPA_POLY2D = 10,
+  EXAMG_FN_KAPPA_RHS2D = 11,
+  EXAMG_FN_KAPPA_EXPSOL2D = 12,
+  EXAMG_FN_KAPPA_COEF2D = 13
+};
+
+int examg_version(void);
+const char *examg_last_error(void);
+/* Number of visible HIP devices (cuda/CUDA_AddGlobals.scala:30-48 does cudaGetDeviceCount). */
+int examg_device_count(void);
+
+/* ---- K1/K2/K3: stencil loops ---------------------------------------------
+ * mode EXAMG_APPLY    : dst = A*u                       (cgTmp1 = Laplace * cgTmp0, ...exa4:166-168)
+ *      EXAMG_RESIDUAL : dst = rhs - A*u                 (Residual = RHS - Laplace * Solution, :215-219)
+ *      EXAMG_SMOOTH   : dst = u + ww * (rhs - A*u)      (Jacobi, Testing/Smoothers/Jac.exa4:125-131;
+ *                       with colour >= 0 and dst == u: one red-black half sweep, ...exa4:204-213)
+ *   ww = w for constant stencils (w is the folded constant omega/diag(A));
+ *   ww = (1.0 / cfield[diag]) * w for stencil fields (w = omega, Testing/SISC/3D_VarCoeff.exa4:145).
+ * colour: -1 = all points, else only points with (i0+i1+i2) % 2 == colour
+ *   (baseExt/l4/L4_ColorLoops.scala:44-66; condition emitted by IR_LoopOverDimensions.scala:215-216).
+ * u and dst may alias only when colour >= 0 (or for disjoint boxes). */
+int examg_stencil_op(int mode, const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs,
+                     const examg_layout_t *ld, double *dst, const examg_stencil_t *st, double w, int colour,
+                     const int32_t *begin, const int32_t *end, examg_stream_t stream);
+
+/* Names of SURVEY.md 8b; thin forms of examg_stencil_op. */
+int examg_jacobi(const examg_layout_t *lu, const double *u, double *u_next, const examg_layout_t *lf, const double *rhs,
+                 const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end, examg_stream_t stream);
+int examg_rbgs_colour(const examg_layout_t *lu, double *u, const examg_layout_t *lf, const double *rhs,
+                      const examg_stencil_t *st, double w, int colour, const int32_t *begin, const int32_t *end,
+                      examg_stream_t stream);
+int examg_residual(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs,
+                   const examg_layout_t *lr, double *res, const examg_stencil_t *st, const int32_t *begin,
+                   const int32_t *end, examg_stream_t stream);
+
+/* One full red-black sweep (colour `first`, then the other) out of place: u_out receives exactly
+ * what two examg_rbgs_colour calls on u_in would leave in the box [begin,end); points of the
+ * u_in box's one-point shell (duplicate/ghost layers, Dirichlet values) are copied through so that
+ * u_out can take u_in's place (pointer swap by the caller).  24 B/LU instead of 48 B/LU. */
+int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_in, double *u_out, const examg_layout_t *lf,
+                           const double *rhs, const examg_stencil_t *st, double w, int first, const int32_t *begin,
+                           const int32_t *end, examg_stream_t stream);
+
+/* ---- K4: RHS@coarser = scale * R * Residual, R = kron [1/4 1/2 1/4]
+ * (operator/l4/L4_DefaultRestriction.scala:29-36,63-88; solver/ir/IR_ResolveIntergridIndices.scala);
+ * begin/end: coarse iterator box. */
+int examg_restrict(const examg_layout_t *lfine, const double *res_fine, const examg_layout_t *lcoarse,
+                   double *rhs_coarse, double scale, const int32_t *begin, const int32_t *end,
+                   examg_stream_t stream);
+
+/* ---- K5: Solution += P@coarser * Solution@coarser, P = 2^d R^T
+ * (operator/l4/L4_DefaultProlongation.scala:30-45; parity cases
+ * stencil/ir/IR_FindStencilConvolutions.scala:135-156); begin/end: fine iterator box. */
+int examg_prolong_add(const examg_layout_t *lcoarse, const double *u_coarse, const examg_layout_t *lfine,
+                      double *u_fine, const int32_t *begin, const int32_t *end, examg_stream_t stream);
+
+/* ---- K6: BLAS-1 loops (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:160-198, 226-229) */
+int examg_set(const examg_layout_t *l, double *x, double v, const int32_t *begin, const int32_t *end,
+              examg_stream_t stream);
+/* y = a*x + b*y, evaluated as the reference statements are written:
+ * b==0: a*x (copy for a==1);  b==1: y + a*x;  a==1: x + b*y. */
+int examg_axpby(const examg_layout_t *lx, const double *x, const examg_layout_t *ly, double *y, double a, double b,
+                const int32_t *begin, const int32_t *end, examg_stream_t stream);
+/* As examg_axpby with a = sign * (*num / *den) or b = (*num / *den) read from device memory
+ * (CG's alpha and beta without a host round trip); which: 0 => a, 1 => b. */
+int examg_axpby_dev(const examg_layout_t *lx, const double *x, const examg_layout_t *ly, double *y, double a,
+                    double b, int which, double sign, const double *num, const double *den, const int32_t *begin,
+                    const int32_t *end, examg_stream_t stream);
+
+/* ---- K7: reductions (`loop over ... with reduction`, ...exa4:113-119; replaces
+ * cuda/CUDA_Reduction.scala:84-131 + DefaultReductionKernel, cuda/CUDA_KernelFunctions.scala:112-238).
+ * Result (one double) is written to device memory `result`; `work` is caller-owned scratch of
+ * examg_reduce_work_bytes() bytes.  Deterministic (fixed tree) for a fixed box. */
+size_t examg_reduce_work_bytes(void);
+int examg_dot(const examg_layout_t *lx, const double *x, const examg_layout_t *ly, const double *y,
+              const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream);
+int examg_max_err_fn(const examg_layout_t *l, const double *x, const examg_geom_t *g, int fn, const double *params,
+                     const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream);
+
+/* ---- K8: x[box] = fn(node position): Dirichlet faces (boundary/ir/IR_DirichletBC.scala:37-40 over
+ * the ranges of boundary/ir/IR_ApplyBCFunction.scala:53-83), InitRHS, SetFuncDir. */
+int examg_fill_fn(const examg_layout_t *l, double *x, const examg_geom_t *g, int fn, const double *params,
+                  const int32_t *begin, const int32_t *end, examg_stream_t stream);
+/* All faces of `apply bc` in one launch: face_mask bit (2*d + (side>0)) set => that face has no
+ * neighbour (IR_IV_NeighborIsValid false) and gets its duplicate plane, tangentially GLB..GRE, set. */
+int examg_apply_dirichlet(const examg_layout_t *l, double *x, const examg_geom_t *g, int fn, const double *params,
+                          uint32_t face_mask, examg_stream_t stream);
+/* Stencil-field initialisation of Testing/SISC/3D_VarCoeff.exa4:206-217 (2*nd+1 entries). */
+int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,
+                         const double *params, const int32_t *begin, const int32_t *end, examg_stream_t stream);
+
+/* ---- K9: halo pack / unpack (communication/ir/IR_NoInterpPacking.scala:53-83): box <-> contiguous
+ * buffer, x fastest; ranges from IR_PackInfoDuplicate.scala:15-39 / IR_PackInfoGhost.scala:13-60. */
+int examg_pack(const examg_layout_t *l, const double *x, double *buf, const int32_t *begin, const int32_t *end,
+               examg_stream_t stream);
+int examg_unpack(const examg_layout_t *l, double *x, const double *buf, const int32_t *begin, const int32_t *end,
+                 examg_stream_t stream);
+
+/* ---- a-16: coarse-grid CG, mgCycle@coarsest (...exa4:152-201) as ONE persistent single-workgroup
+ * kernel (no host round trips).  Fields in the reference layout; `scratch` >= 8 doubles.
+ * info[0] = iterations, info[1] = initial residual, info[2] = final residual (device). */
+int examg_cg_coarse(const examg_layout_t *lu, double *sol, const examg_layout_t *lf, const double *rhs,
+                    const examg_layout_t *lr, double *res, const examg_layout_t *lp, double *p,
+                    const examg_layout_t *lq, double *ap, const examg_stencil_t *st, const examg_geom_t *g,
+                    uint32_t face_mask, int max_it, double rel_tol, const int32_t *begin, const int32_t *end,
+                    double *info, examg_stream_t stream);
+
+/* Deterministic synthetic field (SplitMix64 of the linear index, U(-1,1)); same bits as the oracle's. */
+int examg_fill_random(double *x, int64_t n, uint64_t seed, examg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXAMG_H */

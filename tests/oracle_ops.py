@@ -1,0 +1,143 @@
+"""TEST-ONLY kernel layer backed by the CPU oracle (oracle/examg_oracle.c) on CPU torch tensors.
+
+It lets the product's host logic (exastencils_amd.solver / comm / domain) run without a GPU -- in the
+`-m "not gpu"` suite and in the world_size-2 gloo tests -- with the oracle standing in for the HIP
+kernels.  It is never imported by the package itself.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from oracle import mg
+
+
+def _lp(l):
+    return C.cast(C.pointer(l), C.POINTER(mg.LayoutC))
+
+
+def _gp(g):
+    return C.cast(C.pointer(g), C.POINTER(mg.GeomC))
+
+
+def _iv(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def _p4(params):
+    v = list(params) + [0.0] * (4 - len(params))
+    return (C.c_double * 4)(*v[:4])
+
+
+class OracleOps:
+    name = "oracle"
+
+    def __init__(self):
+        self.L = mg.lib()
+        self.torch = torch
+        self.device = torch.device("cpu")
+
+    def new_array(self, n):
+        return torch.zeros(int(n), dtype=torch.float64)
+
+    def new_scalar(self):
+        return torch.zeros(1, dtype=torch.float64)
+
+    @staticmethod
+    def ptr(t):
+        return t.data_ptr()
+
+    def synchronize(self):
+        pass
+
+    def to_host(self, t):
+        return t.numpy()
+
+    def from_host(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def _st(self, st):
+        s = mg.StencilC()
+        s.nent = len(st.offsets)
+        s.diag = st.diag_index
+        for k, o in enumerate(st.offsets):
+            for d in range(3):
+                s.off[k][d] = o[d]
+            s.coef[k] = st.coefs[k] if st.coefs else 0.0
+        if st.cfield is not None:
+            s.cfield = st.cfield.data_ptr()
+            lc = st.clayout.c_struct()
+            C.memmove(C.byref(s.clayout), C.byref(lc), C.sizeof(mg.LayoutC))
+        else:
+            s.cfield = None
+        return s
+
+    def stencil_op(self, mode, lu, u, lf, rhs, ld, dst, st, w, colour, begin, end):
+        sc = self._st(st)
+        self.L.orc_stencil_op(mode, _lp(lu), self.ptr(u), _lp(lf) if lf is not None else None,
+                              self.ptr(rhs) if rhs is not None else None, _lp(ld), self.ptr(dst), C.byref(sc), float(w),
+                              int(colour), _iv(begin), _iv(end))
+
+    def rbgs_sweep_fused(self, lu, u_in, u_out, lf, rhs, st, w, first, begin, end):
+        u_out.copy_(u_in)
+        for c in (first, 1 - first):
+            self.stencil_op(2, lu, u_out, lf, rhs, lu, u_out, st, w, c, begin, end)
+
+    def restrict(self, lfine, rf, lc, fc, scale, begin, end):
+        self.L.orc_restrict(_lp(lfine), self.ptr(rf), _lp(lc), self.ptr(fc), float(scale), _iv(begin), _iv(end))
+
+    def prolong_add(self, lc, uc, lfine, uf, begin, end):
+        self.L.orc_prolong_add(_lp(lc), self.ptr(uc), _lp(lfine), self.ptr(uf), _iv(begin), _iv(end))
+
+    def set(self, l, x, v, begin, end):
+        self.L.orc_set(_lp(l), self.ptr(x), float(v), _iv(begin), _iv(end))
+
+    def axpby(self, lx, x, ly, y, a, b, begin, end):
+        self.L.orc_axpby(_lp(lx), self.ptr(x), _lp(ly), self.ptr(y), float(a), float(b), _iv(begin), _iv(end))
+
+    def dot(self, lx, x, ly, y, begin, end, out=None):
+        out = self.new_scalar() if out is None else out
+        out[0] = self.L.orc_dot(_lp(lx), self.ptr(x), _lp(ly), self.ptr(y), _iv(begin), _iv(end))
+        return out
+
+    def max_err_fn(self, l, x, geom, fn, params, begin, end, out=None):
+        out = self.new_scalar() if out is None else out
+        out[0] = self.L.orc_max_err_fn(_lp(l), self.ptr(x), _gp(geom), int(fn), _p4(params), _iv(begin), _iv(end))
+        return out
+
+    def scalar_value(self, t):
+        return float(t.item())
+
+    def fill_fn(self, l, x, geom, fn, params, begin, end):
+        self.L.orc_fill_fn(_lp(l), self.ptr(x), _gp(geom), int(fn), _p4(params), _iv(begin), _iv(end))
+
+    def apply_dirichlet(self, l, x, geom, fn, params, face_mask):
+        nd = l.nd
+        for d in range(nd):
+            for side in (0, 1):
+                if not (face_mask >> (2 * d + side)) & 1:
+                    continue
+                b, e = [0, 0, 0], [1, 1, 1]
+                for t in range(nd):
+                    if t == d:
+                        if side == 0:
+                            b[t], e[t] = 0, l.dup_l[t]
+                        else:
+                            b[t] = l.dup_l[t] + l.inner[t]
+                            e[t] = b[t] + l.dup_r[t]
+                    else:
+                        b[t] = -l.ghost_l[t]
+                        e[t] = l.dup_l[t] + l.inner[t] + l.dup_r[t] + l.ghost_r[t]
+                self.fill_fn(l, x, geom, fn, params, b, e)
+
+    def init_varcoeff7(self, lc, cf, geom, coef_fn, params, begin, end):
+        self.L.orc_init_varcoeff7(_lp(lc), self.ptr(cf), _gp(geom), int(coef_fn), _p4(params), _iv(begin), _iv(end))
+
+    def pack(self, l, x, buf, begin, end):
+        self.L.orc_pack(_lp(l), self.ptr(x), self.ptr(buf), _iv(begin), _iv(end))
+
+    def unpack(self, l, x, buf, begin, end):
+        self.L.orc_unpack(_lp(l), self.ptr(x), self.ptr(buf), _iv(begin), _iv(end))
+
+    def fill_random(self, x, seed):
+        self.L.orc_fill_random(self.ptr(x), int(x.numel()), int(seed))

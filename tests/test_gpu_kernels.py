@@ -1,0 +1,366 @@
+"""GPU parity: every HIP kernel, called through the C ABI (ctypes -> libexamg.so), against the CPU oracle on
+the same seeded inputs.  Point-wise kernels: bit-exact.  Reductions: 1e-13 relative (summation order).
+Analytic fills with libm calls: 4 ulp."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle_ops import OracleOps
+
+from exastencils_amd.field import (FN_KAPPA_COEF, FN_KAPPA_EXPSOL, FN_KAPPA_RHS, FN_POLY3D, FN_TRIG2D_SOL,
+                                   FN_TRIG3D_SOL, Stencil, laplace_fd, laplace_unit, stencil_field_offsets)
+from exastencils_amd.layout import FieldLayout
+from exastencils_amd.lib import GeomC
+
+APPLY, RESIDUAL, SMOOTH = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from exastencils_amd.ops import HipOps
+
+    return HipOps(0)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return OracleOps()
+
+
+def both(hip, orc, fn):
+    """Run fn(ops) on both back ends; returns (gpu arrays, cpu arrays) as numpy."""
+    g = fn(hip)
+    hip.synchronize()
+    c = fn(orc)
+    return [hip.to_host(t) for t in g], [orc.to_host(t) for t in c]
+
+
+def assert_same(g, c, what=""):
+    for i, (a, b) in enumerate(zip(g, c)):
+        if not np.array_equal(a, b):
+            d = np.abs(a - b)
+            raise AssertionError("%s[%d]: %d of %d values differ, max abs %.3e" % (what, i, int((d > 0).sum()), d.size, d.max()))
+
+
+def geom(nd, n, lo=0.0):
+    g = GeomC()
+    for d in range(3):
+        g.pos_begin[d] = lo if d < nd else 0.0
+        g.h[d] = 1.0 / n if d < nd else 0.0
+    return g
+
+
+def box(nd, n, lo=1, hi=None):
+    hi = n if hi is None else hi
+    return [lo if d < nd else 0 for d in range(3)], [hi if d < nd else 1 for d in range(3)]
+
+
+def test_fill_random_same_bits(hip, orc):
+    def f(ops):
+        x = ops.new_array(100003)
+        ops.fill_random(x, 12345)
+        return [x]
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "fill_random")
+    assert -1.0 <= g[0].min() and g[0].max() < 1.0
+
+
+def _stencil_case(ops, nd, shape, st, mode, colour, b, e, ghost=1, align=0, cfn=None):
+    lu = FieldLayout.node(nd, shape, ghost, align=align)
+    lf = FieldLayout.node(nd, shape, 0, align=align)
+    u, f, dst = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size)
+    ops.fill_random(u, 12345)
+    ops.fill_random(f, 4711)
+    if cfn is not None:
+        K = len(st.offsets)
+        cf = ops.new_array(K * lf.size)
+        ops.fill_random(cf, 99)
+        cf += 3.0       # keep the diagonal away from zero
+        st = Stencil(st.offsets, [], cf, lf)
+    w = 0.8 / st.diag if cfn is None else 0.8
+    if colour >= 0:
+        ops.stencil_op(mode, lu.c_struct(), u, lf.c_struct(), f, lu.c_struct(), u, st, w, colour, b, e)
+        return [u]
+    ops.stencil_op(mode, lu.c_struct(), u, lf.c_struct(), f, lu.c_struct(), dst, st, w, -1, b, e)
+    return [dst]
+
+
+@pytest.mark.parametrize("mode", [APPLY, RESIDUAL, SMOOTH])
+@pytest.mark.parametrize("order", ["mp", "pm"])
+@pytest.mark.parametrize("n", [64, 96, 130])
+def test_stencil7_fast_path_bit_exact(hip, orc, mode, order, n):
+    """3-D 7-point constant coefficients, both entry orders of the reference programs; 96 and 130 leave ragged
+    tiles in x (128 per wave), y and z."""
+    st = laplace_fd(3, (1.0 / n,) * 3, order)
+    b, e = box(3, n)
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, mode, -1, b, e))
+    assert_same(g, c, "stencil7 mode %d" % mode)
+
+
+def test_stencil7_anisotropic_box_and_interior_faces(hip, orc):
+    """Non-cubic fragment, loop bounds of a block with neighbours on some faces (begin 0 / end n+1)."""
+    shape = (160, 40, 24)
+    st = laplace_unit(3)
+    b, e = [0, 1, 0], [161, 40, 24]
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, shape, st, SMOOTH, -1, b, e))
+    assert_same(g, c, "anisotropic")
+
+
+def test_stencil7_padded_layout(hip, orc):
+    st = laplace_fd(3, (1.0 / 64,) * 3)
+    b, e = box(3, 64)
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (64, 64, 64), st, SMOOTH, -1, b, e, align=16))
+    assert_same(g, c, "padded")
+
+
+@pytest.mark.parametrize("colour", [0, 1])
+@pytest.mark.parametrize("n", [33, 64])
+def test_rbgs_half_sweep_bit_exact(hip, orc, colour, n):
+    st = laplace_fd(3, (1.0 / n,) * 3)
+    b, e = box(3, n)
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, SMOOTH, colour, b, e))
+    assert_same(g, c, "rbgs colour %d" % colour)
+
+
+def test_generic_path_equals_fast_path(hip, orc):
+    n = 96
+    st = laplace_fd(3, (1.0 / n,) * 3)
+    b, e = box(3, n)
+    fast = _stencil_case(hip, 3, (n, n, n), st, SMOOTH, -1, b, e)
+    old = hip.L.examg_debug_force_generic(1)
+    try:
+        gen = _stencil_case(hip, 3, (n, n, n), st, SMOOTH, -1, b, e)
+    finally:
+        hip.L.examg_debug_force_generic(old)
+    hip.synchronize()
+    assert_same([hip.to_host(fast[0])], [hip.to_host(gen[0])], "generic vs fast")
+    c = _stencil_case(orc, 3, (n, n, n), st, SMOOTH, -1, b, e)
+    assert_same([hip.to_host(gen[0])], [orc.to_host(c[0])], "generic vs oracle")
+
+
+@pytest.mark.parametrize("mode", [APPLY, RESIDUAL, SMOOTH])
+@pytest.mark.parametrize("colour", [-1, 0, 1])
+def test_stencil_2d_5point(hip, orc, mode, colour):
+    if colour >= 0 and mode != SMOOTH:
+        pytest.skip("colours only with in-place smoothing")
+    n = 257
+    st = laplace_fd(2, (1.0 / n, 1.0 / n, 0.0))
+    b, e = box(2, n)
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 2, (n, n, 0), st, mode, colour, b, e))
+    assert_same(g, c, "5-point")
+
+
+@pytest.mark.parametrize("mode", [APPLY, RESIDUAL, SMOOTH])
+def test_stencil_field_7_entries(hip, orc, mode):
+    n = 48
+    st = Stencil(stencil_field_offsets(3), [])
+    b, e = box(3, n)
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, mode, -1, b, e, cfn=True))
+    assert_same(g, c, "stencil field")
+
+
+def test_stencil_27_entries_const_and_field(hip, orc):
+    n = 40
+    offs = [(0, 0, 0)] + [(a, b_, c_) for a in (-1, 0, 1) for b_ in (-1, 0, 1) for c_ in (-1, 0, 1) if (a, b_, c_) != (0, 0, 0)]
+    co = [26.0] + [-1.0 / (1 + abs(o[0]) + abs(o[1]) + abs(o[2])) for o in offs[1:]]
+    st = Stencil(offs, co)
+    b, e = box(3, n)
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, SMOOTH, -1, b, e))
+    assert_same(g, c, "27-point const")
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), Stencil(offs, []), SMOOTH, -1, b, e, cfn=True))
+    assert_same(g, c, "27-entry stencil field")
+
+
+def test_empty_iteration_space_is_a_noop(hip, orc):
+    """minLevel 0 on one fragment: `loop over` has no inner points (Examples/Poisson/2D_FD_Poisson_fromL4.knowledge:3)."""
+    st = laplace_fd(2, (1.0, 1.0, 0.0))
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 2, (1, 1, 0), st, SMOOTH, -1, [1, 1, 0], [1, 1, 1]))
+    assert_same(g, c, "empty")
+
+
+@pytest.mark.parametrize("nd,n", [(3, 64), (3, 50), (2, 256)])
+@pytest.mark.parametrize("scale", [1.0, 4.0])
+def test_restrict_and_prolong_bit_exact(hip, orc, nd, n, scale):
+    shape_f = tuple(n if d < nd else 0 for d in range(3))
+    shape_c = tuple(n // 2 if d < nd else 0 for d in range(3))
+
+    def f(ops):
+        lfi, lco = FieldLayout.node(nd, shape_f, 1), FieldLayout.node(nd, shape_c, 1)
+        lrh = FieldLayout.node(nd, shape_c, 0)
+        r, fc, uc, uf = ops.new_array(lfi.size), ops.new_array(lrh.size), ops.new_array(lco.size), ops.new_array(lfi.size)
+        ops.fill_random(r, 1)
+        ops.fill_random(uc, 2)
+        ops.fill_random(uf, 3)
+        bc, ec = box(nd, n // 2)
+        ops.restrict(lfi.c_struct(), r, lrh.c_struct(), fc, scale, bc, ec)
+        bf, ef = box(nd, n)
+        ops.prolong_add(lco.c_struct(), uc, lfi.c_struct(), uf, bf, ef)
+        return [fc, uf]
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "transfer")
+
+
+def test_blas1_forms_bit_exact(hip, orc):
+    n = 40
+
+    def f(ops):
+        lx, ly = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0)
+        outs = []
+        b, e = box(3, n)
+        for a, b_ in [(1.0, 0.0), (2.5, 0.0), (0.37, 1.0), (-0.37, 1.0), (1.0, 0.81), (1.5, -0.25)]:
+            x, y = ops.new_array(lx.size), ops.new_array(ly.size)
+            ops.fill_random(x, 5)
+            ops.fill_random(y, 6)
+            ops.axpby(lx.c_struct(), x, ly.c_struct(), y, a, b_, b, e)
+            outs.append(y)
+        z = ops.new_array(lx.size)
+        ops.fill_random(z, 7)
+        ops.set(lx.c_struct(), z, 0.0, b, e)
+        outs.append(z)
+        return outs
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "blas1")
+
+
+def test_axpby_dev_matches_host_scalars(hip):
+    n = 32
+    lx = FieldLayout.node(3, (n, n, n), 1)
+    b, e = box(3, n)
+    x, y1, y2 = hip.new_array(lx.size), hip.new_array(lx.size), hip.new_array(lx.size)
+    hip.fill_random(x, 5)
+    hip.fill_random(y1, 6)
+    hip.fill_random(y2, 6)
+    num, den = hip.from_host(np.array([3.7])), hip.from_host(np.array([1.9]))
+    hip.axpby(lx.c_struct(), x, lx.c_struct(), y1, -(3.7 / 1.9), 1.0, b, e)
+    hip.axpby_dev(lx.c_struct(), x, lx.c_struct(), y2, 0.0, 1.0, 0, -1.0, num, den, b, e)
+    hip.synchronize()
+    assert np.array_equal(hip.to_host(y1), hip.to_host(y2))
+    hip.axpby(lx.c_struct(), x, lx.c_struct(), y1, 1.0, 3.7 / 1.9, b, e)
+    hip.axpby_dev(lx.c_struct(), x, lx.c_struct(), y2, 1.0, 0.0, 1, 1.0, num, den, b, e)
+    hip.synchronize()
+    assert np.array_equal(hip.to_host(y1), hip.to_host(y2))
+
+
+@pytest.mark.parametrize("n", [16, 64, 129])
+def test_reductions(hip, orc, n):
+    def f(ops):
+        lx, ly = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0)
+        x, y = ops.new_array(lx.size), ops.new_array(ly.size)
+        ops.fill_random(x, 11)
+        ops.fill_random(y, 12)
+        b, e = box(3, n)
+        d1 = ops.dot(lx.c_struct(), x, lx.c_struct(), x, b, e)
+        d2 = ops.dot(lx.c_struct(), x, ly.c_struct(), y, b, e)
+        m = ops.max_err_fn(lx.c_struct(), x, geom(3, n), FN_POLY3D, (), b, e)
+        d0 = ops.dot(lx.c_struct(), x, lx.c_struct(), x, [1, 1, 1], [1, 1, 1])
+        return [d1, d2, m, d0]
+
+    g, c = both(hip, orc, f)
+    assert abs(g[0][0] - c[0][0]) <= 1e-13 * abs(c[0][0])
+    assert abs(g[1][0] - c[1][0]) <= 1e-12 * (n ** 3) ** 0.5
+    assert g[2][0] == c[2][0]          # max of |x - poly| has no summation order
+    assert g[3][0] == 0.0 and c[3][0] == 0.0
+    # deterministic: same launch twice, same bits
+    g2, _ = both(hip, orc, f)
+    assert g[0][0] == g2[0][0] and g[1][0] == g2[1][0]
+
+
+def _ulp_close(a, b, ulps=4):
+    """Device libm vs glibc: a few ulps of the operands' magnitude (differences such as cos(..) - sin(..) cancel)."""
+    scale = np.maximum(np.abs(b), 1.0)
+    return np.all(np.abs(a - b) <= ulps * np.spacing(scale))
+
+
+@pytest.mark.parametrize("fn,nd,exact", [(FN_POLY3D, 3, True), (FN_TRIG2D_SOL, 2, False), (FN_KAPPA_RHS, 3, True),
+                                         (FN_KAPPA_EXPSOL, 3, False), (FN_TRIG3D_SOL, 3, False)])
+def test_fill_fn_and_dirichlet(hip, orc, fn, nd, exact):
+    n = 24
+    shape = tuple(n if d < nd else 0 for d in range(3))
+
+    def f(ops):
+        l = FieldLayout.node(nd, shape, 1)
+        x, y = ops.new_array(l.size), ops.new_array(l.size)
+        ops.fill_random(x, 3)
+        ops.fill_random(y, 3)
+        b, e = box(nd, n)
+        ops.fill_fn(l.c_struct(), x, geom(nd, n, 0.25), fn, (10.0,), b, e)
+        ops.apply_dirichlet(l.c_struct(), y, geom(nd, n, 0.25), fn, (10.0,), (1 << (2 * nd)) - 1 - 2)  # all faces but x+
+        return [x, y]
+
+    g, c = both(hip, orc, f)
+    if exact:
+        assert_same(g, c, "fill_fn")
+    else:
+        for a, b_ in zip(g, c):
+            assert _ulp_close(a, b_, 8)
+    # the +x face was masked out: its duplicate plane must still hold the random fill
+    l = FieldLayout.node(nd, shape, 1)
+    v = g[1].reshape(l.shape_zyx)
+    r = orc.new_array(l.size)
+    orc.fill_random(r, 3)
+    rv = orc.to_host(r).reshape(l.shape_zyx)
+    # interior rows (not on another face's plane) of the x+ duplicate plane
+    sl = (slice(None) if nd == 2 else slice(3, -3), slice(3, -3), l.ref(0) + n)
+    assert np.array_equal(v[sl], rv[sl])
+
+
+def test_init_varcoeff7(hip, orc):
+    n = 20
+
+    def f(ops):
+        l = FieldLayout.node(3, (n, n, n), 0)
+        cf = ops.new_array(7 * l.size)
+        b, e = box(3, n)
+        ops.init_varcoeff7(l.c_struct(), cf, geom(3, n), FN_KAPPA_COEF, (10.0,), b, e)
+        return [cf]
+
+    g, c = both(hip, orc, f)
+    assert np.allclose(g[0], c[0], rtol=1e-14, atol=0.0)
+
+
+def test_pack_unpack_ranges(hip, orc):
+    """All duplicate/ghost send and receive boxes of a 3-D fragment (communication/ir/IR_PackInfo*.scala)."""
+    from exastencils_amd.comm import Communicator
+
+    n = 20
+    lay = FieldLayout.node(3, (n, n + 4, n - 4), 1)
+
+    def f(ops):
+        x, y = ops.new_array(lay.size), ops.new_array(lay.size)
+        ops.fill_random(x, 21)
+        outs = []
+        for d in range(3):
+            (sb, rb) = Communicator.dup_ranges(lay, 3, d)
+            boxes = [sb, rb]
+            for side in (-1, 1):
+                boxes += list(Communicator.ghost_ranges(lay, 3, d, side))
+            for bx in boxes:
+                cnt = Communicator._count(bx)
+                buf = ops.new_array(cnt)
+                ops.pack(lay.c_struct(), x, buf, bx[0], bx[1])
+                ops.unpack(lay.c_struct(), y, buf, bx[0], bx[1])
+                outs.append(buf)
+        outs.append(y)
+        return outs
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "pack/unpack")
+
+
+def test_bad_arguments_fail_loudly(hip):
+    from exastencils_amd.lib import ExamgError
+
+    n = 16
+    lu = FieldLayout.node(3, (n, n, n), 1)
+    st = laplace_unit(3)
+    u, f = hip.new_array(lu.size), hip.new_array(lu.size)
+    with pytest.raises(ExamgError):      # box + stencil reach outside the allocation
+        hip.stencil_op(SMOOTH, lu.c_struct(), u, lu.c_struct(), f, lu.c_struct(), f, st, 0.1, -1, [-1, 1, 1], [n, n, n])
+    with pytest.raises(ExamgError):      # in-place without a colour
+        hip.stencil_op(SMOOTH, lu.c_struct(), u, lu.c_struct(), f, lu.c_struct(), u, st, 0.1, -1, [1, 1, 1], [n, n, n])
+    with pytest.raises(ExamgError):      # residual without rhs
+        hip.stencil_op(RESIDUAL, lu.c_struct(), u, None, None, lu.c_struct(), f, st, 0.1, -1, [1, 1, 1], [n, n, n])

@@ -1,0 +1,72 @@
+"""The product's host driver (exastencils_amd.solver: the mirror of the generated mgCycle/Solve functions)
+run on the CPU with the oracle's loops standing in for the HIP kernels: it must print the reference's
+golden histories too, and agree with the oracle's own driver to the last bit (same loops, same order)."""
+import pytest
+
+from golden_cases import CASES, golden_text, oracle_program
+from oracle import mg
+from oracle_ops import OracleOps
+
+from exastencils_amd.domain import RectDomain
+from exastencils_amd.layout import FieldLayout
+from exastencils_amd.solver import ConfigL3, ConfigL4, SolverFromL3, SolverFromL4
+
+
+def product_program(name, ops, domain=None, comm=None, **override):
+    c = dict(CASES[name])
+    c.update(override)
+    prog = c.pop("program")
+    c.pop("frags")
+    c.pop("frag_len")
+    flen = c.pop("single_len")
+    c["frag_len"] = override.get("frag_len", flen)
+    if prog == "A":
+        c.pop("kappa", None)
+        return SolverFromL4(ConfigL4(fused_coarse=False, **c), ops, domain, comm)
+    return SolverFromL3(ConfigL3(**c), ops, domain, comm)
+
+
+@pytest.mark.parametrize("name", ["CommBasic_PureMPI", "Poisson_2D_FD_Poisson_fromL4", "SISC_3D_ConstCoeff",
+                                  "SISC_3D_VarCoeff", "FMG_3D_Trigonometric"])
+def test_host_driver_reproduces_goldens(name):
+    P = product_program(name, OracleOps())
+    P.setup()
+    P.Solve()
+    assert mg.compare_with_golden(P.log, golden_text(name)) == [], P.log
+    O = oracle_program(name)
+    O.setup()
+    O.Solve()
+    assert P.res_history == O.res_history
+    assert P.err_history == O.err_history
+
+
+def test_layout_matches_reference_sizes():
+    # 512^3 NodeWithComm => TOT = 2^L + 3 = 515 per dim, NodeNoGhost => 513
+    l = FieldLayout.node(3, (512, 512, 512), 1)
+    assert [l.tot(d) for d in range(3)] == [515, 515, 515] and l.ref(0) == 1 and l.size == 515 ** 3
+    l = FieldLayout.node(3, (512, 512, 512), 0)
+    assert [l.tot(d) for d in range(3)] == [513, 513, 513] and l.ref(0) == 0
+    l = FieldLayout.node(2, (256, 256, 0), 1)
+    assert l.shape_zyx == (1, 259, 259)
+    # IR_AddPaddingToFieldLayouts with vector size 4: first dup point aligned, row length a multiple
+    l = FieldLayout.node(3, (8, 8, 8), 1, align=4)
+    assert l.pad_l[0] == 3 and l.ref(0) == 4 and l.tot(0) % 4 == 0 and l.tot(1) == 11
+    assert l.idx("GLB", 0) == -1 and l.idx("DRE", 0) == 9 and l.idx("GRE", 0) == 10
+
+
+def test_domain_rank_mapping_and_offsets():
+    assert RectDomain.blocks_for(8, 3) == (2, 2, 2)
+    assert RectDomain.blocks_for(4, 3) == (2, 2, 1)
+    assert RectDomain.blocks_for(2, 3) == (2, 1, 1)
+    d = RectDomain(3, (2, 2, 2), rank=5)            # x-fastest: 5 = 1 + 2*(0 + 2*1)
+    assert d.pos == (1, 0, 1)
+    assert d.neighbor(0, -1) == 4 and d.neighbor(0, +1) is None
+    assert d.neighbor(1, +1) == 7 and d.neighbor(2, -1) == 1
+    lay = FieldLayout.node(3, d.ncells(3), 1)
+    b, e = d.loop_bounds(lay)
+    assert b == [0, 1, 0] and e == [8, 9, 8]       # interior faces include the dup node, physical faces do not
+    b, e = d.loop_bounds(lay, reduction=True)
+    assert b == [1, 1, 1]
+    assert d.face_mask() == 0b100110
+    g = d.geom(3)
+    assert g.pos_begin[0] == 0.5 and g.pos_begin[1] == 0.0 and abs(g.h[0] - 1.0 / 16) < 1e-16
