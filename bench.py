@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""bench.py -- the reference's headline metric on MI355X.
+
+step      = one application of the smoother function of the generated program
+            (Testing/Smoothers/Jac.exa4:125-131: `communicate ghost of Solution<active>`; the 3-D 7-point
+            Jacobi loop; `advance`) on one 512^3-cell block per GPU (515^3-double fields in the
+            reference layout, 511^3 updated points).
+metric    = LU/s (lattice updates per second, the authors' formula Testing/PolyExpl/Jac3Dcc.exa4:58),
+            whole job: ranks x points x steps / max-over-ranks time.
+roofline  = HBM: 24 algorithmic bytes per update (read u, read rhs, write u_next;
+            Compiler/src/exastencils/performance/ir/IR_EvaluatePerformanceEstimates.scala:206-215)
+            / average Jacobi-kernel launch time measured with events on the launch stream.
+cpu_baseline = the restated reference CPU path (oracle/examg_oracle.c:orc_jacobi7_const, generator-shaped
+            OpenMP loop) timed on this host's cores on a bounded 256^3 sample.
+Also reported (extra keys): one V(3,3) RBGS cycle of the Benchmark/Poisson3D program at 512^3 (config 3).
+
+Launch: `python bench.py` (1 GPU) or
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_LU = 24.0
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--level", type=int, default=9, help="finest level: 2^level cells per dim per GPU (9 => 512^3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vcycle", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds: float):
+    """Restated reference CPU path on a bounded sample: 256^3 Jacobi sweeps for ~`seconds` s."""
+    import ctypes as C
+
+    from oracle import mg
+
+    L = mg.lib()
+    n = 256
+    lu, lf = mg.Layout.node(3, (n, n, n), 1), mg.Layout.node(3, (n, n, n), 0)
+    u, un, f = lu.alloc(), lu.alloc(), lf.alloc()
+    L.orc_fill_random(u.ctypes.data, u.size, 12345)
+    L.orc_fill_random(f.ctypes.data, f.size, 777)
+    st = mg.laplace_examples(3, (1.0 / n,) * 3)
+    sc, luc, lfc = st.c(), lu.c(), lf.c()
+    w = 0.8 / st.coefs[0]
+    b, e = (C.c_int * 3)(1, 1, 1), (C.c_int * 3)(n, n, n)
+    ptr = [u.ctypes.data, un.ctypes.data]
+
+    def sweep(i):
+        L.orc_jacobi7_const(C.byref(luc), ptr[i % 2], C.byref(lfc), f.ctypes.data, ptr[(i + 1) % 2], C.byref(sc), w, b, e)
+
+    sweep(0)
+    sweep(1)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        sweep(k)
+        k += 1
+        dt = time.perf_counter() - t0
+        if (dt >= seconds and k >= 4) or k >= 100000:
+            break
+    pts = (n - 1) ** 3
+    return {
+        "value": pts * k / dt,
+        "unit": "LU/s",
+        "cores": int(L.orc_num_threads()),
+        "kind": "port",
+        "sample": "%d Jacobi 7-pt sweeps of 256^3 cells (255^3 updates each), restated generator-shaped OpenMP loop, %.1f s"
+                  % (k, dt),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.field import Field, laplace_fd
+    from exastencils_amd.layout import FieldLayout
+    from exastencils_amd.ops import HipOps
+
+    ops = HipOps(local_rank)
+    nd, L = 3, args.level
+    dom = RectDomain(nd, RectDomain.blocks_for(world, nd), rank)
+    comm = Communicator(dom, ops)
+    nc = dom.ncells(L)
+    Solution = Field("Solution", L, FieldLayout.node(nd, nc, 1), ops, 2, None)
+    RHS = Field("RHS", L, FieldLayout.node(nd, nc, 0, False, False), ops, 1, None)
+    ops.fill_random(Solution.data(0), 12345 + rank)
+    ops.fill_random(Solution.data(1), 999 + rank)
+    ops.fill_random(RHS.data(), 777 + rank)
+    A = laplace_fd(nd, dom.h(L), "mp")
+    w = 0.8 / A.diag
+    b, e = dom.loop_bounds(Solution.layout)
+    updates = (e[0] - b[0]) * (e[1] - b[1]) * (e[2] - b[2])
+
+    def step():
+        # Function Smoother@finest: communicate ghost of Solution<active>; Jacobi loop; advance
+        comm.exchange(Solution, Solution.active, "ghost")
+        ops.stencil_op(2, Solution.lc, Solution.data(Solution.active), RHS.lc, RHS.data(), Solution.lc,
+                       Solution.data(Solution.next), A, w, -1, b, e)
+        Solution.advance()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=ops.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel alone, events on the launch stream
+    stream = torch.cuda.current_stream()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nk = max(10, min(args.steps, 100))
+    torch.cuda.synchronize()
+    ev0.record(stream)
+    for _ in range(nk):
+        ops.stencil_op(2, Solution.lc, Solution.data(Solution.active), RHS.lc, RHS.data(), Solution.lc,
+                       Solution.data(Solution.next), A, w, -1, b, e)
+        Solution.advance()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / nk
+    achieved = BYTES_PER_LU * updates / (kernel_ms * 1e-3) / 1e9
+
+    extra = {}
+    if not args.no_vcycle:
+        try:
+            extra.update(vcycle(ops, dom, comm, L, world))
+        except Exception as ex:  # the headline number must not depend on the extra measurement
+            extra["vcycle_error"] = repr(ex)[:300]
+
+    out = None
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("jacobi_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "LU/s",
+            "value": world * updates * args.steps / dt,
+            "unit": "LU/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "3D Poisson 7-point Jacobi smoother step (ghost exchange + sweep + advance), %d^3 cells per GPU, "
+                            "reference field layout (%d^3 doubles per slot)" % (nc[0], Solution.layout.tot(0)),
+                "blocks": list(dom.num_blocks),
+                "updates_per_step_per_gpu": updates,
+                "levels": L,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "k_stencil7_zmarch (Jacobi)",
+                "kernel_ms": kernel_ms,
+                "bytes_per_lu": BYTES_PER_LU,
+            },
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def vcycle(ops, dom, comm, L, world):
+    """Config 3: one V(3,3) red-black cycle of Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4, 6 levels."""
+    import torch
+
+    from exastencils_amd.solver import ConfigL4, SolverFromL4
+
+    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6)
+    P = SolverFromL4(cfg, ops, dom, comm)
+    P.setup()
+    P._update_residual(L)
+    r0 = P.ResNorm(L)
+    use_graph = world == 1
+    if use_graph:
+        P.capture_cycle()
+        run = P.replay_cycle
+    else:
+        P.mgCycle(L)
+        run = lambda: P.mgCycle(L)
+    n = 5
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    P._update_residual(L)
+    r1 = P.ResNorm(L)
+    npts = 1
+    b, e = dom.loop_bounds(P.Solution[L].layout)
+    for d in range(3):
+        npts *= e[d] - b[d]
+    # 223 algorithmic bytes per finest-grid point per V(3,3) cycle with the 24 B/LU red-black floor
+    return {
+        "vcycle_ms": ms,
+        "vcycle_levels": 6,
+        "vcycle_residual_reduction": r1 / r0 if r0 else None,
+        "vcycle_gbs_algorithmic": 223.0 * npts / (ms * 1e-3) / 1e9,
+        "vcycle_graph": use_graph,
+    }
+
+
+if __name__ == "__main__":
+    main()

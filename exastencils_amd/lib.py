@@ -59,6 +59,10 @@ def load():
         raise ExamgError(
             "libexamg.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no CPU fallback" % LIB_PATH)
+    # torch first: libexamg.so needs libamdhip64.so.7 and must bind to the one HIP runtime of the process,
+    # the copy PyTorch ships and loads (two runtimes in one process do not both see the device)
+    import torch  # noqa: F401
+
     L = C.CDLL(LIB_PATH)
     vp, ip = C.c_void_p, C.POINTER(C.c_int32)
     lp, sp, gp, dp = C.POINTER(LayoutC), C.POINTER(StencilC), C.POINTER(GeomC), C.POINTER(C.c_double)

@@ -43,8 +43,11 @@ def test_golden_histories_on_gpu(hip, name):
     O.Solve()
     assert P.iterations == O.iterations
     _close(P.res_history, O.res_history)
-    # errors go through device libm (cos/sin/exp/sinh differ from glibc in the last ulps)
-    _close(P.err_history, O.err_history, 1e-9)
+    # max-norm errors: exact solution through device libm, converged iterates differ at rounding level:
+    # compare absolutely, relative to the solution's magnitude (O(1))
+    assert len(P.err_history) == len(O.err_history)
+    for x, y in zip(P.err_history, O.err_history):
+        assert abs(x - y) <= 1e-9 * abs(y) + 1e-12, (P.err_history, O.err_history)
 
 
 def test_golden_rbgs_576_on_gpu(hip):
