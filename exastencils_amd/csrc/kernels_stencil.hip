@@ -13,6 +13,25 @@
 // file is compiled with -ffp-contract=off, so results are bit-identical to the CPU path.
 #include "examg_common.h"
 
+// shipped configuration of the fast path, from the sweeps of tools/tune_jacobi.py on MI355X (gpurun_out/tune*.log,
+// summary in DESIGN.md): 2 rows per wave, 4 waves per workgroup, non-temporal stores (+12 %), loads of the next
+// plane in flight while this one is computed, ~1024 workgroups, z march, plain tile order.
+#ifndef EXAMG_ZM_RY
+#define EXAMG_ZM_RY 2
+#endif
+#ifndef EXAMG_ZM_WY
+#define EXAMG_ZM_WY 4
+#endif
+#ifndef EXAMG_ZM_NT
+#define EXAMG_ZM_NT true
+#endif
+#ifndef EXAMG_ZM_MY
+#define EXAMG_ZM_MY false
+#endif
+#ifndef EXAMG_ZM_PF
+#define EXAMG_ZM_PF 1
+#endif
+
 namespace examg {
 
 struct StencilDev {
@@ -122,13 +141,14 @@ __device__ __forceinline__ double finish(double u, double acc, double f, double 
 }
 
 struct ZMarchGeom {
-  int ntx, nty, ntz;  // tiles per dim
-  int zc;             // planes per z chunk
-  int nblocks;        // ntx * nty * ntz
+  int ntx, ntt, ntm;  // tiles per dim: x, tile-row dim T, march dim M
+  int mc;             // planes (or rows) per march chunk
+  int nblocks;        // ntx * ntt * ntm
+  int remap;          // XCD-aware tile order on/off
 };
 
 // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (blocks b and b+8 share one
-// L2), so give each XCD a contiguous run of tiles -- y-adjacent tiles then share halo rows in L2.
+// L2), so give each XCD a contiguous run of tiles -- adjacent tiles then share halo rows in L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   const int per = nblocks >> 3;
   const int full = per << 3;
@@ -136,65 +156,102 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return (bid & 7) * per + (bid >> 3);
 }
 
-template <int MODE, int ORDER, int RY, int WY, bool NT>
+// Tile = 128 x-points (2 per lane) by RY rows per wave, WY waves per workgroup, marching along M.
+//   MY = false: rows are y, march is z (register pipeline holds u[z-1], u[z], u[z+1]);
+//   MY = true : rows are z, march is y (consecutive steps are 1 row = ~4 KB apart: TLB-friendly).
+template <int MODE, int ORDER, int RY, int WY, bool NT, bool MY, int PF, bool REV>
 __global__ void __launch_bounds__(64 * WY)
 k_stencil7_zmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev ld,
                   double *__restrict__ dst, Coef7 k, double w, Box box, ZMarchGeom g) {
   const int lane = threadIdx.x;   // 0..63
   const int wv = threadIdx.y;     // wave in block
-  int t = xcd_remap(blockIdx.x, g.nblocks);
+  int t = g.remap ? xcd_remap(blockIdx.x, g.nblocks) : (int)blockIdx.x;
+  if (REV) t = g.nblocks - 1 - t;  // backward sweep: last tiles first (see launch_zmarch: Infinity-Cache reuse)
   const int tx = t % g.ntx;
   t /= g.ntx;
-  const int ty = t % g.nty;
-  const int tz = t / g.nty;
+  const int tt = t % g.ntt;
+  const int tm = t / g.ntt;
+
+  const int bT = MY ? box.b2 : box.b1, eT = MY ? box.e2 : box.e1;
+  const int bM = MY ? box.b1 : box.b2, eM = MY ? box.e1 : box.e2;
+  const long long uT = MY ? lu.s2 : lu.s1, uM = MY ? lu.s1 : lu.s2;
+  const long long fT = MY ? lf.s2 : lf.s1, fM = MY ? lf.s1 : lf.s2;
+  const long long dT = MY ? ld.s2 : ld.s1, dM = MY ? ld.s1 : ld.s2;
 
   const int x = box.b0 + tx * 128 + lane * 2;
-  const int yw = box.b1 + (ty * WY + wv) * RY;  // first row of this wave
-  const int zb = box.b2 + tz * g.zc;
-  const int ze = min(zb + g.zc, box.e2);
-  if (yw >= box.e1) return;  // wave-uniform
+  const int rw = bT + (tt * WY + wv) * RY;  // first row of this wave
+  const int mb = bM + tm * g.mc;
+  const int me = min(mb + g.mc, eM);
+  if (rw >= eT) return;  // wave-uniform
   const bool va = x < box.e0, vb = x + 1 < box.e0;
   // right neighbour of b comes from lane+1 unless that lane is past the box
   const bool rload = vb && (lane == 63 || x + 2 >= box.e0);
   const bool lload = va && lane == 0;
-
-  int yr[RY];
-#pragma unroll
-  for (int r = 0; r < RY; ++r) yr[r] = min(yw + r, box.e1);  // clamped rows re-read the upper halo row
-  const int yhm = yw - 1, yhp = min(yw + RY, box.e1);
   const int xs = va ? x : box.b0;  // safe column for idle lanes (never stored)
 
-  d2 um[RY], uc[RY], up[RY];
+  const double *ur[RY];
+  const double *fr[RY];
+  double *dr[RY];
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
-    um[r] = load2(u + lidx(lu, xs, yr[r], zb - 1));
-    uc[r] = load2(u + lidx(lu, xs, yr[r], zb));
+    const int row = min(rw + r, eT);  // clamped rows re-read the upper halo row
+    ur[r] = u + lu.origin + xs + uT * row;
+    fr[r] = rhs + lf.origin + xs + fT * row;
+    dr[r] = dst + ld.origin + xs + dT * row;
   }
-  for (int z = zb; z < ze; ++z) {
-    d2 f[RY];
+  const double *uhm = u + lu.origin + xs + uT * (rw - 1);
+  const double *uhp = u + lu.origin + xs + uT * min(rw + RY, eT);
+
+  constexpr int sg = REV ? -1 : 1;         // march direction
+  const int m0 = REV ? me - 1 : mb;        // first plane; step q handles plane m0 + sg*q
+  const int cnt = me - mb;
+  d2 um[RY], uc[RY];                       // planes m - sg and m of the own rows
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    um[r] = load2(ur[r] + uM * (m0 - sg));
+    uc[r] = load2(ur[r] + uM * m0);
+  }
+  // one pipeline stage = everything step m needs from memory: u[m+1] and rhs[m] of the own rows, the two
+  // halo rows of plane m.  With PF the loads of step m+1 are issued before step m is computed.
+  struct Stage {
+    d2 up[RY], f[RY], hm, hp;
+  };
+  auto load_stage = [&](Stage &st, int q) {
+    const int m = m0 + sg * q;
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-      up[r] = load2(u + lidx(lu, xs, yr[r], z + 1));
-      if (MODE != EXAMG_APPLY) f[r] = load2(rhs + lidx(lf, xs, yr[r], z));
+      st.up[r] = load2(ur[r] + uM * (m + sg));
+      if (MODE != EXAMG_APPLY) st.f[r] = load2(fr[r] + fM * m);
     }
-    const d2 hm = load2(u + lidx(lu, xs, yhm, z));
-    const d2 hp = load2(u + lidx(lu, xs, yhp, z));
+    st.hm = load2(uhm + uM * m);
+    st.hp = load2(uhp + uM * m);
+  };
+  auto compute = [&](const Stage &st, int q) {
+    const int m = m0 + sg * q;
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
       // wavefront-level x-halo exchange
       double xl = __shfl_up(uc[r].y, 1);
       double xr = __shfl_down(uc[r].x, 1);
-      if (lload) xl = u[lidx(lu, x - 1, yr[r], z)];
-      if (rload) xr = u[lidx(lu, x + 2, yr[r], z)];
-      const d2 ym = (r == 0) ? hm : uc[r == 0 ? 0 : r - 1];
-      const d2 yp = (r == RY - 1) ? hp : uc[r == RY - 1 ? r : r + 1];
-      const double acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, ym.x, yp.x, um[r].x, up[r].x);
-      const double acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, ym.y, yp.y, um[r].y, up[r].y);
+      if (lload) xl = ur[r][uM * m - 1];
+      if (rload) xr = ur[r][uM * m + 2];
+      const d2 tm_ = (r == 0) ? st.hm : uc[r == 0 ? 0 : r - 1];
+      const d2 tp_ = (r == RY - 1) ? st.hp : uc[r == RY - 1 ? r : r + 1];
+      const d2 mm_ = REV ? st.up[r] : um[r];   // plane m-1 and m+1 along the march dimension
+      const d2 mp_ = REV ? um[r] : st.up[r];
+      double acc_a, acc_b;
+      if (MY) {
+        acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, mm_.x, mp_.x, tm_.x, tp_.x);
+        acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, mm_.y, mp_.y, tm_.y, tp_.y);
+      } else {
+        acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, tm_.x, tp_.x, mm_.x, mp_.x);
+        acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, tm_.y, tp_.y, mm_.y, mp_.y);
+      }
       d2 o;
-      o.x = finish<MODE>(uc[r].x, acc_a, f[r].x, w);
-      o.y = finish<MODE>(uc[r].y, acc_b, f[r].y, w);
-      if (yw + r < box.e1) {
-        double *q = dst + lidx(ld, x, yw + r, z);
+      o.x = finish<MODE>(uc[r].x, acc_a, st.f[r].x, w);
+      o.y = finish<MODE>(uc[r].y, acc_b, st.f[r].y, w);
+      if (rw + r < eT) {
+        double *q = dr[r] + dM * m;
         if (vb) {
           if (NT) {
             __builtin_nontemporal_store(o.x, q);
@@ -210,7 +267,23 @@ k_stencil7_zmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
       um[r] = uc[r];
-      uc[r] = up[r];
+      uc[r] = st.up[r];
+    }
+  };
+  // software pipeline of depth PF: the loads of step m+PF are in flight while step m is computed
+  Stage st[PF + 1];
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (j < cnt) load_stage(st[j], j);
+  int q = 0;
+  while (q < cnt) {
+#pragma unroll
+    for (int j = 0; j <= PF; ++j) {
+      if (q < cnt) {
+        if (q + PF < cnt) load_stage(st[(j + PF) % (PF + 1)], q + PF);
+        compute(st[j], q);
+        ++q;
+      }
     }
   }
 }
@@ -231,28 +304,84 @@ static int order7(const examg_stencil_t *st) {
 
 static int g_force_generic = 0;  // test hook: examg_debug_force_generic
 
+// Tuning knobs (examg_debug_tune); the defaults are the measured best on MI355X at 512^3.
+struct Tune {
+  int ry = 2, wy = 4, nt = 1, my = 0, pf = 1, remap = 0, blocks = 1024, minchunk = 16, dir = 0;
+};
+static Tune g_tune;
+static bool g_dir_toggle = false;
+
+template <int MODE, int ORDER, int RY, int WY, bool NT, bool MY, int PF>
+static void launch_zmarch_t(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
+                            double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
+  const int nT = MY ? box.n2() : box.n1(), nM = MY ? box.n1() : box.n2();
+  ZMarchGeom g;
+  g.ntx = (box.n0() + 127) / 128;
+  g.ntt = (nT + RY * WY - 1) / (RY * WY);
+  const int xy = g.ntx * g.ntt;
+  int ntm = (g_tune.blocks + xy - 1) / xy;
+  if (ntm < 1) ntm = 1;
+  int mc = (nM + ntm - 1) / ntm;
+  if (mc < g_tune.minchunk) mc = g_tune.minchunk;
+  if (mc > nM) mc = nM;
+  g.mc = mc;
+  g.ntm = (nM + mc - 1) / mc;
+  g.nblocks = g.ntx * g.ntt * g.ntm;
+  g.remap = g_tune.remap;
+  dim3 block(64, WY, 1), grid(g.nblocks, 1, 1);
+  // Sweep direction (tuning knob `dir`; -1 alternates from launch to launch so that a sweep starts where the
+  // previous one ended).  Measured on MI355X at 256^3 and 512^3: no gain -- the 256 MiB Infinity Cache does not
+  // hold streamed data long enough -- so the shipped default is always forward.  Results do not depend on it.
+  bool rev;
+  if (g_tune.dir < 0) { rev = g_dir_toggle; g_dir_toggle = !g_dir_toggle; }
+  else rev = g_tune.dir != 0;
+  if (rev) hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, RY, WY, NT, MY, PF, true>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  else hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, RY, WY, NT, MY, PF, false>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+}
+
+#ifdef EXAMG_TUNE
+// every (RY, WY, NT, MY) combination, for tools/tune_jacobi.py
+template <int MODE, int ORDER, int RY, int WY>
+static void launch_zmarch_ntmy(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
+                               double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
+#define EXAMG_L(NT_, MY_, PF_) launch_zmarch_t<MODE, ORDER, RY, WY, NT_, MY_, PF_>(lu, u, lf, rhs, ld, dst, k, w, box, s)
+  switch (g_tune.pf) {
+    case 1: if (g_tune.nt) EXAMG_L(true, false, 1); else EXAMG_L(false, false, 1); break;
+    case 2: if (g_tune.nt) EXAMG_L(true, false, 2); else EXAMG_L(false, false, 2); break;
+    case 3: if (g_tune.nt) EXAMG_L(true, false, 3); else EXAMG_L(false, false, 3); break;
+    case 4: if (g_tune.nt) EXAMG_L(true, false, 4); else EXAMG_L(false, false, 4); break;
+    default:
+      if (g_tune.nt) { if (g_tune.my) EXAMG_L(true, true, 0); else EXAMG_L(true, false, 0); }
+      else { if (g_tune.my) EXAMG_L(false, true, 0); else EXAMG_L(false, false, 0); }
+  }
+#undef EXAMG_L
+}
+template <int MODE, int ORDER, int RY>
+static void launch_zmarch_wy(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
+                             double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
+  switch (g_tune.wy) {
+    case 1: launch_zmarch_ntmy<MODE, ORDER, RY, 1>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
+    case 2: launch_zmarch_ntmy<MODE, ORDER, RY, 2>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
+    case 8: launch_zmarch_ntmy<MODE, ORDER, RY, 8>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
+    default: launch_zmarch_ntmy<MODE, ORDER, RY, 4>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
+  }
+}
 template <int MODE, int ORDER>
 static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
                           double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
-  constexpr int RY = 2, WY = 4;
-  ZMarchGeom g;
-  g.ntx = (box.n0() + 127) / 128;
-  g.nty = (box.n1() + RY * WY - 1) / (RY * WY);
-  // enough z chunks for >= ~2048 workgroups, but at least 16 planes per chunk
-  int zc = box.n2();
-  const int want = 2048;
-  const int xy = g.ntx * g.nty;
-  int ntz = (want + xy - 1) / xy;
-  if (ntz < 1) ntz = 1;
-  zc = (box.n2() + ntz - 1) / ntz;
-  if (zc < 16) zc = 16;
-  if (zc > box.n2()) zc = box.n2();
-  g.zc = zc;
-  g.ntz = (box.n2() + zc - 1) / zc;
-  g.nblocks = g.ntx * g.nty * g.ntz;
-  dim3 block(64, WY, 1), grid(g.nblocks, 1, 1);
-  hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, RY, WY, false>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  switch (g_tune.ry) {
+    case 1: launch_zmarch_wy<MODE, ORDER, 1>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
+    case 4: launch_zmarch_wy<MODE, ORDER, 4>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
+    default: launch_zmarch_wy<MODE, ORDER, 2>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
+  }
 }
+#else
+template <int MODE, int ORDER>
+static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
+                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
+  launch_zmarch_t<MODE, ORDER, EXAMG_ZM_RY, EXAMG_ZM_WY, EXAMG_ZM_NT, EXAMG_ZM_MY, EXAMG_ZM_PF>(lu, u, lf, rhs, ld, dst, k, w, box, s);
+}
+#endif
 
 }  // namespace examg
 
@@ -262,6 +391,23 @@ extern "C" int examg_debug_force_generic(int on) {
   const int old = g_force_generic;
   g_force_generic = on;
   return old;
+}
+
+// Tuning hook for tools/tune_jacobi.py: key in {ry, wy, nt, my, remap, blocks, minchunk}.  ry/wy/nt/my only
+// take effect in a build with -DEXAMG_TUNE (all template combinations instantiated).
+extern "C" int examg_debug_tune(const char *key, int value) {
+  if (!key) return 1;
+  if (!strcmp(key, "ry")) g_tune.ry = value;
+  else if (!strcmp(key, "wy")) g_tune.wy = value;
+  else if (!strcmp(key, "nt")) g_tune.nt = value;
+  else if (!strcmp(key, "my")) g_tune.my = value;
+  else if (!strcmp(key, "pf")) g_tune.pf = value;
+  else if (!strcmp(key, "dir")) g_tune.dir = value;
+  else if (!strcmp(key, "remap")) g_tune.remap = value;
+  else if (!strcmp(key, "blocks")) g_tune.blocks = value;
+  else if (!strcmp(key, "minchunk")) g_tune.minchunk = value;
+  else return 1;
+  return 0;
 }
 
 extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_,
