@@ -1,0 +1,196 @@
+"""N > 1 path on the CPU: world_size-2 (and 4) `gloo` process groups run the product's decomposition, halo
+exchange (exastencils_amd.comm) and cycle drivers (exastencils_amd.solver) with the oracle's loops standing
+in for the HIP kernels, and must reproduce the single-fragment run of the same global problem.
+
+What this pins: rank -> block position, neighbour ranks, iteration offsets at interior faces, duplicate-layer
+exchange direction, ghost exchange ranges incl. the GLB..GRE tangential extent that makes edge/corner ghosts
+valid with 6 neighbours (needed by 27-point stencils), and the all-reduce after reduction loops."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import mg
+
+    mg.lib().orc_set_num_threads(2)
+
+
+def _global_index(dom, lay, level):
+    """Slices of this block's owned box [DLB, DRE) in a global node array of the same level (z, y, x)."""
+    nc = dom.ncells(level)
+    sl_g, sl_l = [], []
+    for d in (2, 1, 0):
+        if d >= dom.nd:
+            sl_g.append(slice(0, 1))
+            sl_l.append(slice(0, 1))
+            continue
+        o = dom.pos[d] * nc[d]
+        sl_g.append(slice(o, o + nc[d] + 1))
+        sl_l.append(slice(lay.ref(d), lay.ref(d) + nc[d] + 1))
+    return tuple(sl_g), tuple(sl_l)
+
+
+# -------------------------------------------------------------------------------------------------
+def _worker_solver(rank, world, port, blocks, case, out_dir):
+    _init(rank, world, port)
+    from oracle_ops import OracleOps
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.solver import ConfigL3, ConfigL4, SolverFromL3, SolverFromL4
+
+    ops = OracleOps()
+    flen = tuple(2 // blocks[d] if d < 3 else 1 for d in range(3))
+    dom = RectDomain(3, blocks, rank, flen)
+    comm = Communicator(dom, ops)
+    if case == "jacobi_l3":
+        P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="jacobi", omega=0.8, stencil="unit",
+                                  restrict_scale=4.0, tol=1e-5, cg_max=512), ops, dom, comm)
+    elif case == "rbgs_l3":
+        P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="rbgs", omega=1.0, stencil="unit",
+                                  restrict_scale=4.0, tol=1e-5, cg_max=512), ops, dom, comm)
+    else:
+        P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, frag_len=flen, tol=1e-6, fused_coarse=False), ops, dom, comm)
+    P.setup()
+    P.Solve()
+    S = P.Solution[4]
+    arr = S.data().numpy().reshape(S.layout.shape_zyx)
+    sg, sl = _global_index(dom, S.layout, 4)
+    np.save(os.path.join(out_dir, "sol_%d.npy" % rank), arr[sl])
+    json.dump({"res": P.res_history, "it": P.iterations, "slices": [[s.start, s.stop] for s in sg], "log": P.log,
+               "messages": comm.stats["messages"]}, open(os.path.join(out_dir, "res_%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _reference_single(case):
+    from oracle_ops import OracleOps
+
+    from exastencils_amd.solver import ConfigL3, ConfigL4, SolverFromL3, SolverFromL4
+
+    ops = OracleOps()
+    flen = (2, 2, 2)
+    if case == "jacobi_l3":
+        P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="jacobi", omega=0.8, stencil="unit",
+                                  restrict_scale=4.0, tol=1e-5, cg_max=512), ops)
+    elif case == "rbgs_l3":
+        P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="rbgs", omega=1.0, stencil="unit",
+                                  restrict_scale=4.0, tol=1e-5, cg_max=512), ops)
+    else:
+        P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, frag_len=flen, tol=1e-6, fused_coarse=False), ops)
+    P.setup()
+    P.Solve()
+    S = P.Solution[4]
+    lay = S.layout
+    arr = S.data().numpy().reshape(lay.shape_zyx)
+    own = arr[lay.ref(2):lay.ref(2) + 33, lay.ref(1):lay.ref(1) + 33, lay.ref(0):lay.ref(0) + 33]
+    return P, own
+
+
+@pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"),
+                                         ((2, 2, 1), "jacobi_l3")])
+def test_decomposed_solve_matches_single_block(tmp_path, blocks, case):
+    world = blocks[0] * blocks[1] * blocks[2]
+    port = _free_port()
+    mp.spawn(_worker_solver, args=(world, port, blocks, case, str(tmp_path)), nprocs=world, join=True)
+    P, own = _reference_single(case)
+    for r in range(world):
+        meta = json.load(open(tmp_path / ("res_%d.json" % r)))
+        assert meta["it"] == P.iterations
+        assert meta["messages"] > 0
+        for x, y in zip(meta["res"], P.res_history):
+            assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * P.res_history[0], (meta["res"], P.res_history)
+        sol = np.load(tmp_path / ("sol_%d.npy" % r))
+        (z0, z1), (y0, y1), (x0, x1) = meta["slices"]
+        ref = own[z0:z1, y0:y1, x0:x1]
+        assert sol.shape == ref.shape
+        assert np.allclose(sol, ref, rtol=1e-9, atol=1e-12), np.abs(sol - ref).max()
+
+
+# -------------------------------------------------------------------------------------------------
+def _worker_27pt(rank, world, port, out_dir):
+    """One 27-point stencil application after `communicate`: needs valid edge ghosts."""
+    _init(rank, world, port)
+    from oracle_ops import OracleOps
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.field import Field, Stencil
+    from exastencils_amd.layout import FieldLayout
+
+    ops = OracleOps()
+    blocks = (2, 2, 1)
+    dom = RectDomain(3, blocks, rank, (1, 1, 2))
+    comm = Communicator(dom, ops)
+    L = 3
+    lay = FieldLayout.node(3, dom.ncells(L), 1)
+    U, V = Field("U", L, lay, ops), Field("V", L, lay, ops)
+    # global field g(x,y,z) = random per global node; owned nodes filled from it, ghosts left zero
+    n = 16
+    rng = np.random.RandomState(7)
+    G = rng.rand(n + 1, n + 1, n + 1)
+    sg, sl = _global_index(dom, lay, L)
+    u = U.data().numpy().reshape(lay.shape_zyx)
+    u[sl] = G[sg]
+    comm.exchange(U)
+    offs = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)]
+    co = [1.0 + 0.1 * i for i in range(27)]
+    st = Stencil(offs, co)
+    b, e = dom.loop_bounds(lay)
+    ops.stencil_op(0, U.lc, U.data(), None, None, V.lc, V.data(), st, 0.0, -1, b, e)
+    v = V.data().numpy().reshape(lay.shape_zyx)
+    np.save(os.path.join(out_dir, "v_%d.npy" % rank), v[sl])
+    json.dump({"slices": [[s.start, s.stop] for s in sg], "b": b, "e": e}, open(os.path.join(out_dir, "m_%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_corner_ghosts_with_six_neighbours(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_27pt, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    n = 16
+    rng = np.random.RandomState(7)
+    G = rng.rand(n + 1, n + 1, n + 1)
+    offs = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)]
+    co = [1.0 + 0.1 * i for i in range(27)]
+    ref = np.zeros_like(G)
+    acc = None
+    for (a, b, c), w in zip(offs, co):
+        t = w * G[1 + c:n + c, 1 + b:n + b, 1 + a:n + a]
+        acc = t if acc is None else acc + t
+    ref[1:n, 1:n, 1:n] = acc
+    for r in range(4):
+        m = json.load(open(tmp_path / ("m_%d.json" % r)))
+        v = np.load(tmp_path / ("v_%d.npy" % r))
+        (z0, z1), (y0, y1), (x0, x1) = m["slices"]
+        want = ref[z0:z1, y0:y1, x0:x1]
+        # compare on the points this block's loop updated (global interior)
+        mask = np.zeros_like(want, dtype=bool)
+        mask[max(1 - z0, 0):min(n, z1) - z0, max(1 - y0, 0):min(n, y1) - y0, max(1 - x0, 0):min(n, x1) - x0] = True
+        assert np.array_equal(v[mask], want[mask])
