@@ -141,6 +141,7 @@ __device__ __forceinline__ double finish(double u, double acc, double f, double 
 }
 
 struct ZMarchGeom {
+  int colour;         // COL kernels: the colour to update
   int ntx, ntt, ntm;  // tiles per dim: x, tile-row dim T, march dim M
   int mc;             // planes (or rows) per march chunk
   int nblocks;        // ntx * ntt * ntm
@@ -159,10 +160,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // Tile = 128 x-points (2 per lane) by RY rows per wave, WY waves per workgroup, marching along M.
 //   MY = false: rows are y, march is z (register pipeline holds u[z-1], u[z], u[z+1]);
 //   MY = true : rows are z, march is y (consecutive steps are 1 row = ~4 KB apart: TLB-friendly).
-template <int MODE, int ORDER, int RY, int WY, bool NT, bool MY, int PF, bool REV>
+// COL: red-black half sweep in place (dst == u): of the two points a lane holds per row exactly one has
+//   (i0+i1+i2) % 2 == g.colour; it is updated, the other is written back unchanged (whole 16-byte stores).
+//   Race-free: only values of the other colour (never written in this sweep) and the lane's own centre are used.
+template <bool ALIAS> struct Ptr { typedef double *__restrict__ out; typedef const double *__restrict__ in; };
+template <> struct Ptr<true> { typedef double *out; typedef const double *in; };
+
+template <int MODE, int ORDER, int RY, int WY, bool NT, bool MY, int PF, bool REV, bool COL>
 __global__ void __launch_bounds__(64 * WY)
-k_stencil7_zmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev ld,
-                  double *__restrict__ dst, Coef7 k, double w, Box box, ZMarchGeom g) {
+k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev ld,
+                  typename Ptr<COL>::out dst, Coef7 k, double w, Box box, ZMarchGeom g) {
   const int lane = threadIdx.x;   // 0..63
   const int wv = threadIdx.y;     // wave in block
   int t = g.remap ? xcd_remap(blockIdx.x, g.nblocks) : (int)blockIdx.x;
@@ -239,17 +246,30 @@ k_stencil7_zmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
       const d2 tp_ = (r == RY - 1) ? st.hp : uc[r == RY - 1 ? r : r + 1];
       const d2 mm_ = REV ? st.up[r] : um[r];   // plane m-1 and m+1 along the march dimension
       const d2 mp_ = REV ? um[r] : st.up[r];
-      double acc_a, acc_b;
-      if (MY) {
-        acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, mm_.x, mp_.x, tm_.x, tp_.x);
-        acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, mm_.y, mp_.y, tm_.y, tp_.y);
-      } else {
-        acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, tm_.x, tp_.x, mm_.x, mp_.x);
-        acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, tm_.y, tp_.y, mm_.y, mp_.y);
-      }
       d2 o;
-      o.x = finish<MODE>(uc[r].x, acc_a, st.f[r].x, w);
-      o.y = finish<MODE>(uc[r].y, acc_b, st.f[r].y, w);
+      if (COL) {
+        // the point of this lane's pair that carries the colour: a if (x + row + m) is of that parity, else b
+        const bool sel_a = ((x + rw + r + m) & 1) == g.colour;
+        const double c_ = sel_a ? uc[r].x : uc[r].y;
+        const double xm_ = sel_a ? xl : uc[r].x, xp_ = sel_a ? uc[r].y : xr;
+        const double t0 = sel_a ? tm_.x : tm_.y, t1 = sel_a ? tp_.x : tp_.y;
+        const double q0 = sel_a ? mm_.x : mm_.y, q1 = sel_a ? mp_.x : mp_.y;
+        const double acc = MY ? conv7<ORDER>(k, c_, xm_, xp_, q0, q1, t0, t1) : conv7<ORDER>(k, c_, xm_, xp_, t0, t1, q0, q1);
+        const double nv = finish<MODE>(c_, acc, sel_a ? st.f[r].x : st.f[r].y, w);
+        o.x = sel_a ? nv : uc[r].x;
+        o.y = sel_a ? uc[r].y : nv;
+      } else {
+        double acc_a, acc_b;
+        if (MY) {
+          acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, mm_.x, mp_.x, tm_.x, tp_.x);
+          acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, mm_.y, mp_.y, tm_.y, tp_.y);
+        } else {
+          acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, tm_.x, tp_.x, mm_.x, mp_.x);
+          acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, tm_.y, tp_.y, mm_.y, mp_.y);
+        }
+        o.x = finish<MODE>(uc[r].x, acc_a, st.f[r].x, w);
+        o.y = finish<MODE>(uc[r].y, acc_b, st.f[r].y, w);
+      }
       if (rw + r < eT) {
         double *q = dr[r] + dM * m;
         if (vb) {
@@ -313,7 +333,7 @@ static bool g_dir_toggle = false;
 
 template <int MODE, int ORDER, int RY, int WY, bool NT, bool MY, int PF>
 static void launch_zmarch_t(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                            double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
+                            double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
   const int nT = MY ? box.n2() : box.n1(), nM = MY ? box.n1() : box.n2();
   ZMarchGeom g;
   g.ntx = (box.n0() + 127) / 128;
@@ -328,15 +348,22 @@ static void launch_zmarch_t(const LayoutDev &lu, const double *u, const LayoutDe
   g.ntm = (nM + mc - 1) / mc;
   g.nblocks = g.ntx * g.ntt * g.ntm;
   g.remap = g_tune.remap;
+  g.colour = colour;
   dim3 block(64, WY, 1), grid(g.nblocks, 1, 1);
+  if (colour >= 0) {
+    if (MODE == EXAMG_SMOOTH)
+      hipLaunchKernelGGL((k_stencil7_zmarch<EXAMG_SMOOTH, ORDER, RY, WY, NT, MY, PF, false, true>), grid, block, 0, s, lu, u, lf,
+                         rhs, ld, dst, k, w, box, g);
+    return;
+  }
   // Sweep direction (tuning knob `dir`; -1 alternates from launch to launch so that a sweep starts where the
   // previous one ended).  Measured on MI355X at 256^3 and 512^3: no gain -- the 256 MiB Infinity Cache does not
   // hold streamed data long enough -- so the shipped default is always forward.  Results do not depend on it.
   bool rev;
   if (g_tune.dir < 0) { rev = g_dir_toggle; g_dir_toggle = !g_dir_toggle; }
   else rev = g_tune.dir != 0;
-  if (rev) hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, RY, WY, NT, MY, PF, true>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
-  else hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, RY, WY, NT, MY, PF, false>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  if (rev) hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, RY, WY, NT, MY, PF, true, false>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  else hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, RY, WY, NT, MY, PF, false, false>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
 }
 
 #ifdef EXAMG_TUNE
@@ -368,7 +395,11 @@ static void launch_zmarch_wy(const LayoutDev &lu, const double *u, const LayoutD
 }
 template <int MODE, int ORDER>
 static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
+                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
+  if (colour >= 0) {
+    launch_zmarch_t<MODE, ORDER, EXAMG_ZM_RY, EXAMG_ZM_WY, EXAMG_ZM_NT, EXAMG_ZM_MY, EXAMG_ZM_PF>(lu, u, lf, rhs, ld, dst, k, w, box, s, colour);
+    return;
+  }
   switch (g_tune.ry) {
     case 1: launch_zmarch_wy<MODE, ORDER, 1>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
     case 4: launch_zmarch_wy<MODE, ORDER, 4>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
@@ -378,8 +409,8 @@ static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev 
 #else
 template <int MODE, int ORDER>
 static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
-  launch_zmarch_t<MODE, ORDER, EXAMG_ZM_RY, EXAMG_ZM_WY, EXAMG_ZM_NT, EXAMG_ZM_MY, EXAMG_ZM_PF>(lu, u, lf, rhs, ld, dst, k, w, box, s);
+                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
+  launch_zmarch_t<MODE, ORDER, EXAMG_ZM_RY, EXAMG_ZM_WY, EXAMG_ZM_NT, EXAMG_ZM_MY, EXAMG_ZM_PF>(lu, u, lf, rhs, ld, dst, k, w, box, s, colour);
 }
 #endif
 
@@ -434,10 +465,11 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   hipStream_t s = (hipStream_t)stream;
 
   const int ord = order7(st);
-  if (!g_force_generic && lu_->nd == 3 && ord >= 0 && colour < 0 && box.n0() >= 64) {
+  const bool colour_ok = colour < 0 || (mode == EXAMG_SMOOTH && u == dst && memcmp(lu_, ld_, sizeof(*lu_)) == 0);
+  if (!g_force_generic && lu_->nd == 3 && ord >= 0 && colour_ok && box.n0() >= 64) {
     Coef7 k;
     for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
-#define EXAMG_ZM(M, O) launch_zmarch<M, O>(lu, u, lf, rhs, ld, dst, k, w, box, s)
+#define EXAMG_ZM(M, O) launch_zmarch<M, O>(lu, u, lf, rhs, ld, dst, k, w, box, s, colour)
     if (ord == 0) {
       if (mode == EXAMG_APPLY) EXAMG_ZM(EXAMG_APPLY, 0);
       else if (mode == EXAMG_RESIDUAL) EXAMG_ZM(EXAMG_RESIDUAL, 0);

@@ -116,12 +116,24 @@ def test_stencil7_padded_layout(hip, orc):
 
 
 @pytest.mark.parametrize("colour", [0, 1])
-@pytest.mark.parametrize("n", [33, 64])
-def test_rbgs_half_sweep_bit_exact(hip, orc, colour, n):
-    st = laplace_fd(3, (1.0 / n,) * 3)
+@pytest.mark.parametrize("order", ["mp", "pm"])
+@pytest.mark.parametrize("n", [33, 64, 65, 130])
+def test_rbgs_half_sweep_bit_exact(hip, orc, colour, order, n):
+    """n >= 65 takes the coloured z-march fast path (in place), 33 the generic kernel."""
+    st = laplace_fd(3, (1.0 / n,) * 3, order)
     b, e = box(3, n)
     g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, SMOOTH, colour, b, e))
     assert_same(g, c, "rbgs colour %d" % colour)
+
+
+def test_rbgs_interior_faces_and_odd_box(hip, orc):
+    """Half sweeps on a block with neighbours (loop starts at the duplicate node, index 0) and odd extents."""
+    shape = (97, 40, 24)
+    st = laplace_unit(3)
+    for colour in (0, 1):
+        b, e = [0, 1, 0], [98, 40, 24]
+        g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, shape, st, SMOOTH, colour, b, e))
+        assert_same(g, c, "rbgs interior faces")
 
 
 def test_generic_path_equals_fast_path(hip, orc):
