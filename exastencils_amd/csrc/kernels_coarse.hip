@@ -230,20 +230,3 @@ extern "C" int examg_cg_coarse(const examg_layout_t *lu_, double *sol, const exa
   EXAMG_CHECK_LAUNCH("k_cg_coarse");
   return 0;
 }
-
-// First implementation of the fused sweep: copy, then two in-place half sweeps on the copy.
-// (Correct; the single-pass 24 B/LU kernel replaces it in kernels_rbgs.hip when present.)
-extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_in, double *u_out,
-                                      const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w,
-                                      int first, const int32_t *begin, const int32_t *end, examg_stream_t stream) {
-  if (!lu || !u_in || !u_out) { set_error("examg_rbgs_sweep_fused: null argument"); return 1; }
-  if (u_in == u_out) { set_error("examg_rbgs_sweep_fused: out of place only"); return 1; }
-  if (first != 0 && first != 1) { set_error("examg_rbgs_sweep_fused: first colour must be 0 or 1"); return 1; }
-  const LayoutDev l = make_layout(lu);
-  int rc = check_hip(hipMemcpyAsync(u_out, u_in, (size_t)l.size * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream),
-                     "examg_rbgs_sweep_fused copy");
-  if (rc) return rc;
-  rc = examg_rbgs_colour(lu, u_out, lf, rhs, st, w, first, begin, end, stream);
-  if (rc) return rc;
-  return examg_rbgs_colour(lu, u_out, lf, rhs, st, w, 1 - first, begin, end, stream);
-}

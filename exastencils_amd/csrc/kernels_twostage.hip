@@ -1,0 +1,323 @@
+// Two dependent 7-point stencil applications in ONE pass over HBM (gfx950):
+//   * fused red-black Gauss-Seidel sweep: stage 1 updates the points of the first colour, stage 2 the
+//     points of the other colour from the stage-1 values -- exactly the two `color with` loops of
+//     Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:204-213, which the reference runs as two launches
+//     over the full box (48 B per update pair; Compiler/src/exastencils/baseExt/l4/L4_ColorLoops.scala:44-66);
+//   * two Jacobi steps (Testing/Smoothers/Jac.exa4:125-131 applied twice): temporal blocking, the
+//     reference's IR_ContractingLoop idea (baseExt/ir/IR_ContractingLoop.scala) for the
+//     CommFullTempBlockable layouts of the generated-from-L3 programs.
+// Both read u and rhs once and write the result once: 24 B per point per pass.
+//
+// Structure: out of place (u_out != u_in, the caller swaps pointers), so tiles are independent: every wave
+// recomputes the stage-1 values of its halo (2-point halo in x, y and z of the input, 1-point halo of the
+// stage-1 field).  A wave loads a 128-point x window (2 per lane) and produces the inner 124; it owns RY rows,
+// computes stage 1 on RY+2 rows from RY+4 loaded rows, and marches in z with 3-plane register rings for the
+// input and for the stage-1 field.  x-neighbours come from the adjacent lanes.
+// Arithmetic per point is the same expression, in the same order, as the one-stage kernels: results are
+// bit-identical to running the two loops one after the other.
+#include "examg_common.h"
+
+namespace examg {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(8))) d2u_ts { double a, b; };
+
+struct Coef7 {
+  double c[7];
+};
+
+template <int ORDER>
+__device__ __forceinline__ double conv7(const Coef7 &k, double c, double xm, double xp, double ym, double yp, double zm,
+                                        double zp) {
+  double acc = k.c[0] * c;
+  if (ORDER == 0) {
+    acc = acc + k.c[1] * xm;
+    acc = acc + k.c[2] * xp;
+    acc = acc + k.c[3] * ym;
+    acc = acc + k.c[4] * yp;
+    acc = acc + k.c[5] * zm;
+    acc = acc + k.c[6] * zp;
+  } else {
+    acc = acc + k.c[1] * xp;
+    acc = acc + k.c[2] * xm;
+    acc = acc + k.c[3] * yp;
+    acc = acc + k.c[4] * ym;
+    acc = acc + k.c[5] * zp;
+    acc = acc + k.c[6] * zm;
+  }
+  return acc;
+}
+
+struct TSGeom {
+  int ntx, nty, ntz, zc, nblocks;
+  int first;               // COL: colour updated in stage 1
+  int ax0, ax1, ay0, ay1, az0, az1;  // allocation of u in iterator coordinates, half open
+};
+
+constexpr int TS_OUT = 124;  // outputs per 128-point window
+
+// 16-byte load where both points are inside the allocation, scalar loads at the edges, 0 outside
+__device__ __forceinline__ d2 load2g(const double *p, bool oka, bool okb) {
+  d2 r = {0.0, 0.0};
+  if (oka && okb) {
+    const d2u_ts v = *reinterpret_cast<const d2u_ts *>(p);
+    r.x = v.a;
+    r.y = v.b;
+  } else if (oka) {
+    r.x = p[0];
+  } else if (okb) {
+    r.y = p[1];
+  }
+  return r;
+}
+
+template <int ORDER, bool COL, int RY, int WY, bool NT>
+__global__ void __launch_bounds__(64 * WY)
+k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs,
+             double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g) {
+  constexpr int RU = RY + 4;  // input rows per plane
+  constexpr int RV = RY + 2;  // stage-1 rows per plane
+  const int lane = threadIdx.x, wv = threadIdx.y;
+  int t = blockIdx.x;
+  const int tx = t % g.ntx;
+  t /= g.ntx;
+  const int ty = t % g.nty;
+  const int tz = t / g.nty;
+
+  const int xa = box.b0 - 2 + TS_OUT * tx + 2 * lane;  // this lane's points: xa, xa + 1
+  const int rw = box.b1 + (ty * WY + wv) * RY;           // first own row
+  const int mb = box.b2 + tz * g.zc;
+  const int me = min(mb + g.zc, box.e2);
+  if (rw >= box.e1) return;  // wave-uniform
+
+  const bool alloc_a = xa >= g.ax0 && xa < g.ax1, alloc_b = xa + 1 >= g.ax0 && xa + 1 < g.ax1;
+  const bool inx_a = xa >= box.b0 && xa < box.e0, inx_b = xa + 1 >= box.b0 && xa + 1 < box.e0;
+  // lanes 1..62 produce output (window-relative points 2..125)
+  const bool out_lane = lane >= 1 && lane <= 62;
+
+  const double *ubase = u + lu.origin + xa;
+  const double *fbase = rhs + lf.origin + xa;
+  double *obase = out + lu.origin + xa;
+
+  // input ring: U[s][i] = plane slot s, row rw - 2 + i ; stage-1 ring: V[s][i] = row rw - 1 + i
+  d2 U[3][RU], V[3][RV];
+  d2 Fown[RY];  // rhs of the own rows on the plane that stage 2 handles next
+
+  auto row_ok = [&](int row) { return row >= g.ay0 && row < g.ay1; };
+  auto load_plane = [&](d2 (&P)[RU], int p) {
+    const bool pok = p >= g.az0 && p < g.az1;
+#pragma unroll
+    for (int i = 0; i < RU; ++i) {
+      const int row = rw - 2 + i;
+      const bool ok = pok && row_ok(row);
+      P[i] = load2g(ubase + lu.s1 * row + lu.s2 * p, ok && alloc_a, ok && alloc_b);
+    }
+  };
+
+  // stage 1 on plane p: VP = stage-1 field from input planes Um (p-1), Uc (p), Up (p+1)
+  auto stage1 = [&](d2 (&VP)[RV], const d2 (&Um)[RU], const d2 (&Uc)[RU], const d2 (&Up)[RU], d2 (&Fkeep)[RY], int p) {
+    const bool pin = p >= box.b2 && p < box.e2;
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+      const int row = rw - 1 + i;
+      const d2 c = Uc[i + 1];
+      d2 v = c;
+      const bool rin = pin && row >= box.b1 && row < box.e1;  // wave-uniform
+      if (rin) {
+        const bool da = inx_a, db = inx_b;
+        d2 f = load2g(fbase + lf.s1 * row + lf.s2 * p, da, db);
+        if (i >= 1 && i <= RY) Fkeep[i - 1] = f;
+        const double xl = __shfl_up(c.y, 1), xr = __shfl_down(c.x, 1);
+        const int par = (xa + row + p) & 1;  // parity of point a; b has the other one
+        const bool ua = da && (!COL || par == g.first);
+        const bool ub = db && (!COL || par != g.first);
+        const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Uc[i].x, Uc[i + 2].x, Um[i + 1].x, Up[i + 1].x);
+        const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Uc[i].y, Uc[i + 2].y, Um[i + 1].y, Up[i + 1].y);
+        const double na = c.x + w * (f.x - acc_a);
+        const double nb = c.y + w * (f.y - acc_b);
+        v.x = ua ? na : c.x;
+        v.y = ub ? nb : c.y;
+      }
+      VP[i] = v;
+    }
+  };
+
+  // stage 2 on plane m: result from stage-1 planes Vm (m-1), Vc (m), Vp (m+1); own rows only
+  auto stage2 = [&](const d2 (&Vm)[RV], const d2 (&Vc)[RV], const d2 (&Vp)[RV], const d2 (&F)[RY], int m) {
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      const int row = rw + r;
+      if (row >= box.e1) continue;  // wave-uniform
+      const d2 c = Vc[r + 1];
+      const double xl = __shfl_up(c.y, 1), xr = __shfl_down(c.x, 1);
+      const int par = (xa + row + m) & 1;
+      const bool ua = inx_a && (!COL || par != g.first);
+      const bool ub = inx_b && (!COL || par == g.first);
+      const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Vc[r].x, Vc[r + 2].x, Vm[r + 1].x, Vp[r + 1].x);
+      const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Vc[r].y, Vc[r + 2].y, Vm[r + 1].y, Vp[r + 1].y);
+      const double na = c.x + w * (F[r].x - acc_a);
+      const double nb = c.y + w * (F[r].y - acc_b);
+      d2 o;
+      o.x = ua ? na : c.x;
+      o.y = ub ? nb : c.y;
+      if (out_lane) {
+        double *q = obase + lu.s1 * row + lu.s2 * m;
+        if (inx_a && inx_b) {
+          if (NT) {
+            __builtin_nontemporal_store(o.x, q);
+            __builtin_nontemporal_store(o.y, q + 1);
+          } else {
+            d2u_ts s;
+            s.a = o.x;
+            s.b = o.y;
+            *reinterpret_cast<d2u_ts *>(q) = s;
+          }
+        } else if (inx_a) {
+          q[0] = o.x;
+        } else if (inx_b) {
+          q[1] = o.y;
+        }
+      }
+    }
+  };
+
+  // pipeline over q = mb-1 .. me: load u(q+1), stage 1 on plane q, stage 2 on plane q-1.
+  // ring slot of plane p: (p - (mb - 2)) % 3
+  d2 Fnext[RY];
+  load_plane(U[0], mb - 2);
+  load_plane(U[1], mb - 1);
+  // V slot for plane mb-2 is never read before it is written (stage 2 starts at plane mb)
+  int q = mb - 1;
+  while (q <= me) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (q <= me) {
+        // slots: plane q-1 -> j, q -> j+1, q+1 -> j+2 (mod 3); V: plane q-2 -> j+2... same ring convention
+        load_plane(U[(j + 2) % 3], q + 1);
+        stage1(V[(j + 1) % 3], U[j], U[(j + 1) % 3], U[(j + 2) % 3], Fnext, q);
+        if (q - 1 >= mb) stage2(V[(j + 2) % 3], V[j], V[(j + 1) % 3], Fown, q - 1);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) Fown[r] = Fnext[r];
+        ++q;
+      }
+    }
+  }
+}
+
+static int order7_ts(const examg_stencil_t *st) {
+  static const int o0[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+  static const int o1[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+  if (st->nent != 7 || st->cfield) return -1;
+  bool m0 = true, m1 = true;
+  for (int k = 0; k < 7; ++k)
+    for (int d = 0; d < 3; ++d) {
+      m0 = m0 && st->off[k][d] == o0[k][d];
+      m1 = m1 && st->off[k][d] == o1[k][d];
+    }
+  return m0 ? 0 : (m1 ? 1 : -1);
+}
+
+static int g_ts_blocks = 1024;
+static int g_ts_disable = 0;
+
+template <bool COL>
+static int launch_two_stage(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
+                            double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s) {
+  constexpr int RY = 2, WY = 4;
+  const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
+  TSGeom g;
+  g.ntx = (box.n0() + TS_OUT - 1) / TS_OUT;
+  g.nty = (box.n1() + RY * WY - 1) / (RY * WY);
+  const int xy = g.ntx * g.nty;
+  int ntz = (g_ts_blocks + xy - 1) / xy;
+  if (ntz < 1) ntz = 1;
+  int zc = (box.n2() + ntz - 1) / ntz;
+  if (zc < 16) zc = 16;
+  if (zc > box.n2()) zc = box.n2();
+  g.zc = zc;
+  g.ntz = (box.n2() + zc - 1) / zc;
+  g.nblocks = xy * g.ntz;
+  g.first = first;
+  g.ax0 = -lu.ref0; g.ax1 = lu.tot0 - lu.ref0;
+  g.ay0 = -lu.ref1; g.ay1 = lu.tot1 - lu.ref1;
+  g.az0 = -lu.ref2; g.az1 = lu.tot2 - lu.ref2;
+  Coef7 k;
+  for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
+  const int ord = order7_ts(st);
+  dim3 block(64, WY, 1), grid(g.nblocks, 1, 1);
+  if (ord == 0) hipLaunchKernelGGL((k_two_stage7<0, COL, RY, WY, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
+  else hipLaunchKernelGGL((k_two_stage7<1, COL, RY, WY, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
+  EXAMG_CHECK_LAUNCH("k_two_stage7");
+  return 0;
+}
+
+static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
+  return !g_ts_disable && lu->nd == 3 && order7_ts(st) >= 0 && box.n0() >= 64 && box_inside(lu, box, 1) &&
+         box_inside(lf, box, 0);
+}
+
+}  // namespace examg
+
+using namespace examg;
+
+extern "C" int examg_debug_two_stage(int disable, int blocks) {
+  g_ts_disable = disable;
+  if (blocks > 0) g_ts_blocks = blocks;
+  return 0;
+}
+
+// One full red-black sweep, out of place.
+extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_in, double *u_out,
+                                      const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w,
+                                      int first, const int32_t *begin, const int32_t *end, examg_stream_t stream) {
+  if (!lu || !u_in || !u_out || !lf || !rhs || !st || !begin || !end) { set_error("examg_rbgs_sweep_fused: null argument"); return 1; }
+  if (u_in == u_out) { set_error("examg_rbgs_sweep_fused: out of place only"); return 1; }
+  if (first != 0 && first != 1) { set_error("examg_rbgs_sweep_fused: first colour must be 0 or 1"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (two_stage_ok(lu, lf, st, box)) return launch_two_stage<true>(lu, u_in, lf, rhs, u_out, st, w, first, box, (hipStream_t)stream);
+  // general stencils / small boxes: bring the box and its one-stencil-reach shell over, then the two half
+  // sweeps in place on the copy (the shell of u_out receives u_in's shell values -- see the header)
+  int reach = 0;
+  for (int k = 0; k < st->nent; ++k)
+    for (int d = 0; d < 3; ++d) reach = reach > abs(st->off[k][d]) ? reach : abs(st->off[k][d]);
+  int32_t b2[3], e2[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool on = d < lu->nd;
+    b2[d] = begin[d] - (on ? reach : 0);
+    e2[d] = end[d] + (on ? reach : 0);
+  }
+  int rc = examg_axpby(lu, u_in, lu, u_out, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_rbgs_colour(lu, u_out, lf, rhs, st, w, first, begin, end, stream);
+  if (rc) return rc;
+  return examg_rbgs_colour(lu, u_out, lf, rhs, st, w, 1 - first, begin, end, stream);
+}
+
+// Two Jacobi steps, u_in -> (u_in's values after two sweeps) in u_out; `tmp` is only used by the fallback
+// (general stencils / small boxes), where it receives the intermediate sweep.
+extern "C" int examg_jacobi2(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp,
+                             const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w,
+                             const int32_t *begin, const int32_t *end, examg_stream_t stream) {
+  if (!lu || !u_in || !u_out || !lf || !rhs || !st || !begin || !end) { set_error("examg_jacobi2: null argument"); return 1; }
+  if (u_in == u_out) { set_error("examg_jacobi2: out of place only"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (two_stage_ok(lu, lf, st, box)) return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box, (hipStream_t)stream);
+  if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2: fallback needs a distinct tmp array"); return 1; }
+  // the intermediate sweep needs the box's shell (Dirichlet / halo values) in tmp
+  int reach = 0;
+  for (int k = 0; k < st->nent; ++k)
+    for (int d = 0; d < 3; ++d) reach = reach > abs(st->off[k][d]) ? reach : abs(st->off[k][d]);
+  int32_t b2[3], e2[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool on = d < lu->nd;
+    b2[d] = begin[d] - (on ? reach : 0);
+    e2[d] = end[d] + (on ? reach : 0);
+  }
+  int rc = examg_axpby(lu, u_in, lu, tmp, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_jacobi(lu, u_in, tmp, lf, rhs, st, w, begin, end, stream);
+  if (rc) return rc;
+  return examg_jacobi(lu, tmp, u_out, lf, rhs, st, w, begin, end, stream);
+}

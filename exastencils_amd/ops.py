@@ -67,6 +67,12 @@ class HipOps:
                                             C.byref(sc), float(w), int(first), ivec(begin), ivec(end), self._stream()),
               "examg_rbgs_sweep_fused")
 
+    def jacobi2(self, lu, u_in, u_out, tmp, lf, rhs, st: Stencil, w: float, begin, end):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_jacobi2(C.byref(lu), self.ptr(u_in), self.ptr(u_out), self.ptr(tmp) if tmp is not None else None,
+                                   C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin), ivec(end), self._stream()),
+              "examg_jacobi2")
+
     # -- inter-grid -------------------------------------------------------------------------------
     def restrict(self, lfine, rf, lc, fc, scale: float, begin, end):
         check(self.L.examg_restrict(C.byref(lfine), self.ptr(rf), C.byref(lc), self.ptr(fc), float(scale), ivec(begin),

@@ -200,6 +200,7 @@ class SolverFromL4(_Program):
                 alt = self._sol_alt[l]
                 self.ops.rbgs_sweep_fused(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e)
                 self._sol_alt[l], S.slots[0] = S.slots[0], alt
+                self.apply_bc(S)      # the sweep writes the loop's box only; the Dirichlet shell comes from `apply bc`
             return
         for _ in range(self.cfg.n_smooth):
             for colour in (0, 1):
@@ -320,6 +321,7 @@ class ConfigL3:
     kappa: float = 10.0
     fmg: bool = False
     align: int = 0
+    temporal_blocking: bool = False   # single block: pairs of Jacobi steps in one pass (examg_jacobi2)
 
 
 class SolverFromL3(_Program):
@@ -391,6 +393,31 @@ class SolverFromL3(_Program):
                 self.communicate(S, S.active)
                 self.ops.stencil_op(SMOOTH, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, self._w(l), colour, b, e)
 
+    # `repeat n times { Smoother@current ( ) }`
+    def Smoothers(self, l: int, n: int):
+        cfg = self.cfg
+        if not (cfg.temporal_blocking and cfg.smoother == "jacobi" and self._single_block() and cfg.stencil != "varcoeff"):
+            for _ in range(n):
+                self.Smoother(l)
+            return
+        # Single block: `communicate ghost of Solution` is empty, so two consecutive Smoother calls are two Jacobi steps
+        # on the same data: one pass over HBM computes both (the reference's contracting-loop idea).  Reads slot
+        # <active>, writes slot <next>; two `advance`s would return to <active>, so the result slot is reached by one.
+        S, F, A = self.Solution[l], self.RHS[l], self.Laplace[l]
+        b, e = self.bounds(S)
+        k = n
+        while k >= 2:
+            if not hasattr(self, "_jac_tmp"):
+                self._jac_tmp = {}
+            tmp = self._jac_tmp.get(l)
+            if tmp is None:
+                tmp = self._jac_tmp[l] = self.ops.new_array(S.layout.size)
+            self.ops.jacobi2(S.lc, S.data(S.active), S.data(S.next), tmp, F.lc, F.data(), A, self._w(l), b, e)
+            S.advance()
+            k -= 2
+        if k:
+            self.Smoother(l)
+
     # Function Restriction / Correction / SetSolution
     def Restriction(self, l: int):
         R, Fc = self.Residual[l], self.RHS[l - 1]
@@ -413,15 +440,13 @@ class SolverFromL3(_Program):
     def VCycle(self, l: int):
         if l == self.cfg.min_level:
             return self.VCycle_0(l)
-        for _ in range(self.cfg.n_smooth):
-            self.Smoother(l)
+        self.Smoothers(l, self.cfg.n_smooth)
         self.UpResidual(l)
         self.Restriction(l)
         self.SetSolution(l - 1, 0.0)
         self.VCycle(l - 1)
         self.Correction(l)
-        for _ in range(self.cfg.n_smooth):
-            self.Smoother(l)
+        self.Smoothers(l, self.cfg.n_smooth)
 
     # Function VCycle_0@coarsest (Testing/Smoothers/Jac.exa4:75-109)
     def VCycle_0(self, l: int):

@@ -124,13 +124,23 @@ int examg_residual(const examg_layout_t *lu, const double *u, const examg_layout
                    const examg_layout_t *lr, double *res, const examg_stencil_t *st, const int32_t *begin,
                    const int32_t *end, examg_stream_t stream);
 
-/* One full red-black sweep (colour `first`, then the other) out of place: u_out receives exactly
- * what two examg_rbgs_colour calls on u_in would leave in the box [begin,end); points of the
- * u_in box's one-point shell (duplicate/ghost layers, Dirichlet values) are copied through so that
- * u_out can take u_in's place (pointer swap by the caller).  24 B/LU instead of 48 B/LU. */
+/* One full red-black sweep (colour `first`, then the other) out of place, in ONE pass over HBM: the points of
+ * [begin,end) of u_out receive exactly (bit for bit) what the two examg_rbgs_colour calls would leave there;
+ * outside the box at most the one-stencil-reach shell is touched, and only by copying u_in's values there; the
+ * caller keeps u_out's duplicate/ghost shell valid the way the program does anyway (`apply bc` / `communicate`
+ * after the loop) and swaps the two pointers.  24 B per update instead of 48 B.  3-D 7-point constant stencils
+ * take the two-stage kernel (writes the box only); anything else falls back to copy + two half sweeps. */
 int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_in, double *u_out, const examg_layout_t *lf,
                            const double *rhs, const examg_stencil_t *st, double w, int first, const int32_t *begin,
                            const int32_t *end, examg_stream_t stream);
+
+/* Two Jacobi steps (Smoother called twice, Testing/Smoothers/Jac.exa4:125-131) in ONE pass: temporal blocking in the
+ * sense of baseExt/ir/IR_ContractingLoop.scala.  u_out[box] = J(J(u_in)); bit-identical to two examg_jacobi calls
+ * u_in -> tmp -> u_out.  Only valid when no halo exchange is needed between the two steps (single block, or ghost
+ * layers two deep); `tmp` is used by the fallback path only (general stencils, small boxes) and may be NULL otherwise. */
+int examg_jacobi2(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp, const examg_layout_t *lf,
+                  const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end,
+                  examg_stream_t stream);
 
 /* ---- K4: RHS@coarser = scale * R * Residual, R = kron [1/4 1/2 1/4]
  * (operator/l4/L4_DefaultRestriction.scala:29-36,63-88; solver/ir/IR_ResolveIntergridIndices.scala);

@@ -83,6 +83,10 @@ class OracleOps:
         for c in (first, 1 - first):
             self.stencil_op(2, lu, u_out, lf, rhs, lu, u_out, st, w, c, begin, end)
 
+    def jacobi2(self, lu, u_in, u_out, tmp, lf, rhs, st, w, begin, end):
+        self.stencil_op(2, lu, u_in, lf, rhs, lu, tmp, st, w, -1, begin, end)
+        self.stencil_op(2, lu, tmp, lf, rhs, lu, u_out, st, w, -1, begin, end)
+
     def restrict(self, lfine, rf, lc, fc, scale, begin, end):
         self.L.orc_restrict(_lp(lfine), self.ptr(rf), _lp(lc), self.ptr(fc), float(scale), _iv(begin), _iv(end))
 

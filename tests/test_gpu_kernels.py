@@ -136,6 +136,86 @@ def test_rbgs_interior_faces_and_odd_box(hip, orc):
         assert_same(g, c, "rbgs interior faces")
 
 
+def _two_stage_case(ops, kind, shape, st, b, e, first=0):
+    lu = FieldLayout.node(3, shape, 1)
+    lf = FieldLayout.node(3, shape, 0)
+    u, f, out, tmp = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size)
+    ops.fill_random(u, 12345)
+    ops.fill_random(f, 4711)
+    ops.fill_random(out, 5)          # whatever was in the output array outside the box must survive
+    w = 0.8 / st.diag
+    if kind == "rbgs":
+        ops.rbgs_sweep_fused(lu.c_struct(), u, out, lf.c_struct(), f, st, w, first, b, e)
+    else:
+        ops.jacobi2(lu.c_struct(), u, out, tmp, lf.c_struct(), f, st, w, b, e)
+    return [out, u]
+
+
+def _two_stage_reference(orc, kind, shape, st, b, e, first=0):
+    """Two separate loops on the CPU; outside the box the output array keeps its previous content."""
+    lu = FieldLayout.node(3, shape, 1)
+    lf = FieldLayout.node(3, shape, 0)
+    u, f, out, tmp = orc.new_array(lu.size), orc.new_array(lf.size), orc.new_array(lu.size), orc.new_array(lu.size)
+    orc.fill_random(u, 12345)
+    orc.fill_random(f, 4711)
+    orc.fill_random(out, 5)
+    w = 0.8 / st.diag
+    L, Fl = lu.c_struct(), lf.c_struct()
+    if kind == "rbgs":
+        work = u.clone()
+        for c in (first, 1 - first):
+            orc.stencil_op(SMOOTH, L, work, Fl, f, L, work, st, w, c, b, e)
+    else:
+        tmp.copy_(u)
+        orc.stencil_op(SMOOTH, L, u, Fl, f, L, tmp, st, w, -1, b, e)
+        work = u.clone()
+        orc.stencil_op(SMOOTH, L, tmp, Fl, f, L, work, st, w, -1, b, e)
+    orc.axpby(L, work, L, out, 1.0, 0.0, b, e)      # box only
+    return [orc.to_host(out), orc.to_host(u)]
+
+
+@pytest.mark.parametrize("kind", ["rbgs", "jacobi2"])
+@pytest.mark.parametrize("order", ["mp", "pm"])
+@pytest.mark.parametrize("n,first", [(65, 0), (130, 1), (200, 0)])
+def test_two_stage_kernel_bit_exact(hip, orc, kind, order, n, first):
+    """Fused red-black sweep / two Jacobi steps in one pass == the two loops run one after the other, bit for bit;
+    130 and 200 leave ragged 124-point x windows, row groups and z chunks."""
+    st = laplace_fd(3, (1.0 / n,) * 3, order)
+    b, e = box(3, n)
+    g = _two_stage_case(hip, kind, (n, n, n), st, b, e, first)
+    hip.synchronize()
+    c = _two_stage_reference(orc, kind, (n, n, n), st, b, e, first)
+    assert_same([hip.to_host(t) for t in g], c, "two-stage " + kind)
+
+
+@pytest.mark.parametrize("kind", ["rbgs", "jacobi2"])
+def test_two_stage_interior_faces_anisotropic(hip, orc, kind):
+    """Block with neighbours on some faces: the loop includes the duplicate planes (begin 0 / end n+1), so the
+    two-point input halo reaches the ghost layer and beyond the allocation (guarded)."""
+    shape = (150, 36, 20)
+    st = laplace_unit(3)
+    b, e = [0, 1, 0], [151, 36, 21]
+    g = _two_stage_case(hip, kind, shape, st, b, e)
+    hip.synchronize()
+    c = _two_stage_reference(orc, kind, shape, st, b, e)
+    assert_same([hip.to_host(t) for t in g], c, "two-stage faces " + kind)
+
+
+def test_two_stage_fallback_small_and_2d(hip, orc):
+    """Boxes the fused kernel does not take (rows < 64 points) go through copy + two loops: same result."""
+    n = 24
+    st = laplace_fd(3, (1.0 / n,) * 3)
+    b, e = box(3, n)
+    for kind in ("rbgs", "jacobi2"):
+        g = _two_stage_case(hip, kind, (n, n, n), st, b, e)
+        hip.synchronize()
+        c = _two_stage_reference(orc, kind, (n, n, n), st, b, e)
+        got = [hip.to_host(t) for t in g]
+        lu = FieldLayout.node(3, (n, n, n), 1)
+        sl = (slice(2, n + 1),) * 3          # the box (array index = iterator + 1)
+        assert np.array_equal(got[0].reshape(lu.shape_zyx)[sl], c[0].reshape(lu.shape_zyx)[sl]), kind
+
+
 def test_generic_path_equals_fast_path(hip, orc):
     n = 96
     st = laplace_fd(3, (1.0 / n,) * 3)

@@ -118,6 +118,22 @@ def test_fused_rbgs_sweep_bit_exact(hip):
         assert np.array_equal(hip.to_host(a.Solution[l].data()), hip.to_host(b.Solution[l].data())), l
 
 
+def test_temporal_blocking_jacobi_bit_exact(hip):
+    """SolverFromL3 with pairs of Jacobi steps fused (examg_jacobi2) follows the plain program bit for bit."""
+    from exastencils_amd.solver import ConfigL3, SolverFromL3
+
+    res = []
+    for tb in (False, True):
+        P = SolverFromL3(ConfigL3(nd=3, min_level=2, max_level=7, smoother="jacobi", omega=0.8, stencil="unit",
+                                  restrict_scale=4.0, tol=1e-5, cg_max=512, temporal_blocking=tb), hip)
+        P.setup()
+        P.Solve()
+        res.append(P)
+    assert res[0].res_history == res[1].res_history
+    S0, S1 = res[0].Solution[7], res[1].Solution[7]
+    assert np.array_equal(hip.to_host(S0.data()), hip.to_host(S1.data()))
+
+
 def test_config3_512_properties(hip):
     """Config 3 (512^3, levels 4..9) at full size, through size-independent properties: the V-cycle contracts
     the residual by the factor the oracle shows at 128^3 (multigrid convergence is h-independent), the history
