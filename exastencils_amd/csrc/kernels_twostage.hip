@@ -99,8 +99,10 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
   const double *fbase = rhs + lf.origin + xa;
   double *obase = out + lu.origin + xa;
 
-  // input ring: U[s][i] = plane slot s, row rw - 2 + i ; stage-1 ring: V[s][i] = row rw - 1 + i
-  d2 U[3][RU], V[3][RV];
+  // input ring: U[s][i] = plane slot s, row rw - 2 + i ; stage-1 ring: V[s][i] = row rw - 1 + i.
+  // Four slots: while plane q is processed the loads of plane q+2 (and rhs of q+1) are already in flight.
+  d2 U[4][RU], V[4][RV];
+  d2 F[2][RV];  // rhs on the stage-1 rows: F[q & 1] belongs to plane q
   d2 Fown[RY];  // rhs of the own rows on the plane that stage 2 handles next
 
   auto row_ok = [&](int row) { return row >= g.ay0 && row < g.ay1; };
@@ -115,7 +117,16 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
   };
 
   // stage 1 on plane p: VP = stage-1 field from input planes Um (p-1), Uc (p), Up (p+1)
-  auto stage1 = [&](d2 (&VP)[RV], const d2 (&Um)[RU], const d2 (&Uc)[RU], const d2 (&Up)[RU], d2 (&Fkeep)[RY], int p) {
+  auto load_rhs = [&](d2 (&FP)[RV], int p) {
+    const bool pin = p >= box.b2 && p < box.e2;
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+      const int row = rw - 1 + i;
+      const bool rin = pin && row >= box.b1 && row < box.e1;
+      FP[i] = load2g(fbase + lf.s1 * row + lf.s2 * p, rin && inx_a, rin && inx_b);
+    }
+  };
+  auto stage1 = [&](d2 (&VP)[RV], const d2 (&Um)[RU], const d2 (&Uc)[RU], const d2 (&Up)[RU], const d2 (&FP)[RV], int p) {
     const bool pin = p >= box.b2 && p < box.e2;
 #pragma unroll
     for (int i = 0; i < RV; ++i) {
@@ -125,8 +136,7 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
       const bool rin = pin && row >= box.b1 && row < box.e1;  // wave-uniform
       if (rin) {
         const bool da = inx_a, db = inx_b;
-        d2 f = load2g(fbase + lf.s1 * row + lf.s2 * p, da, db);
-        if (i >= 1 && i <= RY) Fkeep[i - 1] = f;
+        const d2 f = FP[i];
         const double xl = __shfl_up(c.y, 1), xr = __shfl_down(c.x, 1);
         const int par = (xa + row + p) & 1;  // parity of point a; b has the other one
         const bool ua = da && (!COL || par == g.first);
@@ -181,23 +191,26 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
     }
   };
 
-  // pipeline over q = mb-1 .. me: load u(q+1), stage 1 on plane q, stage 2 on plane q-1.
-  // ring slot of plane p: (p - (mb - 2)) % 3
-  d2 Fnext[RY];
+  // pipeline over q = mb-1 .. me: prefetch u(q+2) and rhs(q+1), stage 1 on plane q, stage 2 on plane q-1.
+  // ring slot of plane p: (p - (mb - 2)) & 3 ; rhs buffer of plane p: (p - (mb - 1)) & 1
   load_plane(U[0], mb - 2);
   load_plane(U[1], mb - 1);
-  // V slot for plane mb-2 is never read before it is written (stage 2 starts at plane mb)
+  load_plane(U[2], mb);
+  load_rhs(F[0], mb - 1);
   int q = mb - 1;
   while (q <= me) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 4; ++j) {
       if (q <= me) {
-        // slots: plane q-1 -> j, q -> j+1, q+1 -> j+2 (mod 3); V: plane q-2 -> j+2... same ring convention
-        load_plane(U[(j + 2) % 3], q + 1);
-        stage1(V[(j + 1) % 3], U[j], U[(j + 1) % 3], U[(j + 2) % 3], Fnext, q);
-        if (q - 1 >= mb) stage2(V[(j + 2) % 3], V[j], V[(j + 1) % 3], Fown, q - 1);
+        // slots: plane q-1 -> j, q -> j+1, q+1 -> j+2, q+2 -> j+3 (mod 4); plane q-2 (stage-1 field) -> j+3
+        if (q + 1 <= me) {
+          load_plane(U[(j + 3) & 3], q + 2);
+          load_rhs(F[(j + 1) & 1], q + 1);
+        }
+        stage1(V[(j + 1) & 3], U[j], U[(j + 1) & 3], U[(j + 2) & 3], F[j & 1], q);
+        if (q - 1 >= mb) stage2(V[(j + 3) & 3], V[j], V[(j + 1) & 3], Fown, q - 1);
 #pragma unroll
-        for (int r = 0; r < RY; ++r) Fown[r] = Fnext[r];
+        for (int r = 0; r < RY; ++r) Fown[r] = F[j & 1][r + 1];
         ++q;
       }
     }
