@@ -104,6 +104,21 @@ __device__ static inline double eval_fn(int fn, const double *p, double x, doubl
   }
 }
 
+// Wavefront-level halo exchange: value of the neighbouring lane through DPP wave shifts (one v_mov_b32_dpp per
+// dword, no LDS crossbar round trip as with ds_bpermute / __shfl).  Lane 0 (resp. 63) keeps its own value.
+__device__ __forceinline__ double lane_below(double v) {   // lane l receives lane l-1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);   // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_above(double v) {   // lane l receives lane l+1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);   // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 struct Params4 {
   double v[4];
 };

@@ -238,8 +238,8 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
       // wavefront-level x-halo exchange
-      double xl = __shfl_up(uc[r].y, 1);
-      double xr = __shfl_down(uc[r].x, 1);
+      double xl = lane_below(uc[r].y);
+      double xr = lane_above(uc[r].x);
       if (lload) xl = ur[r][uM * m - 1];
       if (rload) xr = ur[r][uM * m + 2];
       const d2 tm_ = (r == 0) ? st.hm : uc[r == 0 ? 0 : r - 1];

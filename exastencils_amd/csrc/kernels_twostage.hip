@@ -49,7 +49,7 @@ __device__ __forceinline__ double conv7(const Coef7 &k, double c, double xm, dou
 }
 
 struct TSGeom {
-  int ntx, nty, ntz, zc, nblocks;
+  int ntx, nty, ntz, zc, nblocks, remap;
   int first;               // COL: colour updated in stage 1
   int ax0, ax1, ay0, ay1, az0, az1;  // allocation of u in iterator coordinates, half open
 };
@@ -79,6 +79,10 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
   constexpr int RV = RY + 2;  // stage-1 rows per plane
   const int lane = threadIdx.x, wv = threadIdx.y;
   int t = blockIdx.x;
+  if (g.remap) {  // XCD-contiguous tile order: y-adjacent tiles share their halo rows in one L2
+    const int per = g.nblocks >> 3;
+    if (t < (per << 3)) t = (t & 7) * per + (t >> 3);
+  }
   const int tx = t % g.ntx;
   t /= g.ntx;
   const int ty = t % g.nty;
@@ -137,16 +141,26 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
       if (rin) {
         const bool da = inx_a, db = inx_b;
         const d2 f = FP[i];
-        const double xl = __shfl_up(c.y, 1), xr = __shfl_down(c.x, 1);
+        const double xl = lane_below(c.y), xr = lane_above(c.x);
         const int par = (xa + row + p) & 1;  // parity of point a; b has the other one
-        const bool ua = da && (!COL || par == g.first);
-        const bool ub = db && (!COL || par != g.first);
-        const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Uc[i].x, Uc[i + 2].x, Um[i + 1].x, Up[i + 1].x);
-        const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Uc[i].y, Uc[i + 2].y, Um[i + 1].y, Up[i + 1].y);
-        const double na = c.x + w * (f.x - acc_a);
-        const double nb = c.y + w * (f.y - acc_b);
-        v.x = ua ? na : c.x;
-        v.y = ub ? nb : c.y;
+        if (COL) {
+          // exactly one point of the pair carries the stage-1 colour: one convolution per pair
+          const bool sa = par == g.first;
+          const double cc = sa ? c.x : c.y;
+          const double acc = conv7<ORDER>(k, cc, sa ? xl : c.x, sa ? c.y : xr, sa ? Uc[i].x : Uc[i].y,
+                                          sa ? Uc[i + 2].x : Uc[i + 2].y, sa ? Um[i + 1].x : Um[i + 1].y,
+                                          sa ? Up[i + 1].x : Up[i + 1].y);
+          const double nv = cc + w * ((sa ? f.x : f.y) - acc);
+          v.x = (sa && da) ? nv : c.x;
+          v.y = (!sa && db) ? nv : c.y;
+        } else {
+          const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Uc[i].x, Uc[i + 2].x, Um[i + 1].x, Up[i + 1].x);
+          const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Uc[i].y, Uc[i + 2].y, Um[i + 1].y, Up[i + 1].y);
+          const double na = c.x + w * (f.x - acc_a);
+          const double nb = c.y + w * (f.y - acc_b);
+          v.x = da ? na : c.x;
+          v.y = db ? nb : c.y;
+        }
       }
       VP[i] = v;
     }
@@ -159,17 +173,26 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
       const int row = rw + r;
       if (row >= box.e1) continue;  // wave-uniform
       const d2 c = Vc[r + 1];
-      const double xl = __shfl_up(c.y, 1), xr = __shfl_down(c.x, 1);
+      const double xl = lane_below(c.y), xr = lane_above(c.x);
       const int par = (xa + row + m) & 1;
-      const bool ua = inx_a && (!COL || par != g.first);
-      const bool ub = inx_b && (!COL || par == g.first);
-      const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Vc[r].x, Vc[r + 2].x, Vm[r + 1].x, Vp[r + 1].x);
-      const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Vc[r].y, Vc[r + 2].y, Vm[r + 1].y, Vp[r + 1].y);
-      const double na = c.x + w * (F[r].x - acc_a);
-      const double nb = c.y + w * (F[r].y - acc_b);
       d2 o;
-      o.x = ua ? na : c.x;
-      o.y = ub ? nb : c.y;
+      if (COL) {
+        const bool sa = par != g.first;   // the point of the pair with the stage-2 colour
+        const double cc = sa ? c.x : c.y;
+        const double acc = conv7<ORDER>(k, cc, sa ? xl : c.x, sa ? c.y : xr, sa ? Vc[r].x : Vc[r].y,
+                                        sa ? Vc[r + 2].x : Vc[r + 2].y, sa ? Vm[r + 1].x : Vm[r + 1].y,
+                                        sa ? Vp[r + 1].x : Vp[r + 1].y);
+        const double nv = cc + w * ((sa ? F[r].x : F[r].y) - acc);
+        o.x = (sa && inx_a) ? nv : c.x;
+        o.y = (!sa && inx_b) ? nv : c.y;
+      } else {
+        const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Vc[r].x, Vc[r + 2].x, Vm[r + 1].x, Vp[r + 1].x);
+        const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Vc[r].y, Vc[r + 2].y, Vm[r + 1].y, Vp[r + 1].y);
+        const double na = c.x + w * (F[r].x - acc_a);
+        const double nb = c.y + w * (F[r].y - acc_b);
+        o.x = inx_a ? na : c.x;
+        o.y = inx_b ? nb : c.y;
+      }
       if (out_lane) {
         double *q = obase + lu.s1 * row + lu.s2 * m;
         if (inx_a && inx_b) {
@@ -230,13 +253,17 @@ static int order7_ts(const examg_stencil_t *st) {
   return m0 ? 0 : (m1 ? 1 : -1);
 }
 
-static int g_ts_blocks = 1024;
+// launch knobs, defaults from tools/tune_two_stage.py on MI355X (512^3: two Jacobi steps 0.89 ms, fused red-black
+// sweep 0.94 ms; 256^3: 0.138 / 0.146 ms): 8 waves per workgroup, ~4096 workgroups, plain tile order
+static int g_ts_blocks = 4096;
 static int g_ts_disable = 0;
+static int g_ts_remap = 0;
+static int g_ts_wy = 8;
 
-template <bool COL>
-static int launch_two_stage(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
-                            double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s) {
-  constexpr int RY = 2, WY = 4;
+template <bool COL, int WY>
+static int launch_two_stage_w(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
+                              double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s) {
+  constexpr int RY = 2;
   const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
   TSGeom g;
   g.ntx = (box.n0() + TS_OUT - 1) / TS_OUT;
@@ -250,6 +277,7 @@ static int launch_two_stage(const examg_layout_t *lu_, const double *u, const ex
   g.zc = zc;
   g.ntz = (box.n2() + zc - 1) / zc;
   g.nblocks = xy * g.ntz;
+  g.remap = g_ts_remap;
   g.first = first;
   g.ax0 = -lu.ref0; g.ax1 = lu.tot0 - lu.ref0;
   g.ay0 = -lu.ref1; g.ay1 = lu.tot1 - lu.ref1;
@@ -264,6 +292,14 @@ static int launch_two_stage(const examg_layout_t *lu_, const double *u, const ex
   return 0;
 }
 
+template <bool COL>
+static int launch_two_stage(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
+                            double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s) {
+  if (g_ts_wy == 8) return launch_two_stage_w<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, s);
+  if (g_ts_wy == 2) return launch_two_stage_w<COL, 2>(lu_, u, lf_, rhs, out, st, w, first, box, s);
+  return launch_two_stage_w<COL, 4>(lu_, u, lf_, rhs, out, st, w, first, box, s);
+}
+
 static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
   return !g_ts_disable && lu->nd == 3 && order7_ts(st) >= 0 && box.n0() >= 64 && box_inside(lu, box, 1) &&
          box_inside(lf, box, 0);
@@ -273,9 +309,11 @@ static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, con
 
 using namespace examg;
 
-extern "C" int examg_debug_two_stage(int disable, int blocks) {
+extern "C" int examg_debug_two_stage(int disable, int blocks, int remap, int wy) {
   g_ts_disable = disable;
   if (blocks > 0) g_ts_blocks = blocks;
+  if (remap >= 0) g_ts_remap = remap;
+  if (wy > 0) g_ts_wy = wy;
   return 0;
 }
 
