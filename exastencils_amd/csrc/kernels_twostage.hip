@@ -51,6 +51,7 @@ __device__ __forceinline__ double conv7(const Coef7 &k, double c, double xm, dou
 struct TSGeom {
   int ntx, nty, ntz, zc, nblocks, remap;
   int first;               // COL: colour updated in stage 1
+  Box box1;                // stage-1 box (contains the output box); points outside keep the input value
   int ax0, ax1, ay0, ay1, az0, az1;  // allocation of u in iterator coordinates, half open
 };
 
@@ -96,6 +97,8 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
 
   const bool alloc_a = xa >= g.ax0 && xa < g.ax1, alloc_b = xa + 1 >= g.ax0 && xa + 1 < g.ax1;
   const bool inx_a = xa >= box.b0 && xa < box.e0, inx_b = xa + 1 >= box.b0 && xa + 1 < box.e0;
+  const Box &box1 = g.box1;
+  const bool in1_a = xa >= box1.b0 && xa < box1.e0, in1_b = xa + 1 >= box1.b0 && xa + 1 < box1.e0;
   // lanes 1..62 produce output (window-relative points 2..125)
   const bool out_lane = lane >= 1 && lane <= 62;
 
@@ -122,24 +125,24 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
 
   // stage 1 on plane p: VP = stage-1 field from input planes Um (p-1), Uc (p), Up (p+1)
   auto load_rhs = [&](d2 (&FP)[RV], int p) {
-    const bool pin = p >= box.b2 && p < box.e2;
+    const bool pin = p >= box1.b2 && p < box1.e2;
 #pragma unroll
     for (int i = 0; i < RV; ++i) {
       const int row = rw - 1 + i;
-      const bool rin = pin && row >= box.b1 && row < box.e1;
-      FP[i] = load2g(fbase + lf.s1 * row + lf.s2 * p, rin && inx_a, rin && inx_b);
+      const bool rin = pin && row >= box1.b1 && row < box1.e1;
+      FP[i] = load2g(fbase + lf.s1 * row + lf.s2 * p, rin && in1_a, rin && in1_b);
     }
   };
   auto stage1 = [&](d2 (&VP)[RV], const d2 (&Um)[RU], const d2 (&Uc)[RU], const d2 (&Up)[RU], const d2 (&FP)[RV], int p) {
-    const bool pin = p >= box.b2 && p < box.e2;
+    const bool pin = p >= box1.b2 && p < box1.e2;
 #pragma unroll
     for (int i = 0; i < RV; ++i) {
       const int row = rw - 1 + i;
       const d2 c = Uc[i + 1];
       d2 v = c;
-      const bool rin = pin && row >= box.b1 && row < box.e1;  // wave-uniform
+      const bool rin = pin && row >= box1.b1 && row < box1.e1;  // wave-uniform
       if (rin) {
-        const bool da = inx_a, db = inx_b;
+        const bool da = in1_a, db = in1_b;
         const d2 f = FP[i];
         const double xl = lane_below(c.y), xr = lane_above(c.x);
         const int par = (xa + row + p) & 1;  // parity of point a; b has the other one
@@ -262,7 +265,8 @@ static int g_ts_wy = 8;
 
 template <bool COL, int WY>
 static int launch_two_stage_w(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
-                              double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s) {
+                              double *out, const examg_stencil_t *st, double w, int first, const Box &box, const Box &box1,
+                              hipStream_t s) {
   constexpr int RY = 2;
   const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
   TSGeom g;
@@ -279,6 +283,7 @@ static int launch_two_stage_w(const examg_layout_t *lu_, const double *u, const 
   g.nblocks = xy * g.ntz;
   g.remap = g_ts_remap;
   g.first = first;
+  g.box1 = box1;
   g.ax0 = -lu.ref0; g.ax1 = lu.tot0 - lu.ref0;
   g.ay0 = -lu.ref1; g.ay1 = lu.tot1 - lu.ref1;
   g.az0 = -lu.ref2; g.az1 = lu.tot2 - lu.ref2;
@@ -294,10 +299,12 @@ static int launch_two_stage_w(const examg_layout_t *lu_, const double *u, const 
 
 template <bool COL>
 static int launch_two_stage(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
-                            double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s) {
-  if (g_ts_wy == 8) return launch_two_stage_w<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, s);
-  if (g_ts_wy == 2) return launch_two_stage_w<COL, 2>(lu_, u, lf_, rhs, out, st, w, first, box, s);
-  return launch_two_stage_w<COL, 4>(lu_, u, lf_, rhs, out, st, w, first, box, s);
+                            double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s,
+                            const Box *box1 = nullptr) {
+  const Box &b1 = box1 ? *box1 : box;
+  if (g_ts_wy == 8) return launch_two_stage_w<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
+  if (g_ts_wy == 2) return launch_two_stage_w<COL, 2>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
+  return launch_two_stage_w<COL, 4>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
 }
 
 static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
@@ -343,6 +350,40 @@ extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_
   rc = examg_rbgs_colour(lu, u_out, lf, rhs, st, w, first, begin, end, stream);
   if (rc) return rc;
   return examg_rbgs_colour(lu, u_out, lf, rhs, st, w, 1 - first, begin, end, stream);
+}
+
+// Two Jacobi steps with separate boxes: stage 1 = J on [begin1,end1) (points outside keep u_in's value), stage 2 = J of
+// that field on [begin2,end2) (inside box 1), written to u_out.  A block with neighbours uses box 2 = box 1 minus the
+// duplicate planes at interior faces: everything stage 2 needs there is local (exastencils_amd/solver.py: Smoothers).
+extern "C" int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp,
+                                   const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w,
+                                   const int32_t *begin1, const int32_t *end1, const int32_t *begin2, const int32_t *end2,
+                                   examg_stream_t stream) {
+  if (!lu || !u_in || !u_out || !lf || !rhs || !st || !begin1 || !end1 || !begin2 || !end2) { set_error("examg_jacobi2_boxes: null argument"); return 1; }
+  if (u_in == u_out) { set_error("examg_jacobi2_boxes: out of place only"); return 1; }
+  const Box box1 = make_box(begin1, end1), box2 = make_box(begin2, end2);
+  if (box2.count() == 0) return 0;
+  if (box2.b0 < box1.b0 || box2.b1 < box1.b1 || box2.b2 < box1.b2 || box2.e0 > box1.e0 || box2.e1 > box1.e1 || box2.e2 > box1.e2) {
+    set_error("examg_jacobi2_boxes: the stage-2 box must lie inside the stage-1 box");
+    return 1;
+  }
+  if (two_stage_ok(lu, lf, st, box2) && box_inside(lu, box1, 1) && box_inside(lf, box1, 0))
+    return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box2, (hipStream_t)stream, &box1);
+  if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2_boxes: fallback needs a distinct tmp array"); return 1; }
+  int reach = 0;
+  for (int k = 0; k < st->nent; ++k)
+    for (int d = 0; d < 3; ++d) reach = reach > abs(st->off[k][d]) ? reach : abs(st->off[k][d]);
+  int32_t b2[3], e2[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool on = d < lu->nd;
+    b2[d] = begin1[d] - (on ? reach : 0);
+    e2[d] = end1[d] + (on ? reach : 0);
+  }
+  int rc = examg_axpby(lu, u_in, lu, tmp, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_jacobi(lu, u_in, tmp, lf, rhs, st, w, begin1, end1, stream);
+  if (rc) return rc;
+  return examg_jacobi(lu, tmp, u_out, lf, rhs, st, w, begin2, end2, stream);
 }
 
 // Two Jacobi steps, u_in -> (u_in's values after two sweeps) in u_out; `tmp` is only used by the fallback

@@ -73,6 +73,12 @@ class HipOps:
                                    C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin), ivec(end), self._stream()),
               "examg_jacobi2")
 
+    def jacobi2_boxes(self, lu, u_in, u_out, tmp, lf, rhs, st: Stencil, w: float, begin1, end1, begin2, end2):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_jacobi2_boxes(C.byref(lu), self.ptr(u_in), self.ptr(u_out), self.ptr(tmp) if tmp is not None else None,
+                                         C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin1), ivec(end1),
+                                         ivec(begin2), ivec(end2), self._stream()), "examg_jacobi2_boxes")
+
     # -- inter-grid -------------------------------------------------------------------------------
     def restrict(self, lfine, rf, lc, fc, scale: float, begin, end):
         check(self.L.examg_restrict(C.byref(lfine), self.ptr(rf), C.byref(lc), self.ptr(fc), float(scale), ivec(begin),

@@ -1,0 +1,56 @@
+"""Temporally blocked smoother steps (two Jacobi steps per pass over HBM), also across block neighbours.
+
+Reference idea: `repeat n times with contraction` / IR_ContractingLoop (Compiler/src/exastencils/baseExt/ir/
+IR_ContractingLoop.scala; Testing/PolyExpl/Jac3Dcc.exa4:27) and the `Comm*TempBlockable` layouts of the
+generated-from-L3 programs.  The reference widens the ghost layers to block in time; here the ghost layers stay
+one deep (the drop-in layout) and the second step of the duplicate planes at interior faces is finished separately:
+
+  1. communicate ghost of u                                   (as every Smoother call does)
+  2. u_out = J(J(u)) on the loop's box minus the duplicate planes at interior faces   (examg_jacobi2_boxes;
+     the first step is evaluated on the whole box, so everything the second step needs there is local)
+  3. tmp = J(u) on the two planes next to every interior face   (thin launches)
+  4. communicate ghost of tmp                                  (the neighbours' first-step values)
+  5. u_out = J(tmp) on the duplicate planes at interior faces   (thin launches)
+
+Two exchanges per two steps -- as many as two plain Smoother calls -- and bit-identical results.  On a single block
+steps 3-5 vanish and 1 is empty.
+"""
+from __future__ import annotations
+
+SMOOTH = 2
+
+
+def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field):
+    """Two applications of `Smoother@current` (Testing/Smoothers/Jac.exa4:125-131) on field S (2 slots):
+    reads slot <active>, leaves the result in the slot two `advance`s would make active (the same one),
+    reached through one advance of the out-of-place pass.  tmp_field: scratch field of S's layout whose
+    Dirichlet shell holds S's boundary values."""
+    nd = domain.nd
+    b, e = domain.loop_bounds(S.layout)
+    src, dst = S.active, S.next
+    faces = [(d, side) for d in range(nd) for side in (-1, 1) if domain.neighbor(d, side) is not None]
+    comm.exchange(S, src, "ghost")
+    b2, e2 = list(b), list(e)
+    for d, side in faces:
+        if side < 0:
+            b2[d] = b[d] + 1
+        else:
+            e2[d] = e[d] - 1
+    ops.jacobi2_boxes(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, b, e, b2, e2)
+    if faces:
+        for d, side in faces:
+            sb, se = list(b), list(e)
+            if side < 0:
+                se[d] = b[d] + 2
+            else:
+                sb[d] = e[d] - 2
+            ops.stencil_op(SMOOTH, S.lc, S.data(src), F.lc, F.data(), tmp_field.lc, tmp_field.data(), A, w, -1, sb, se)
+        comm.exchange(tmp_field, None, "ghost")
+        for d, side in faces:
+            sb, se = list(b), list(e)
+            if side < 0:
+                se[d] = b[d] + 1
+            else:
+                sb[d] = e[d] - 1
+            ops.stencil_op(SMOOTH, tmp_field.lc, tmp_field.data(), F.lc, F.data(), S.lc, S.data(dst), A, w, -1, sb, se)
+    S.advance()

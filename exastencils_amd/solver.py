@@ -396,24 +396,23 @@ class SolverFromL3(_Program):
     # `repeat n times { Smoother@current ( ) }`
     def Smoothers(self, l: int, n: int):
         cfg = self.cfg
-        if not (cfg.temporal_blocking and cfg.smoother == "jacobi" and self._single_block() and cfg.stencil != "varcoeff"):
+        if not (cfg.temporal_blocking and cfg.smoother == "jacobi"):
             for _ in range(n):
                 self.Smoother(l)
             return
-        # Single block: `communicate ghost of Solution` is empty, so two consecutive Smoother calls are two Jacobi steps
-        # on the same data: one pass over HBM computes both (the reference's contracting-loop idea).  Reads slot
-        # <active>, writes slot <next>; two `advance`s would return to <active>, so the result slot is reached by one.
-        S, F, A = self.Solution[l], self.RHS[l], self.Laplace[l]
-        b, e = self.bounds(S)
+        # pairs of Smoother calls as one pass over HBM (exastencils_amd/smoothers.py), bit-identical
+        from .smoothers import jacobi_pair
+
+        S = self.Solution[l]
+        if not hasattr(self, "_pair_tmp"):
+            self._pair_tmp = {}
+        tmp = self._pair_tmp.get(l)
+        if tmp is None:
+            tmp = self._pair_tmp[l] = Field("SolutionTmp", l, S.layout, self.ops, 1, S.bc_fn, S.bc_params)
+            self.apply_bc(tmp)
         k = n
         while k >= 2:
-            if not hasattr(self, "_jac_tmp"):
-                self._jac_tmp = {}
-            tmp = self._jac_tmp.get(l)
-            if tmp is None:
-                tmp = self._jac_tmp[l] = self.ops.new_array(S.layout.size)
-            self.ops.jacobi2(S.lc, S.data(S.active), S.data(S.next), tmp, F.lc, F.data(), A, self._w(l), b, e)
-            S.advance()
+            jacobi_pair(self.ops, self.comm, self.domain, S, self.RHS[l], self.Laplace[l], self._w(l), tmp)
             k -= 2
         if k:
             self.Smoother(l)

@@ -142,6 +142,14 @@ int examg_jacobi2(const examg_layout_t *lu, const double *u_in, double *u_out, d
                   const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end,
                   examg_stream_t stream);
 
+/* As examg_jacobi2 with separate boxes: stage 1 = J on [begin1,end1) (points outside keep u_in's value), stage 2 = J of
+ * that field on [begin2,end2), inside box 1, written to u_out.  With block neighbours: box 1 = the loop's box, box 2 =
+ * box 1 without the duplicate planes at interior faces, whose second step needs the neighbour's first-step values
+ * (halo exchange of the intermediate field, then a thin single-step launch on those planes). */
+int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp, const examg_layout_t *lf,
+                        const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin1, const int32_t *end1,
+                        const int32_t *begin2, const int32_t *end2, examg_stream_t stream);
+
 /* ---- K4: RHS@coarser = scale * R * Residual, R = kron [1/4 1/2 1/4]
  * (operator/l4/L4_DefaultRestriction.scala:29-36,63-88; solver/ir/IR_ResolveIntergridIndices.scala);
  * begin/end: coarse iterator box. */

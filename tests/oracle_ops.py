@@ -87,6 +87,11 @@ class OracleOps:
         self.stencil_op(2, lu, u_in, lf, rhs, lu, tmp, st, w, -1, begin, end)
         self.stencil_op(2, lu, tmp, lf, rhs, lu, u_out, st, w, -1, begin, end)
 
+    def jacobi2_boxes(self, lu, u_in, u_out, tmp, lf, rhs, st, w, begin1, end1, begin2, end2):
+        tmp.copy_(u_in)
+        self.stencil_op(2, lu, u_in, lf, rhs, lu, tmp, st, w, -1, begin1, end1)
+        self.stencil_op(2, lu, tmp, lf, rhs, lu, u_out, st, w, -1, begin2, end2)
+
     def restrict(self, lfine, rf, lc, fc, scale, begin, end):
         self.L.orc_restrict(_lp(lfine), self.ptr(rf), _lp(lc), self.ptr(fc), float(scale), _iv(begin), _iv(end))
 

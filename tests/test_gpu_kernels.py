@@ -201,6 +201,29 @@ def test_two_stage_interior_faces_anisotropic(hip, orc, kind):
     assert_same([hip.to_host(t) for t in g], c, "two-stage faces " + kind)
 
 
+@pytest.mark.parametrize("shape,b,e,b2,e2", [
+    ((150, 36, 40), [0, 1, 0], [151, 36, 41], [1, 1, 1], [150, 36, 40]),     # neighbours in x and z: both dup planes excluded
+    ((130, 70, 33), [1, 0, 1], [130, 71, 33], [1, 1, 1], [130, 71, 33]),     # lower y neighbour only
+    ((40, 20, 20), [0, 1, 1], [41, 20, 20], [1, 1, 1], [41, 20, 20]),        # small rows: fallback path
+])
+def test_jacobi2_boxes_bit_exact(hip, orc, shape, b, e, b2, e2):
+    """Two Jacobi steps with the first step on the loop's box and the second on the box without the duplicate planes at
+    interior faces (what a block with neighbours runs, exastencils_amd/smoothers.py)."""
+    st = laplace_unit(3)
+
+    def f(ops):
+        lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+        u, fr, out, tmp = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size)
+        ops.fill_random(u, 12345)
+        ops.fill_random(fr, 4711)
+        ops.fill_random(out, 5)
+        ops.jacobi2_boxes(lu.c_struct(), u, out, tmp, lf.c_struct(), fr, st, 0.8 / st.diag, b, e, b2, e2)
+        return [out]
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "jacobi2_boxes")
+
+
 def test_two_stage_fallback_small_and_2d(hip, orc):
     """Boxes the fused kernel does not take (rows < 64 points) go through copy + two loops: same result."""
     n = 24
