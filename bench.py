@@ -214,7 +214,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("jacobi_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj["single_step" if args.no_temporal_blocking else "two_step"]["bytes_per_launch"]
             except Exception:
                 traffic = None
         out = {

@@ -81,7 +81,44 @@ static void run(const char *name, double *o, double *a, double *b, long long n, 
   fflush(stdout);
 }
 
-int main() {
+// calibration kernels for the FETCH_SIZE / WRITE_SIZE counters: known byte counts in the stencil kernels' access shape
+struct __attribute__((packed, aligned(8))) pk2 { double a, b; };
+__global__ void __launch_bounds__(256) k_read_unaligned(double *o, const double *a, long long n2) {
+  // 16-byte loads at 8-byte alignment (a is offset by one double), like rows of the 515-wide reference layout
+  dv2 acc = {0, 0};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+    const pk2 v = *reinterpret_cast<const pk2 *>(a + 2 * i);
+    acc.x += v.a;
+    acc.y += v.b;
+  }
+  if (acc.x + acc.y == 123.456) o[0] = acc.x;
+}
+__global__ void __launch_bounds__(256) k_write_unaligned(double *o, long long n2, double w) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+    __builtin_nontemporal_store(w, &o[2 * i]);
+    __builtin_nontemporal_store(w, &o[2 * i + 1]);
+  }
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1) {  // calibration mode: one launch each, known traffic (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+    const long long n = 515LL * 515 * 515;
+    double *a, *o;
+    CHECK(hipMalloc(&a, (n + 2) * 8));
+    CHECK(hipMalloc(&o, (n + 2) * 8));
+    CHECK(hipMemset(a, 0, (n + 2) * 8));
+    CHECK(hipDeviceSynchronize());
+    hipLaunchKernelGGL((k<2, false, false, 1>), dim3(4096), dim3(256), 0, 0, o, a, a, n / 2, 0.5);   // reads a twice: 2 * n * 8 B
+    CHECK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_read_unaligned, dim3(4096), dim3(256), 0, 0, o, a + 1, n / 2);           // n * 8 B at 8-byte alignment
+    CHECK(hipDeviceSynchronize());
+    hipLaunchKernelGGL((k<3, true, false, 1>), dim3(4096), dim3(256), 0, 0, o, a, a, n / 2, 0.5);    // writes n * 8 B
+    CHECK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_write_unaligned, dim3(4096), dim3(256), 0, 0, o + 1, n / 2, 0.5);        // writes n * 8 B, 8-byte aligned
+    CHECK(hipDeviceSynchronize());
+    printf("calibration: n*8 = %lld bytes\n", n * 8);
+    return 0;
+  }
   const long long n = 515LL * 515 * 515;  // one 512^3 field slot in the reference layout
   double *a, *b, *o;
   CHECK(hipMalloc(&a, n * 8));
