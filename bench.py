@@ -116,7 +116,7 @@ def main():
     ops = HipOps(local_rank)
     nd, L = 3, args.level
     dom = RectDomain(nd, RectDomain.blocks_for(world, nd), rank)
-    comm = Communicator(dom, ops)
+    comm = Communicator(dom, ops, concurrent_ghost_axes=True)   # 7-point stencil: face ghosts only
     nc = dom.ncells(L)
     Solution = Field("Solution", L, FieldLayout.node(nd, nc, 1), ops, 2, None)
     RHS = Field("RHS", L, FieldLayout.node(nd, nc, 0, False, False), ops, 1, None)
@@ -134,7 +134,7 @@ def main():
 
     def step():
         # Function Smoother@finest: communicate ghost of Solution<active>; Jacobi loop; advance
-        comm.exchange(Solution, Solution.active, "ghost")
+        comm.exchange(Solution, Solution.active, "ghost", axis_only=True)
         ops.stencil_op(2, Solution.lc, Solution.data(Solution.active), RHS.lc, RHS.data(), Solution.lc,
                        Solution.data(Solution.next), A, w, -1, b, e)
         Solution.advance()

@@ -29,7 +29,8 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field):
     b, e = domain.loop_bounds(S.layout)
     src, dst = S.active, S.next
     faces = [(d, side) for d in range(nd) for side in (-1, 1) if domain.neighbor(d, side) is not None]
-    comm.exchange(S, src, "ghost")
+    axis_only = all(sum(1 for c in o if c != 0) <= 1 for o in A.offsets)   # 5/7-point: face ghosts suffice
+    comm.exchange(S, src, "ghost", axis_only)
     b2, e2 = list(b), list(e)
     for d, side in faces:
         if side < 0:
@@ -45,7 +46,7 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field):
             else:
                 sb[d] = e[d] - 2
             ops.stencil_op(SMOOTH, S.lc, S.data(src), F.lc, F.data(), tmp_field.lc, tmp_field.data(), A, w, -1, sb, se)
-        comm.exchange(tmp_field, None, "ghost")
+        comm.exchange(tmp_field, None, "ghost", axis_only)
         for d, side in faces:
             sb, se = list(b), list(e)
             if side < 0:

@@ -68,10 +68,10 @@ def _worker_solver(rank, world, port, blocks, case, out_dir):
     ops = OracleOps()
     flen = tuple(2 // blocks[d] if d < 3 else 1 for d in range(3))
     dom = RectDomain(3, blocks, rank, flen)
-    comm = Communicator(dom, ops)
-    if case in ("jacobi_l3", "jacobi_l3_tb"):
+    comm = Communicator(dom, ops, concurrent_ghost_axes=case.endswith("_cg"))
+    if case in ("jacobi_l3", "jacobi_l3_tb", "jacobi_l3_tb_cg"):
         P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="jacobi", omega=0.8, stencil="unit",
-                                  restrict_scale=4.0, tol=1e-5, cg_max=512, temporal_blocking=case.endswith("_tb")), ops, dom, comm)
+                                  restrict_scale=4.0, tol=1e-5, cg_max=512, temporal_blocking="_tb" in case), ops, dom, comm)
     elif case == "rbgs_l3":
         P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="rbgs", omega=1.0, stencil="unit",
                                   restrict_scale=4.0, tol=1e-5, cg_max=512), ops, dom, comm)
@@ -96,7 +96,7 @@ def _reference_single(case):
 
     ops = OracleOps()
     flen = (2, 2, 2)
-    if case in ("jacobi_l3", "jacobi_l3_tb"):
+    if case in ("jacobi_l3", "jacobi_l3_tb", "jacobi_l3_tb_cg"):
         P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="jacobi", omega=0.8, stencil="unit",
                                   restrict_scale=4.0, tol=1e-5, cg_max=512), ops)
     elif case == "rbgs_l3":
@@ -114,7 +114,8 @@ def _reference_single(case):
 
 
 @pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"),
-                                         ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb")])
+                                         ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
+                                         ((2, 2, 1), "jacobi_l3_tb_cg")])
 def test_decomposed_solve_matches_single_block(tmp_path, blocks, case):
     world = blocks[0] * blocks[1] * blocks[2]
     port = _free_port()
