@@ -444,3 +444,39 @@ extern "C" int examg_debug_triad(double *o, const double *a, const double *b, in
   EXAMG_CHECK_LAUNCH("k_triad");
   return 0;
 }
+
+// ---- external fields (interfacing/ir/IR_CopyToExternalField.scala:31-90, IR_CopyFromExternalField.scala) ----------
+// get<Name>(dest, slot) / set<Name>(src, slot): copy between a caller-owned array in its own layout and the internal
+// field over [DLB - min(ghost_int, ghost_ext), DRE + min(ghost_int, ghost_ext)) per dimension; iterator coordinates
+// coincide (0 = lower duplicate node in both layouts).
+static int external_box(const examg_layout_t *li, const examg_layout_t *le, int32_t *b, int32_t *e) {
+  if (li->nd != le->nd) { set_error("external field: dimensionality mismatch"); return 1; }
+  for (int d = 0; d < 3; ++d) {
+    if (d >= li->nd) { b[d] = 0; e[d] = 1; continue; }
+    if (li->dup_l[d] != le->dup_l[d] || li->dup_r[d] != le->dup_r[d] || li->inner[d] != le->inner[d]) {
+      set_error("external field: duplicate/inner extents differ in dimension %d", d);
+      return 1;
+    }
+    const int gl = li->ghost_l[d] < le->ghost_l[d] ? li->ghost_l[d] : le->ghost_l[d];
+    const int gr = li->ghost_r[d] < le->ghost_r[d] ? li->ghost_r[d] : le->ghost_r[d];
+    b[d] = -gl;
+    e[d] = li->dup_l[d] + li->inner[d] + li->dup_r[d] + gr;
+  }
+  return 0;
+}
+
+extern "C" int examg_copy_to_external(const examg_layout_t *l_int, const double *x_int, const examg_layout_t *l_ext,
+                                      double *dest, examg_stream_t stream) {
+  if (!l_int || !x_int || !l_ext || !dest) { set_error("examg_copy_to_external: null argument"); return 1; }
+  int32_t b[3], e[3];
+  if (external_box(l_int, l_ext, b, e)) return 1;
+  return examg_axpby(l_int, x_int, l_ext, dest, 1.0, 0.0, b, e, stream);
+}
+
+extern "C" int examg_copy_from_external(const examg_layout_t *l_ext, const double *src, const examg_layout_t *l_int,
+                                        double *x_int, examg_stream_t stream) {
+  if (!l_int || !x_int || !l_ext || !src) { set_error("examg_copy_from_external: null argument"); return 1; }
+  int32_t b[3], e[3];
+  if (external_box(l_int, l_ext, b, e)) return 1;
+  return examg_axpby(l_ext, src, l_int, x_int, 1.0, 0.0, b, e, stream);
+}

@@ -46,7 +46,7 @@ SYMBOLS = [
     "examg_rbgs_colour", "examg_residual", "examg_rbgs_sweep_fused", "examg_jacobi2", "examg_jacobi2_boxes", "examg_restrict", "examg_prolong_add",
     "examg_set", "examg_axpby", "examg_axpby_dev", "examg_reduce_work_bytes", "examg_dot", "examg_max_err_fn",
     "examg_fill_fn", "examg_apply_dirichlet", "examg_init_varcoeff7", "examg_pack", "examg_unpack",
-    "examg_cg_coarse", "examg_fill_random",
+    "examg_cg_coarse", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
 ]
 
 
@@ -90,6 +90,8 @@ def load():
     L.examg_pack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_unpack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_cg_coarse.argtypes = [lp, vp, lp, vp, lp, vp, lp, vp, lp, vp, sp, gp, C.c_uint32, C.c_int, C.c_double, ip, ip, vp, vp]
+    L.examg_copy_to_external.argtypes = [lp, vp, lp, vp, vp]
+    L.examg_copy_from_external.argtypes = [lp, vp, lp, vp, vp]
     L.examg_fill_random.argtypes = [vp, C.c_int64, C.c_uint64, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported

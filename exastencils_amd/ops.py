@@ -47,6 +47,12 @@ class HipOps:
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
 
+    def side_stream(self):
+        """A second HIP stream for halo traffic that overlaps the interior kernels."""
+        if getattr(self, "_side", None) is None:
+            self._side = self.torch.cuda.Stream(self.device)
+        return self._side
+
     def to_host(self, t):
         return t.detach().cpu().numpy()
 
@@ -150,3 +156,12 @@ class HipOps:
 
     def fill_random(self, x, seed: int):
         check(self.L.examg_fill_random(self.ptr(x), int(x.numel()), int(seed), self._stream()), "examg_fill_random")
+
+    # -- external fields -------------------------------------------------------------------------------
+    def copy_to_external(self, l_int, x_int, l_ext, dest):
+        check(self.L.examg_copy_to_external(C.byref(l_int), self.ptr(x_int), C.byref(l_ext), self.ptr(dest), self._stream()),
+              "examg_copy_to_external")
+
+    def copy_from_external(self, l_ext, src, l_int, x_int):
+        check(self.L.examg_copy_from_external(C.byref(l_ext), self.ptr(src), C.byref(l_int), self.ptr(x_int), self._stream()),
+              "examg_copy_from_external")

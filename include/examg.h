@@ -214,6 +214,15 @@ int examg_cg_coarse(const examg_layout_t *lu, double *sol, const examg_layout_t 
                     uint32_t face_mask, int max_it, double rel_tol, const int32_t *begin, const int32_t *end,
                     double *info, examg_stream_t stream);
 
+/* ---- external fields: get<Name>(dest, slot) / set<Name>(src, slot) of `external Field` declarations
+ * (interfacing/ir/IR_CopyToExternalField.scala:31-90, IR_CopyFromExternalField.scala): device-to-device copy between a
+ * caller-owned array in its own layout (same duplicate/inner extents, its own ghost/pad widths) and the internal field
+ * over [DLB - min(ghosts), DRE + min(ghosts)) per dimension. */
+int examg_copy_to_external(const examg_layout_t *l_int, const double *x_int, const examg_layout_t *l_ext, double *dest,
+                           examg_stream_t stream);
+int examg_copy_from_external(const examg_layout_t *l_ext, const double *src, const examg_layout_t *l_int, double *x_int,
+                             examg_stream_t stream);
+
 /* Deterministic synthetic field (SplitMix64 of the linear index, U(-1,1)); same bits as the oracle's. */
 int examg_fill_random(double *x, int64_t n, uint64_t seed, examg_stream_t stream);
 

@@ -479,3 +479,32 @@ def test_bad_arguments_fail_loudly(hip):
         hip.stencil_op(SMOOTH, lu.c_struct(), u, lu.c_struct(), f, lu.c_struct(), u, st, 0.1, -1, [1, 1, 1], [n, n, n])
     with pytest.raises(ExamgError):      # residual without rhs
         hip.stencil_op(RESIDUAL, lu.c_struct(), u, None, None, lu.c_struct(), f, st, 0.1, -1, [1, 1, 1], [n, n, n])
+
+
+def test_external_field_copy(hip):
+    """get<Name>/set<Name>: internal NodeWithComm field <-> external layout without ghost layers and with padding."""
+    from exastencils_amd.external import ExternalField
+    from exastencils_amd.field import Field
+
+    n = 12
+    internal = FieldLayout.node(3, (n, n + 2, n - 2), 1)
+    F = Field("Solution", 3, internal, hip)
+    hip.fill_random(F.data(), 9)
+    for ext in (FieldLayout.node(3, (n, n + 2, n - 2), 0, align=4), FieldLayout.node(3, (n, n + 2, n - 2), 1)):
+        E = ExternalField("extSol", ext, F, hip)
+        got = E.get()
+        full = hip.to_host(F.data()).reshape(internal.shape_zyx)
+        g = min(ext.ghost[0], 1)
+        iz = slice(internal.ref(2) - g, internal.ref(2) + (n - 2) + 1 + g)
+        iy = slice(internal.ref(1) - g, internal.ref(1) + (n + 2) + 1 + g)
+        ix = slice(internal.ref(0) - g, internal.ref(0) + n + 1 + g)
+        ez = slice(ext.ref(2) - g, ext.ref(2) + (n - 2) + 1 + g)
+        ey = slice(ext.ref(1) - g, ext.ref(1) + (n + 2) + 1 + g)
+        ex = slice(ext.ref(0) - g, ext.ref(0) + n + 1 + g)
+        assert np.array_equal(got[ez, ey, ex], full[iz, iy, ix])
+        # round trip through set<Name>
+        new = np.arange(ext.size, dtype=np.float64).reshape(ext.shape_zyx)
+        E.set(new)
+        hip.synchronize()
+        full2 = hip.to_host(F.data()).reshape(internal.shape_zyx)
+        assert np.array_equal(full2[iz, iy, ix], new[ez, ey, ex])

@@ -134,6 +134,71 @@ def test_temporal_blocking_jacobi_bit_exact(hip):
     assert np.array_equal(hip.to_host(S0.data()), hip.to_host(S1.data()))
 
 
+class _LoopbackComm:
+    """Stands in for the block neighbours on ONE GPU: every interior face receives this block's own opposite inner
+    planes (pack -> unpack on the current stream).  Exercises the pack/unpack kernels, the thin face launches and the
+    stream/event logic of jacobi_pair without a second GPU."""
+
+    def __init__(self, domain, ops):
+        from exastencils_amd.comm import Communicator
+
+        self.domain, self.ops, self.C = domain, ops, Communicator
+        self.calls = 0
+
+    def exchange(self, f, slot=None, what="all", axis_only=False):
+        lay, nd = f.layout, self.domain.nd
+        x = f.data(slot)
+        for d in range(nd):
+            for side in (-1, 1):
+                if self.domain.neighbor(d, side) is None:
+                    continue
+                sbox, rbox = self.C.ghost_ranges(lay, nd, d, side)
+                buf = self.ops.new_array(self.C._count(sbox))
+                self.ops.pack(f.lc, x, buf, sbox[0], sbox[1])
+                self.ops.unpack(f.lc, x, buf, rbox[0], rbox[1])
+                self.calls += 1
+
+
+@pytest.mark.parametrize("rank", [0, 5])
+def test_jacobi_pair_overlap_equals_sequential(hip, rank):
+    """jacobi_pair on a block with interior faces (2x2x2 decomposition, loop-back neighbours): halo traffic on the side
+    stream overlapped with the interior kernel gives the same bits as the sequential order and as two single steps."""
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.field import Field, laplace_unit
+    from exastencils_amd.layout import FieldLayout
+    from exastencils_amd.smoothers import jacobi_pair
+
+    dom = RectDomain(3, (2, 2, 2), rank)
+    L = 7
+    lay, layf = FieldLayout.node(3, dom.ncells(L), 1), FieldLayout.node(3, dom.ncells(L), 0, False, False)
+    A = laplace_unit(3)
+    w = 0.8 / A.diag
+    outs = []
+    for mode in ("overlap", "sequential", "single"):
+        S, F, T = Field("S", L, lay, hip, 2, None), Field("F", L, layf, hip, 1, None), Field("T", L, lay, hip, 1, None)
+        hip.fill_random(S.data(0), 1)
+        S.data(1).copy_(S.data(0))      # both slots and the scratch field carry the same Dirichlet shell,
+        T.data().copy_(S.data(0))       # as `apply bc` leaves them in the programs
+        hip.fill_random(F.data(), 3)
+        comm = _LoopbackComm(dom, hip)
+        for _ in range(2):
+            if mode == "single":
+                for _k in range(2):
+                    comm.exchange(S, S.active, "ghost")
+                    b, e = dom.loop_bounds(lay)
+                    hip.stencil_op(2, S.lc, S.data(S.active), F.lc, F.data(), S.lc, S.data(S.next), A, w, -1, b, e)
+                    S.advance()
+            else:
+                jacobi_pair(hip, comm, dom, S, F, A, w, T, overlap=(mode == "overlap"))
+        hip.synchronize()
+        b, e = dom.loop_bounds(lay)
+        v = hip.to_host(S.data()).reshape(lay.shape_zyx)
+        outs.append(v[b[2] + 1:e[2] + 1, b[1] + 1:e[1] + 1, b[0] + 1:e[0] + 1].copy())
+        assert comm.calls > 0
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[2])
+
+
 def test_config3_512_properties(hip):
     """Config 3 (512^3, levels 4..9) at full size, through size-independent properties: the V-cycle contracts
     the residual by the factor the oracle shows at 128^3 (multigrid convergence is h-independent), the history

@@ -1,0 +1,45 @@
+"""`.knowledge` reader: flat key = value files with imports and comments, and the derived decomposition."""
+from exastencils_amd import knowledge as K
+
+JAC = """
+testing_enabled       = true
+dimensionality				= 3     // 3-D
+minLevel					= 0
+maxLevel					= 6
+domain_rect_generate			= true
+domain_rect_numBlocks_x			= 3
+domain_rect_numBlocks_y			= 3
+domain_rect_numBlocks_z			= 3
+domain_rect_numFragsPerBlock_x	= 3
+domain_rect_numFragsPerBlock_y	= 3
+domain_rect_numFragsPerBlock_z	= 3
+omp_enabled					= true
+omp_numThreads				= 3
+mpi_numThreads				= 27
+benchmark_backend = "likwid"
+cuda_preferredExecution        = 'Device'
+some_real = 1.5e-3
+"""
+
+
+def test_parse_and_derive():
+    k = K.parse_text(JAC)
+    assert k["testing_enabled"] is True and k["maxLevel"] == 6 and k["benchmark_backend"] == "likwid"
+    assert k["cuda_preferredExecution"] == "Device" and abs(k["some_real"] - 1.5e-3) < 1e-18
+    d = K.derive(k)
+    assert d["num_blocks"] == (3, 3, 3) and d["frags_total"] == (9, 9, 9)
+    assert d["cells_per_dim_finest"] == (576, 576, 576)          # Testing/Smoothers/Jac: 576^3
+    assert d["mpi_ranks"] == 27 and d["omp_threads"] == 3
+
+
+def test_import_and_domain(tmp_path):
+    (tmp_path / "lib").mkdir()
+    (tmp_path / "lib" / "domain.knowledge").write_text("domain_rect_numBlocks_x = 2\ndomain_rect_numBlocks_y = 2\n")
+    (tmp_path / "main.knowledge").write_text("dimensionality = 3\nmaxLevel = 5\nimport 'lib/domain.knowledge'\n"
+                                             "domain_fragmentLength_x = 2\ndomain_rect_numFragsPerBlock_z = 2\n")
+    k = K.parse_file(str(tmp_path / "main.knowledge"))
+    dom = K.domain_for_rank(k, 3)
+    assert dom.num_blocks == (2, 2, 1) and dom.pos == (1, 1, 0)
+    assert dom.frag_len == (2, 1, 2)
+    assert dom.ncells(5) == (64, 32, 64)
+    assert abs(dom.h(5)[0] - 1.0 / 128) < 1e-18 and abs(dom.h(5)[2] - 1.0 / 64) < 1e-18
