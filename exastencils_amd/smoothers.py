@@ -3,22 +3,21 @@
 Reference idea: `repeat n times with contraction` / IR_ContractingLoop (Compiler/src/exastencils/baseExt/ir/
 IR_ContractingLoop.scala; Testing/PolyExpl/Jac3Dcc.exa4:27) and the `Comm*TempBlockable` layouts of the
 generated-from-L3 programs.  The reference widens the ghost layers to block in time; here the ghost layers stay
-one deep (the drop-in layout) and the second step of the duplicate planes at interior faces is finished separately:
+one deep (the drop-in layout) and the block is split into a deep interior, which needs no halo at all for two steps,
+and a two-point shell along the interior faces:
 
-  1. communicate ghost of u                                   (as every Smoother call does)
-  2. u_out = J(J(u)) on the loop's box minus the duplicate planes at interior faces   (examg_jacobi2_boxes;
-     the first step is evaluated on the whole box, so everything the second step needs there is local)
-  3. tmp = J(u) on the two planes next to every interior face   (thin launches)
-  4. communicate ghost of tmp                                  (the neighbours' first-step values)
-  5. u_out = J(tmp) on the duplicate planes at interior faces   (thin launches)
+  main stream   u_out = J(J(u)) on the loop's box shrunk by 2 at interior faces; the first step is evaluated on the box
+                shrunk by 1 (examg_jacobi2_boxes) -- reads no ghost value, starts immediately
+  side stream   1. communicate ghost of u                      (as every Smoother call does)
+                2. tmp = J(u) on the three planes next to every interior face       (thin launches)
+                3. communicate ghost of tmp                    (the neighbours' first-step values)
+                4. u_out = J(tmp) on the two planes next to every interior face     (thin launches)
+  join          (events)
 
-Two exchanges per two steps -- as many as two plain Smoother calls -- and bit-identical results.  On a single block
-steps 3-5 vanish and 1 is empty.
-
-Overlap: steps 3 and 4 (thin launches, pack, RCCL send/recv over xGMI, unpack) run on a side stream while the main
-stream executes step 2, the only large kernel; step 5 waits for both (events).  This is the reference's core/boundary
+Two exchanges per two steps -- as many as two plain Smoother calls -- all of it (pack, RCCL send/recv over xGMI, unpack,
+thin kernels) overlapped with the one large kernel, and bit-identical results.  This is the reference's core/boundary
 split (Compiler/src/exastencils/baseExt/ir/IR_LoopOverPointsInOneFragment.scala:143-222,
-experimental_splitLoopsForAsyncComm) with the roles swapped: the interior needs no halo at all here.
+experimental_splitLoopsForAsyncComm) applied to a pair of steps.  On a single block only the main-stream launch remains.
 """
 from __future__ import annotations
 
@@ -35,47 +34,62 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool =
     src, dst = S.active, S.next
     faces = [(d, side) for d in range(nd) for side in (-1, 1) if domain.neighbor(d, side) is not None]
     axis_only = all(sum(1 for c in o if c != 0) <= 1 for o in A.offsets)   # 5/7-point: face ghosts suffice
-    comm.exchange(S, src, "ghost", axis_only)
-    b2, e2 = list(b), list(e)
-    for d, side in faces:
-        if side < 0:
-            b2[d] = b[d] + 1
-        else:
-            e2[d] = e[d] - 1
-    def first_step_on_face_slabs_and_exchange():
+
+    def shrunk(k):
+        bb, ee = list(b), list(e)
         for d, side in faces:
-            sb, se = list(b), list(e)
             if side < 0:
-                se[d] = b[d] + 2
+                bb[d] = b[d] + k
             else:
-                sb[d] = e[d] - 2
+                ee[d] = e[d] - k
+        return bb, ee
+
+    def slab(d, side, k):
+        """The k planes of the loop's box next to face (d, side), tangentially the whole box."""
+        sb, se = list(b), list(e)
+        if side < 0:
+            se[d] = min(b[d] + k, e[d])
+        else:
+            sb[d] = max(e[d] - k, b[d])
+        return sb, se
+
+    def interior():
+        b1, e1 = shrunk(1)
+        b2, e2 = shrunk(2)
+        if all(e2[d] > b2[d] for d in range(nd)):
+            ops.jacobi2_boxes(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, b1, e1, b2, e2)
+
+    def shell():
+        comm.exchange(S, src, "ghost", axis_only)
+        for d, side in faces:
+            sb, se = slab(d, side, 3)
             ops.stencil_op(SMOOTH, S.lc, S.data(src), F.lc, F.data(), tmp_field.lc, tmp_field.data(), A, w, -1, sb, se)
         comm.exchange(tmp_field, None, "ghost", axis_only)
+        for d, side in faces:
+            sb, se = slab(d, side, 2)
+            ops.stencil_op(SMOOTH, tmp_field.lc, tmp_field.data(), F.lc, F.data(), S.lc, S.data(dst), A, w, -1, sb, se)
 
-    side_stream = ops.side_stream() if (faces and overlap and hasattr(ops, "side_stream")) else None
-    # The fallback of examg_jacobi2_boxes (short rows on coarse levels) uses tmp as scratch for the whole first step:
-    # it must then run BEFORE the face slabs and the exchange write tmp, hence no overlap for those boxes.
+    if not faces:
+        comm.exchange(S, src, "ghost", axis_only)      # empty on a single block
+        ops.jacobi2_boxes(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, b, e, b, e)
+        S.advance()
+        return
+
+    # The fallback of examg_jacobi2_boxes (short rows on coarse levels, other stencils) uses tmp as scratch for its whole
+    # first step: it must then finish before the shell work writes tmp -- sequential order, no overlap.
+    b2, e2 = shrunk(2)
     canonical7 = nd == 3 and A.cfield is None and len(A.offsets) == 7 and axis_only
-    if side_stream is not None and ((e2[0] - b2[0]) < 64 or not canonical7):
-        side_stream = None
+    fused = canonical7 and (e2[0] - b2[0]) >= 64
+    side_stream = ops.side_stream() if (overlap and fused and hasattr(ops, "side_stream")) else None
     if side_stream is not None:
         torch = ops.torch
         main = torch.cuda.current_stream(ops.device)
-        side_stream.wait_stream(main)                # ghosts of u are in place
+        side_stream.wait_stream(main)                # everything issued so far (u, rhs) is visible to the side stream
         with torch.cuda.stream(side_stream):
-            first_step_on_face_slabs_and_exchange()
-        ops.jacobi2_boxes(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, b, e, b2, e2)
+            shell()
+        interior()
         main.wait_stream(side_stream)
     else:
-        ops.jacobi2_boxes(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, b, e, b2, e2)
-        if faces:
-            first_step_on_face_slabs_and_exchange()
-    if faces:
-        for d, side in faces:
-            sb, se = list(b), list(e)
-            if side < 0:
-                se[d] = b[d] + 1
-            else:
-                sb[d] = e[d] - 1
-            ops.stencil_op(SMOOTH, tmp_field.lc, tmp_field.data(), F.lc, F.data(), S.lc, S.data(dst), A, w, -1, sb, se)
+        interior()
+        shell()
     S.advance()
