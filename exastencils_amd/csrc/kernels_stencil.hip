@@ -248,16 +248,18 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
       const d2 mp_ = REV ? um[r] : st.up[r];
       d2 o;
       if (COL) {
-        // the point of this lane's pair that carries the colour: a if (x + row + m) is of that parity, else b
-        const bool sel_a = ((x + rw + r + m) & 1) == g.colour;
-        const double c_ = sel_a ? uc[r].x : uc[r].y;
-        const double xm_ = sel_a ? xl : uc[r].x, xp_ = sel_a ? uc[r].y : xr;
-        const double t0 = sel_a ? tm_.x : tm_.y, t1 = sel_a ? tp_.x : tp_.y;
-        const double q0 = sel_a ? mm_.x : mm_.y, q1 = sel_a ? mp_.x : mp_.y;
-        const double acc = MY ? conv7<ORDER>(k, c_, xm_, xp_, q0, q1, t0, t1) : conv7<ORDER>(k, c_, xm_, xp_, t0, t1, q0, q1);
-        const double nv = finish<MODE>(c_, acc, sel_a ? st.f[r].x : st.f[r].y, w);
-        o.x = sel_a ? nv : uc[r].x;
-        o.y = sel_a ? uc[r].y : nv;
+        // the point of this lane's pair that carries the colour: a if (x + row + m) has that parity, else b; x = b0 +
+        // 128*tx + 2*lane, so the parity is the same in every lane: scalar branch, one convolution, one lane exchange
+        o = uc[r];
+        if (((box.b0 + rw + r + m) & 1) == g.colour) {
+          const double acc = MY ? conv7<ORDER>(k, uc[r].x, xl, uc[r].y, mm_.x, mp_.x, tm_.x, tp_.x)
+                                : conv7<ORDER>(k, uc[r].x, xl, uc[r].y, tm_.x, tp_.x, mm_.x, mp_.x);
+          o.x = finish<MODE>(uc[r].x, acc, st.f[r].x, w);
+        } else {
+          const double acc = MY ? conv7<ORDER>(k, uc[r].y, uc[r].x, xr, mm_.y, mp_.y, tm_.y, tp_.y)
+                                : conv7<ORDER>(k, uc[r].y, uc[r].x, xr, tm_.y, tp_.y, mm_.y, mp_.y);
+          o.y = finish<MODE>(uc[r].y, acc, st.f[r].y, w);
+        }
       } else {
         double acc_a, acc_b;
         if (MY) {

@@ -90,6 +90,7 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
   const int tz = t / g.nty;
 
   const int xa = box.b0 - 2 + TS_OUT * tx + 2 * lane;  // this lane's points: xa, xa + 1
+  const int xpar = (box.b0 + TS_OUT * tx) & 1;         // parity of xa, the same in every lane
   const int rw = box.b1 + (ty * WY + wv) * RY;           // first own row
   const int mb = box.b2 + tz * g.zc;
   const int me = min(mb + g.zc, box.e2);
@@ -144,19 +145,23 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
       if (rin) {
         const bool da = in1_a, db = in1_b;
         const d2 f = FP[i];
-        const double xl = lane_below(c.y), xr = lane_above(c.x);
-        const int par = (xa + row + p) & 1;  // parity of point a; b has the other one
+        // parity of point a (b has the other one); 2*lane does not change it, so it is wave-uniform: scalar branches
+        const int par = (xpar + row + p) & 1;
         if (COL) {
-          // exactly one point of the pair carries the stage-1 colour: one convolution per pair
-          const bool sa = par == g.first;
-          const double cc = sa ? c.x : c.y;
-          const double acc = conv7<ORDER>(k, cc, sa ? xl : c.x, sa ? c.y : xr, sa ? Uc[i].x : Uc[i].y,
-                                          sa ? Uc[i + 2].x : Uc[i + 2].y, sa ? Um[i + 1].x : Um[i + 1].y,
-                                          sa ? Up[i + 1].x : Up[i + 1].y);
-          const double nv = cc + w * ((sa ? f.x : f.y) - acc);
-          v.x = (sa && da) ? nv : c.x;
-          v.y = (!sa && db) ? nv : c.y;
+          // exactly one point of the pair carries the stage-1 colour: one convolution and one lane exchange per pair
+          if (par == g.first) {
+            const double xl = lane_below(c.y);
+            const double acc = conv7<ORDER>(k, c.x, xl, c.y, Uc[i].x, Uc[i + 2].x, Um[i + 1].x, Up[i + 1].x);
+            const double nv = c.x + w * (f.x - acc);
+            v.x = da ? nv : c.x;
+          } else {
+            const double xr = lane_above(c.x);
+            const double acc = conv7<ORDER>(k, c.y, c.x, xr, Uc[i].y, Uc[i + 2].y, Um[i + 1].y, Up[i + 1].y);
+            const double nv = c.y + w * (f.y - acc);
+            v.y = db ? nv : c.y;
+          }
         } else {
+          const double xl = lane_below(c.y), xr = lane_above(c.x);
           const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Uc[i].x, Uc[i + 2].x, Um[i + 1].x, Up[i + 1].x);
           const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Uc[i].y, Uc[i + 2].y, Um[i + 1].y, Up[i + 1].y);
           const double na = c.x + w * (f.x - acc_a);
@@ -176,19 +181,22 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
       const int row = rw + r;
       if (row >= box.e1) continue;  // wave-uniform
       const d2 c = Vc[r + 1];
-      const double xl = lane_below(c.y), xr = lane_above(c.x);
-      const int par = (xa + row + m) & 1;
-      d2 o;
+      const int par = (xpar + row + m) & 1;   // wave-uniform
+      d2 o = c;
       if (COL) {
-        const bool sa = par != g.first;   // the point of the pair with the stage-2 colour
-        const double cc = sa ? c.x : c.y;
-        const double acc = conv7<ORDER>(k, cc, sa ? xl : c.x, sa ? c.y : xr, sa ? Vc[r].x : Vc[r].y,
-                                        sa ? Vc[r + 2].x : Vc[r + 2].y, sa ? Vm[r + 1].x : Vm[r + 1].y,
-                                        sa ? Vp[r + 1].x : Vp[r + 1].y);
-        const double nv = cc + w * ((sa ? F[r].x : F[r].y) - acc);
-        o.x = (sa && inx_a) ? nv : c.x;
-        o.y = (!sa && inx_b) ? nv : c.y;
+        if (par != g.first) {   // point a carries the stage-2 colour
+          const double xl = lane_below(c.y);
+          const double acc = conv7<ORDER>(k, c.x, xl, c.y, Vc[r].x, Vc[r + 2].x, Vm[r + 1].x, Vp[r + 1].x);
+          const double nv = c.x + w * (F[r].x - acc);
+          o.x = inx_a ? nv : c.x;
+        } else {
+          const double xr = lane_above(c.x);
+          const double acc = conv7<ORDER>(k, c.y, c.x, xr, Vc[r].y, Vc[r + 2].y, Vm[r + 1].y, Vp[r + 1].y);
+          const double nv = c.y + w * (F[r].y - acc);
+          o.y = inx_b ? nv : c.y;
+        }
       } else {
+        const double xl = lane_below(c.y), xr = lane_above(c.x);
         const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Vc[r].x, Vc[r + 2].x, Vm[r + 1].x, Vp[r + 1].x);
         const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Vc[r].y, Vc[r + 2].y, Vm[r + 1].y, Vp[r + 1].y);
         const double na = c.x + w * (F[r].x - acc_a);
