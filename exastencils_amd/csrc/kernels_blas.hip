@@ -480,3 +480,66 @@ extern "C" int examg_copy_from_external(const examg_layout_t *l_ext, const doubl
   if (external_box(l_int, l_ext, b, e)) return 1;
   return examg_axpby(l_ext, src, l_int, x_int, 1.0, 0.0, b, e, stream);
 }
+
+// ---- config 4: 27-entry stencil field of -div(a grad u) - k^2 u (trilinear elements, lumped mass); same expression
+// order as oracle/examg_oracle.c:orc_init_helmholtz27 ----------------------------------------------------------
+namespace examg {
+__global__ void __launch_bounds__(256) k_init_helmholtz27(LayoutDev lc, double *cf, Geom g, int fn, Params4 p, Box box) {
+  const long long total = box.count();
+  const long long plane = lc.size;
+  const double ksq = p.v[1];
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i0, i1, i2;
+    unflatten(box, t, i0, i1, i2);
+    const double h = g.h0;
+    const double x = i0 * g.h0 + g.pb0, y = i1 * g.h1 + g.pb1, z = i2 * g.h2 + g.pb2;
+    double ae[2][2][2];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+        for (int sz = 0; sz < 2; ++sz)
+          ae[sx][sy][sz] = eval_fn(fn, p.v, x + (sx ? 0.5 : -0.5) * h, y + (sy ? 0.5 : -0.5) * h, z + (sz ? 0.5 : -0.5) * h);
+    const long long k = lidx(lc, i0, i1, i2);
+    int ent = 1;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz) {
+          const int nnz = (dx != 0) + (dy != 0) + (dz != 0);
+          double s = 0.0;
+          bool first = true;
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+              for (int sz = 0; sz < 2; ++sz) {
+                const bool okx = dx == 0 || (dx > 0) == (sx == 1), oky = dy == 0 || (dy > 0) == (sy == 1),
+                           okz = dz == 0 || (dz > 0) == (sz == 1);
+                if (okx && oky && okz) { s = first ? ae[sx][sy][sz] : s + ae[sx][sy][sz]; first = false; }
+              }
+          const double kf = nnz == 0 ? (1.0 / 3.0) : (nnz == 1 ? 0.0 : (-1.0 / 12.0));
+          double c = (s * kf) / (h * h);
+          if (nnz == 0) { c = c - ksq; cf[k] = c; }
+          else { cf[k + (long long)ent * plane] = c; ++ent; }
+        }
+  }
+}
+}  // namespace examg
+
+extern "C" int examg_init_helmholtz27(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,
+                                      const double *params, const int32_t *begin, const int32_t *end,
+                                      examg_stream_t stream) {
+  if (!lc || !cfield || !g || !begin || !end) { set_error("examg_init_helmholtz27: null argument"); return 1; }
+  if (lc->nd != 3) { set_error("examg_init_helmholtz27: 3-D only"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (!box_inside(lc, box, 0)) { set_error("examg_init_helmholtz27: box leaves the allocation"); return 1; }
+  hipLaunchKernelGGL(examg::k_init_helmholtz27, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(lc), cfield, make_geom(g), coef_fn, make_params(params), box);
+  EXAMG_CHECK_LAUNCH("k_init_helmholtz27");
+  return 0;
+}

@@ -118,3 +118,8 @@ def stencil_field_offsets(nd: int) -> List[Tuple[int, int, int]]:
         for s in (1, -1):
             offs.append(_axis(d, s))
     return offs
+
+
+def helmholtz27_offsets() -> List[Tuple[int, int, int]]:
+    """Entry order of the 27-entry stencil field of examg_init_helmholtz27: centre first, then (dx,dy,dz) lexicographic."""
+    return [(0, 0, 0)] + [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if (a, b, c) != (0, 0, 0)]

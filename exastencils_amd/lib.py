@@ -45,7 +45,7 @@ SYMBOLS = [
     "examg_version", "examg_last_error", "examg_device_count", "examg_stencil_op", "examg_jacobi",
     "examg_rbgs_colour", "examg_residual", "examg_rbgs_sweep_fused", "examg_jacobi2", "examg_jacobi2_boxes", "examg_restrict", "examg_prolong_add",
     "examg_set", "examg_axpby", "examg_axpby_dev", "examg_reduce_work_bytes", "examg_dot", "examg_max_err_fn",
-    "examg_fill_fn", "examg_apply_dirichlet", "examg_init_varcoeff7", "examg_pack", "examg_unpack",
+    "examg_fill_fn", "examg_apply_dirichlet", "examg_init_varcoeff7", "examg_init_helmholtz27", "examg_pack", "examg_unpack",
     "examg_cg_coarse", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
 ]
 
@@ -87,6 +87,7 @@ def load():
     L.examg_fill_fn.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp]
     L.examg_apply_dirichlet.argtypes = [lp, vp, gp, C.c_int, dp, C.c_uint32, vp]
     L.examg_init_varcoeff7.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp]
+    L.examg_init_helmholtz27.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp]
     L.examg_pack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_unpack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_cg_coarse.argtypes = [lp, vp, lp, vp, lp, vp, lp, vp, lp, vp, sp, gp, C.c_uint32, C.c_int, C.c_double, ip, ip, vp, vp]

@@ -137,6 +137,10 @@ class HipOps:
         check(self.L.examg_init_varcoeff7(C.byref(lc), self.ptr(cf), C.byref(geom), int(coef_fn), dvec4(params),
                                           ivec(begin), ivec(end), self._stream()), "examg_init_varcoeff7")
 
+    def init_helmholtz27(self, lc, cf, geom, coef_fn: int, params: Sequence[float], begin, end):
+        check(self.L.examg_init_helmholtz27(C.byref(lc), self.ptr(cf), C.byref(geom), int(coef_fn), dvec4(params),
+                                            ivec(begin), ivec(end), self._stream()), "examg_init_helmholtz27")
+
     # -- halo ------------------------------------------------------------------------------------------
     def pack(self, l, x, buf, begin, end):
         check(self.L.examg_pack(C.byref(l), self.ptr(x), self.ptr(buf), ivec(begin), ivec(end), self._stream()), "examg_pack")

@@ -321,7 +321,9 @@ class ConfigL3:
     kappa: float = 10.0
     fmg: bool = False
     align: int = 0
-    temporal_blocking: bool = False   # single block: pairs of Jacobi steps in one pass (examg_jacobi2)
+    temporal_blocking: bool = False   # pairs of Jacobi steps in one pass (exastencils_amd/smoothers.py)
+    ksq: float = 0.0                  # stencil 'helmholtz27': shift k^2 of  -div(a grad u) - k^2 u  (config 4)
+    rhs_from_solution: bool = False   # RHS = A * sol_fn (discrete manufactured solution)
 
 
 class SolverFromL3(_Program):
@@ -347,6 +349,13 @@ class SolverFromL3(_Program):
                 self.Laplace[l] = laplace_unit(nd)
             elif cfg.stencil == "scaled":
                 self.Laplace[l] = laplace_fd(nd, dom.h(l), "pm", "mul")
+            elif cfg.stencil == "helmholtz27":   # config 4: 27-entry stencil field (examg_init_helmholtz27)
+                from .field import helmholtz27_offsets
+
+                cf = ops.new_array(27 * nocomm.size)
+                b, e = dom.loop_bounds(nocomm)
+                ops.init_helmholtz27(nocomm.c_struct(), cf, dom.geom(l), cfg.coef_fn, (cfg.kappa, cfg.ksq), b, e)
+                self.Laplace[l] = Stencil(helmholtz27_offsets(), [], cf, nocomm)
             else:   # InitLaplace@l (Testing/SISC/3D_VarCoeff.exa4:206-217)
                 cf = ops.new_array((2 * nd + 1) * nocomm.size)
                 b, e = dom.loop_bounds(nocomm)
@@ -357,7 +366,7 @@ class SolverFromL3(_Program):
         self.VecGradP = Field("VecGradP", lo, FieldLayout.node(nd, nc, 0, False, False, cfg.align), ops, 1, None)
 
     def _w(self, l: int) -> float:
-        if self.cfg.stencil == "varcoeff":
+        if self.cfg.stencil in ("varcoeff", "helmholtz27"):
             return self.cfg.omega                       # kernel forms (1.0 / diag) * omega per point
         return (1.0 / self.Laplace[l].diag) * self.cfg.omega
 
@@ -519,7 +528,17 @@ class SolverFromL3(_Program):
     # Function Application: init part
     def setup(self):
         cfg, hi = self.cfg, self.cfg.max_level
-        if cfg.rhs_fn is not None:
+        if cfg.rhs_from_solution:
+            # RHS = A * u_exact on the finest level: the discrete solution is then sol_fn itself
+            S, F = self.Solution[hi], self.RHS[hi]
+            lay = S.layout
+            tmp = self.ops.new_array(lay.size)
+            gb = [lay.idx("GLB", d) if d < self.nd else 0 for d in range(3)]
+            ge = [lay.idx("GRE", d) if d < self.nd else 1 for d in range(3)]
+            self.ops.fill_fn(S.lc, tmp, self.domain.geom(hi), cfg.sol_fn, (cfg.kappa,), gb, ge)
+            b, e = self.bounds(F)
+            self.ops.stencil_op(APPLY, S.lc, tmp, None, None, F.lc, F.data(), self.Laplace[hi], 0.0, -1, b, e)
+        elif cfg.rhs_fn is not None:
             self.InitRHS(hi)
         for l in self.levels:
             for s_ in range(self.Solution[l].num_slots):

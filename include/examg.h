@@ -198,6 +198,13 @@ int examg_apply_dirichlet(const examg_layout_t *l, double *x, const examg_geom_t
 int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,
                          const double *params, const int32_t *begin, const int32_t *end, examg_stream_t stream);
 
+/* 27-entry stencil field of -div(a grad u) - k^2 u (BASELINE.json config 4): trilinear elements with element-wise
+ * constant a = coef_fn(element centre), lumped mass, scaled by 1/h^3; params[0] = kappa of the profile, params[1] = k^2.
+ * Entry order: (0,0,0), then (dx,dy,dz) lexicographic with dx slowest.  The stencil-field mechanism is the reference's
+ * (stencil/ir/IR_StencilConvolution.scala:73-95); the reference itself ships 2d+1-entry fields only. */
+int examg_init_helmholtz27(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,
+                           const double *params, const int32_t *begin, const int32_t *end, examg_stream_t stream);
+
 /* ---- K9: halo pack / unpack (communication/ir/IR_NoInterpPacking.scala:53-83): box <-> contiguous
  * buffer, x fastest; ranges from IR_PackInfoDuplicate.scala:15-39 / IR_PackInfoGhost.scala:13-60. */
 int examg_pack(const examg_layout_t *l, const double *x, double *buf, const int32_t *begin, const int32_t *end,

@@ -458,3 +458,53 @@ void orc_set_num_threads(int n) { omp_set_num_threads(n); }
 int orc_num_threads(void) { return 1; }
 void orc_set_num_threads(int n) { (void)n; }
 #endif
+
+/* ------------------------------------------------------------------ */
+/* Config 4 (BASELINE.json): 27-entry stencil field of a variable-coefficient Helmholtz operator
+ *   -div(a grad u) - k^2 u,  a = coefficient profile `coef_fn`,
+ * discretised with trilinear elements (element-wise constant a sampled at the element centre, lumped
+ * mass), scaled by 1/h^3 so that it matches the finite-difference scaling of the other programs.
+ * The reference ships stencil fields with 2d+1 entries only (Testing/SISC/3D_VarCoeff.exa4); this is
+ * the same mechanism (entry index slowest, C/stencil/ir/IR_StencilConvolution.scala:73-95) with 27
+ * entries -- no golden exists for it in the reference ("parity unpinned").
+ * Entry order: (0,0,0) first, then offsets (dx,dy,dz) in lexicographic order, dx slowest.
+ * Element matrix of the unit cube (Q1): 1/3 on the diagonal, 0 across an edge, -1/12 across a face
+ * diagonal and across the body diagonal; entry(o) = sum over the elements containing both nodes.   */
+void orc_init_helmholtz27(const orc_layout_t *lc, double *cf, const orc_geom_t *g, int coef_fn, const double *p,
+                          const int *begin, const int *end) {
+  const ptrdiff_t plane = lay_size(lc);
+  const double ksq = p[1];
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int i2 = begin[2]; i2 < end[2]; ++i2)
+    for (int i1 = begin[1]; i1 < end[1]; ++i1)
+      for (int i0 = begin[0]; i0 < end[0]; ++i0) {
+        const double h = g->h[0];
+        const double x = i0 * g->h[0] + g->pos_begin[0];
+        const double y = i1 * g->h[1] + g->pos_begin[1];
+        const double z = i2 * g->h[2] + g->pos_begin[2];
+        double ae[2][2][2];
+        for (int sx = 0; sx < 2; ++sx)
+          for (int sy = 0; sy < 2; ++sy)
+            for (int sz = 0; sz < 2; ++sz)
+              ae[sx][sy][sz] = orc_eval_fn(coef_fn, p, x + (sx ? 0.5 : -0.5) * h, y + (sy ? 0.5 : -0.5) * h, z + (sz ? 0.5 : -0.5) * h);
+        const ptrdiff_t k = lay_idx(lc, i0, i1, i2);
+        int ent = 1;
+        for (int dx = -1; dx <= 1; ++dx)
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+              const int nnz = (dx != 0) + (dy != 0) + (dz != 0);
+              double s = 0.0;
+              int first = 1;
+              for (int sx = 0; sx < 2; ++sx)
+                for (int sy = 0; sy < 2; ++sy)
+                  for (int sz = 0; sz < 2; ++sz) {
+                    const int okx = dx == 0 || (dx > 0) == sx, oky = dy == 0 || (dy > 0) == sy, okz = dz == 0 || (dz > 0) == sz;
+                    if (okx && oky && okz) { s = first ? ae[sx][sy][sz] : s + ae[sx][sy][sz]; first = 0; }
+                  }
+              const double kf = nnz == 0 ? (1.0 / 3.0) : (nnz == 1 ? 0.0 : (-1.0 / 12.0));
+              double c = (s * kf) / (h * h);
+              if (nnz == 0) { c = c - ksq; cf[k] = c; }
+              else { cf[k + (ptrdiff_t)ent * plane] = c; ++ent; }
+            }
+      }
+}

@@ -96,6 +96,8 @@ def lib():
         L.orc_max_err_fn.restype = C.c_double
         L.orc_init_varcoeff7.argtypes = [lp, dp, C.POINTER(GeomC), C.c_int, C.POINTER(C.c_double), ip, ip]
         L.orc_init_varcoeff7.restype = None
+        L.orc_init_helmholtz27.argtypes = [lp, dp, C.POINTER(GeomC), C.c_int, C.POINTER(C.c_double), ip, ip]
+        L.orc_init_helmholtz27.restype = None
         L.orc_pack.argtypes = [lp, dp, dp, ip, ip]
         L.orc_pack.restype = None
         L.orc_unpack.argtypes = [lp, dp, dp, ip, ip]
@@ -711,6 +713,8 @@ class ConfigB:
     kappa: float = 10.0
     fmg: bool = False
     align: int = 0
+    ksq: float = 0.0
+    rhs_from_solution: bool = False
 
 
 class ProgramB:
@@ -740,6 +744,8 @@ class ProgramB:
                     st = laplace_tests_unit(nd)
                 elif cfg.stencil == "scaled":
                     st = laplace_tests_scaled(nd, self.dom.h(l))
+                elif cfg.stencil == "helmholtz27":
+                    st = self._init_helmholtz27(l, p, nocomm)
                 else:
                     st = self._init_laplace(l, p, nocomm)
                 self.Laplace[l][p] = st
@@ -764,6 +770,16 @@ class ProgramB:
         st = laplace_tests_scaled(nd, self.dom.h(l))
         return Stencil(st.offsets, [], cf, lay)
 
+    def _init_helmholtz27(self, l: int, p, lay: Layout) -> Stencil:
+        cf = np.zeros(27 * lay.size)
+        b, e = loop_bounds(self.dom, lay, p)
+        g = self.dom.geom(l, p)
+        pp = (C.c_double * 4)(self.cfg.kappa, self.cfg.ksq, 0, 0)
+        lc = lay.c()
+        lib().orc_init_helmholtz27(C.byref(lc), _ptr(cf), C.byref(g), self.cfg.coef_fn, pp, _ivec(b), _ivec(e))
+        offs = [(0, 0, 0)] + [(a, b_, c) for a in (-1, 0, 1) for b_ in (-1, 0, 1) for c in (-1, 0, 1) if (a, b_, c) != (0, 0, 0)]
+        return Stencil(offs, [], cf, lay)
+
     # -- leveled functions ------------------------------------------------
     def UpResidual(self, l: int):
         S = self.Solution[l]
@@ -780,7 +796,7 @@ class ProgramB:
         S, cfg = self.Solution[l], self.cfg
         if cfg.smoother == "jacobi":
             communicate(S, S.active, "ghost")
-            if cfg.stencil == "varcoeff":
+            if cfg.stencil in ("varcoeff", "helmholtz27"):
                 w = cfg.omega
             else:
                 st = next(iter(self.Laplace[l].values()))
@@ -790,7 +806,7 @@ class ProgramB:
         else:   # Testing/Smoothers/RBGS.exa4:125-133, colour 0 first
             for colour in (0, 1):
                 communicate(S, S.active)
-                if cfg.stencil == "varcoeff":
+                if cfg.stencil in ("varcoeff", "helmholtz27"):
                     w = cfg.omega
                 else:
                     st = next(iter(self.Laplace[l].values()))
@@ -853,7 +869,21 @@ class ProgramB:
     # Function Application
     def setup(self):
         cfg, hi = self.cfg, self.cfg.max_level
-        if cfg.rhs_fn is not None:
+        if cfg.rhs_from_solution:
+            S, F = self.Solution[hi], self.RHS[hi]
+            lay = S.layout
+            pp = (C.c_double * 4)(cfg.kappa, 0, 0, 0)
+            for p in self.dom.frags:
+                tmp = lay.alloc()
+                gb = [lay.it("GLB", d) if d < cfg.nd else 0 for d in range(3)]
+                ge = [lay.it("GRE", d) if d < cfg.nd else 1 for d in range(3)]
+                g = self.dom.geom(hi, p)
+                lib().orc_fill_fn(C.byref(S.lc), _ptr(tmp), C.byref(g), cfg.sol_fn, pp, _ivec(gb), _ivec(ge))
+                b, e = loop_bounds(self.dom, F.layout, p)
+                sc = self.Laplace[hi][p].c()
+                lib().orc_stencil_op(APPLY, C.byref(S.lc), _ptr(tmp), None, None, C.byref(F.lc), _ptr(F.arr(p)), C.byref(sc), 0.0,
+                                     -1, _ivec(b), _ivec(e))
+        elif cfg.rhs_fn is not None:
             fill_fn(self.dom, self.RHS[hi], cfg.rhs_fn, (cfg.kappa,))
         for l in self.levels:
             for s in range(self.Solution[l].nslots):

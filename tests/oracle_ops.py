@@ -142,6 +142,9 @@ class OracleOps:
     def init_varcoeff7(self, lc, cf, geom, coef_fn, params, begin, end):
         self.L.orc_init_varcoeff7(_lp(lc), self.ptr(cf), _gp(geom), int(coef_fn), _p4(params), _iv(begin), _iv(end))
 
+    def init_helmholtz27(self, lc, cf, geom, coef_fn, params, begin, end):
+        self.L.orc_init_helmholtz27(_lp(lc), self.ptr(cf), _gp(geom), int(coef_fn), _p4(params), _iv(begin), _iv(end))
+
     def pack(self, l, x, buf, begin, end):
         self.L.orc_pack(_lp(l), self.ptr(x), self.ptr(buf), _iv(begin), _iv(end))
 

@@ -23,6 +23,11 @@ for p in (ROOT, HERE):
         sys.path.insert(0, p)
 
 
+# Testing/FMG/3D_VarCoeff.exa4 at a reduced size: stencil field, FMG start, error print
+_FMG_VAR = dict(nd=3, min_level=1, max_level=4, smoother="jacobi", omega=0.85, stencil="varcoeff", restrict_scale=1.0, tol=1e-5,
+                cg_max=1024, bc_fn=6, rhs_fn=5, sol_fn=6, coef_fn=7, kappa=10.0, fmg=True)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -75,6 +80,12 @@ def _worker_solver(rank, world, port, blocks, case, out_dir):
     elif case == "rbgs_l3":
         P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="rbgs", omega=1.0, stencil="unit",
                                   restrict_scale=4.0, tol=1e-5, cg_max=512), ops, dom, comm)
+    elif case == "fmg_varcoeff":
+        P = SolverFromL3(ConfigL3(**_FMG_VAR, frag_len=flen), ops, dom, comm)
+    elif case == "helmholtz27":
+        from test_host_logic import HELMHOLTZ27
+
+        P = SolverFromL3(ConfigL3(**HELMHOLTZ27, frag_len=flen), ops, dom, comm)
     else:
         P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, frag_len=flen, tol=1e-6, fused_coarse=False), ops, dom, comm)
     P.setup()
@@ -102,6 +113,12 @@ def _reference_single(case):
     elif case == "rbgs_l3":
         P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="rbgs", omega=1.0, stencil="unit",
                                   restrict_scale=4.0, tol=1e-5, cg_max=512), ops)
+    elif case == "fmg_varcoeff":
+        P = SolverFromL3(ConfigL3(**_FMG_VAR, frag_len=flen), ops)
+    elif case == "helmholtz27":
+        from test_host_logic import HELMHOLTZ27
+
+        P = SolverFromL3(ConfigL3(**HELMHOLTZ27, frag_len=flen), ops)
     else:
         P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, frag_len=flen, tol=1e-6, fused_coarse=False), ops)
     P.setup()
@@ -115,7 +132,7 @@ def _reference_single(case):
 
 @pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"),
                                          ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
-                                         ((2, 2, 1), "jacobi_l3_tb_cg")])
+                                         ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 1, 1), "fmg_varcoeff"), ((2, 2, 1), "helmholtz27")])
 def test_decomposed_solve_matches_single_block(tmp_path, blocks, case):
     world = blocks[0] * blocks[1] * blocks[2]
     port = _free_port()

@@ -508,3 +508,17 @@ def test_external_field_copy(hip):
         hip.synchronize()
         full2 = hip.to_host(F.data()).reshape(internal.shape_zyx)
         assert np.array_equal(full2[iz, iy, ix], new[ez, ey, ex])
+
+
+def test_init_helmholtz27(hip, orc):
+    n = 24
+
+    def f(ops):
+        l = FieldLayout.node(3, (n, n, n), 0)
+        cf = ops.new_array(27 * l.size)
+        b, e = box(3, n)
+        ops.init_helmholtz27(l.c_struct(), cf, geom(3, n), FN_KAPPA_COEF, (10.0, 2.0), b, e)
+        return [cf]
+
+    g, c = both(hip, orc, f)
+    assert np.allclose(g[0], c[0], rtol=1e-13, atol=0.0)      # exp() through device libm
