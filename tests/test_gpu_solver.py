@@ -217,6 +217,26 @@ def test_config4_helmholtz27_on_gpu(hip):
     assert P.err_history[-1] < 1e-8
 
 
+def test_cpp_host_program_matches_oracle():
+    """examples/poisson3d_host.cpp: a C++ host in the shape of the generated program, linked against libexamg only
+    (no Python, no PyTorch in that process), prints the oracle's residual history."""
+    import os
+    import subprocess
+
+    import __graft_entry__ as ge
+
+    exe = ge.build_example()
+    out = subprocess.run([exe, "6", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    hist = [float(l[2:]) for l in out.stdout.splitlines() if l.startswith("# ")]
+    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=2, max_level=6, tol=1e-6))
+    O.setup()
+    O.Solve()
+    _close(hist, O.res_history)
+    printed = [l for l in out.stdout.splitlines() if l and not l.startswith("#") and not l.startswith("iterations")]
+    assert mg.compare_with_golden(printed, "\n".join(O.log)) == []
+
+
 def test_config3_512_properties(hip):
     """Config 3 (512^3, levels 4..9) at full size, through size-independent properties: the V-cycle contracts
     the residual by the factor the oracle shows at 128^3 (multigrid convergence is h-independent), the history
