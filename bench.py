@@ -292,6 +292,15 @@ def vcycle(ops, dom, comm, L, world):
     ms = (time.perf_counter() - t0) / n * 1e3
     P._update_residual(L)
     r1 = P.ResNorm(L)
+    # the reference benchmark's own reported quantity: `totalTimeSolve` (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:263-276):
+    # Solve@finest from the zero state to 1e-6 reduction, residual norm on the host after every cycle
+    Q = P
+    Q.reset()          # zero fields, boundary values: the benchmark's initial state (the captured graph stays valid)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    its = Q.Solve(use_graph=use_graph)
+    torch.cuda.synchronize()
+    solve_s = time.perf_counter() - t0
     npts = 1
     b, e = dom.loop_bounds(P.Solution[L].layout)
     for d in range(3):
@@ -302,6 +311,9 @@ def vcycle(ops, dom, comm, L, world):
         "vcycle_levels": 6,
         "vcycle_residual_reduction": r1 / r0 if r0 else None,
         "vcycle_gbs_algorithmic": 223.0 * npts / (ms * 1e-3) / 1e9,
+        "totalTimeSolve": solve_s,
+        "solve_iterations": its,
+        "solve_residual_reduction": (Q.res_history[-1] / Q.res_history[0]) if Q.res_history and Q.res_history[0] else None,
         "vcycle_graph": use_graph,
         "vcycle_fused_rbgs": world == 1,
     }

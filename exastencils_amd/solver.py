@@ -159,6 +159,19 @@ class SolverFromL4(_Program):
             self.ops.fill_fn(f.lc, f.data(), self.domain.geom(hi), cfg.rhs_fn, (), b, e)
         self.apply_bc(self.Solution[hi])
 
+    def reset(self):
+        """Back to the state after initFieldsWithZero + setup(): arrays are zeroed in place (device pointers, and with
+        them a captured graph, stay valid)."""
+        for l in self.levels:
+            for t in self.Solution[l].slots + self.RHS[l].slots + self.Residual[l].slots:
+                t.zero_()
+            if l in self._sol_alt:
+                self._sol_alt[l].zero_()
+        for t in self.cgTmp0.slots + self.cgTmp1.slots:
+            t.zero_()
+        self.log, self.res_history, self.err_history, self.cg_iters = [], [], [], []
+        self.setup()
+
     # Function Solve@finest (...exa4:121-150)
     def Solve(self, use_graph: bool = False) -> int:
         cfg, hi = self.cfg, self.cfg.max_level
