@@ -326,6 +326,11 @@ static int order7(const examg_stencil_t *st) {
 
 static int g_force_generic = 0;  // test hook: examg_debug_force_generic
 
+// kernels_stencilfield.hip
+bool stencilfield7_ok(const examg_layout_t *lu, const examg_stencil_t *st, const Box &box, int colour);
+int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
+                         double *dst, const LayoutDev &lc, const double *cf, double w, const Box &box, hipStream_t s);
+
 // Tuning knobs (examg_debug_tune); the defaults are the measured best on MI355X at 512^3.
 struct Tune {
   int ry = 2, wy = 4, nt = 1, my = 0, pf = 1, remap = 0, blocks = 1024, minchunk = 16, dir = 0;
@@ -484,6 +489,11 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
 #undef EXAMG_ZM
     EXAMG_CHECK_LAUNCH("k_stencil7_zmarch");
     return 0;
+  }
+
+  if (!g_force_generic && stencilfield7_ok(lu_, st, box, colour)) {
+    const LayoutDev lcf = make_layout(&st->clayout);
+    return launch_stencilfield7(mode, lu, u, lf, rhs, ld, dst, lcf, st->cfield, w, box, s);
   }
 
   StencilDev sd;

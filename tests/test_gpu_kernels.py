@@ -268,6 +268,19 @@ def test_stencil_2d_5point(hip, orc, mode, colour):
 
 
 @pytest.mark.parametrize("mode", [APPLY, RESIDUAL, SMOOTH])
+@pytest.mark.parametrize("n", [65, 130])
+def test_stencil_field_7_entries_fast_path(hip, orc, mode, n):
+    """Rows >= 64 points take the z-march stencil-field kernel; ragged tiles; and a block with interior faces."""
+    st = Stencil(stencil_field_offsets(3), [])
+    b, e = box(3, n)
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, mode, -1, b, e, cfn=True))
+    assert_same(g, c, "stencil field fast path")
+    b, e = [0, 1, 0], [n + 1, n, n + 1]
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, mode, -1, b, e, cfn=True))
+    assert_same(g, c, "stencil field fast path, interior faces")
+
+
+@pytest.mark.parametrize("mode", [APPLY, RESIDUAL, SMOOTH])
 def test_stencil_field_7_entries(hip, orc, mode):
     n = 48
     st = Stencil(stencil_field_offsets(3), [])
