@@ -331,6 +331,7 @@ bool stencilfield7_ok(const examg_layout_t *lu, const examg_stencil_t *st, const
 int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
                          double *dst, const LayoutDev &lc, const double *cf, double w, const Box &box, hipStream_t s);
 
+
 // Tuning knobs (examg_debug_tune); the defaults are the measured best on MI355X at 512^3.
 struct Tune {
   int ry = 2, wy = 4, nt = 1, my = 0, pf = 1, remap = 0, blocks = 1024, minchunk = 16, dir = 0;

@@ -301,6 +301,22 @@ def test_stencil_27_entries_const_and_field(hip, orc):
     assert_same(g, c, "27-entry stencil field")
 
 
+@pytest.mark.parametrize("mode", [APPLY, RESIDUAL, SMOOTH])
+@pytest.mark.parametrize("n", [66, 130])
+def test_stencil_field_27_entries_long_rows(hip, orc, mode, n):
+    """27-entry stencil field in the entry order of examg_init_helmholtz27 on long rows; also a block with interior
+    faces (loop starts on the duplicate plane, edge and corner ghosts are read)."""
+    from exastencils_amd.field import helmholtz27_offsets
+
+    st = Stencil(helmholtz27_offsets(), [])
+    b, e = box(3, n)
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, mode, -1, b, e, cfn=True))
+    assert_same(g, c, "27-entry stencil field fast path")
+    b, e = [0, 1, 0], [n + 1, n, n + 1]
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, mode, -1, b, e, cfn=True))
+    assert_same(g, c, "27-entry stencil field fast path, interior faces")
+
+
 def test_empty_iteration_space_is_a_noop(hip, orc):
     """minLevel 0 on one fragment: `loop over` has no inner points (Examples/Poisson/2D_FD_Poisson_fromL4.knowledge:3)."""
     st = laplace_fd(2, (1.0, 1.0, 0.0))
