@@ -251,6 +251,229 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS variant: the NW waves of a workgroup share one 128-point x window and a stack of 2*NW stage-1 rows.  Every wave
+// owns two consecutive rows: it keeps their z pipeline (input planes q-1, q, q+1 and stage-1 planes m-1, m, m+1) in
+// registers and publishes plane q+1 of the input and plane q of the stage-1 field in LDS, from where the waves above
+// and below read their y-neighbour rows.  Each input row is loaded from memory once per workgroup (2*NW + 2 rows for
+// 2*NW - 2 output rows) instead of three times, the first stage is evaluated on 2*NW rows instead of 4*NW - 4, and a
+// wave needs ~100 instead of 250 registers, so two workgroups share a CU.  One barrier per plane (double-buffered LDS).
+// ---------------------------------------------------------------------------------------------------------------
+template <int ORDER, bool COL, int NW, bool NT>
+__global__ void __launch_bounds__(64 * NW)
+k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs,
+                 double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g) {
+  constexpr int NS = 2 * NW;        // stage-1 rows of the workgroup: s = 0 .. NS-1, global row rw0 - 1 + s
+  constexpr int NI = NS + 2;        // input rows: i = 0 .. NI-1, global row rw0 - 2 + i (centre of stage-1 row s is i = s+1)
+  constexpr int NO = NS - 2;        // output rows: stage-1 rows 1 .. NS-2
+  __shared__ d2 UB[2][NI][64];      // input plane p in UB[p & 1]
+  __shared__ d2 VB[2][NS][64];      // stage-1 plane p in VB[p & 1]
+  const int lane = threadIdx.x, wv = threadIdx.y;
+  int t = blockIdx.x;
+  const int tx = t % g.ntx;
+  t /= g.ntx;
+  const int ty = t % g.nty;
+  const int tz = t / g.nty;
+  const int xa = box.b0 - 2 + TS_OUT * tx + 2 * lane;
+  const int xpar = (box.b0 + TS_OUT * tx) & 1;
+  const int rw0 = box.b1 + ty * NO;             // first output row of the workgroup
+  const int mb = box.b2 + tz * g.zc;
+  const int me = min(mb + g.zc, box.e2);
+  const Box &box1 = g.box1;
+  const bool alloc_a = xa >= g.ax0 && xa < g.ax1, alloc_b = xa + 1 >= g.ax0 && xa + 1 < g.ax1;
+  const bool inx_a = xa >= box.b0 && xa < box.e0, inx_b = xa + 1 >= box.b0 && xa + 1 < box.e0;
+  const bool in1_a = xa >= box1.b0 && xa < box1.e0, in1_b = xa + 1 >= box1.b0 && xa + 1 < box1.e0;
+  const bool out_lane = lane >= 1 && lane <= 62;
+
+  // this wave: stage-1 rows s0 = 2*wv, s0 + 1; their centre input rows i = s + 1; global rows
+  const int s0 = 2 * wv;
+  const int grow[2] = {rw0 - 1 + s0, rw0 + s0};
+  const bool row_alloc[2] = {grow[0] >= g.ay0 && grow[0] < g.ay1, grow[1] >= g.ay0 && grow[1] < g.ay1};
+  const bool row_in1[2] = {grow[0] >= box1.b1 && grow[0] < box1.e1, grow[1] >= box1.b1 && grow[1] < box1.e1};
+  // output rows: stage-1 rows 1 .. NS-2 inside the box
+  const bool row_out[2] = {s0 >= 1 && grow[0] >= box.b1 && grow[0] < box.e1, s0 + 1 <= NS - 2 && grow[1] >= box.b1 && grow[1] < box.e1};
+  // the two outermost input rows (i = 0 and i = NI-1) are nobody's centre row: wave 0 / wave NW-1 carry them along
+  const bool has_outer = wv == 0 || wv == NW - 1;
+  const int outer_i = wv == 0 ? 0 : NI - 1;
+  const int outer_row = rw0 - 2 + outer_i;
+  const bool outer_alloc = outer_row >= g.ay0 && outer_row < g.ay1;
+
+  const double *ubase = u + lu.origin + xa;
+  const double *fbase = rhs + lf.origin + xa;
+  double *obase = out + lu.origin + xa;
+
+  auto load_u = [&](int row, bool rok, int p) {
+    const bool ok = rok && p >= g.az0 && p < g.az1;
+    return load2g(ubase + lu.s1 * row + lu.s2 * p, ok && alloc_a, ok && alloc_b);
+  };
+  auto load_f = [&](int r, int p) {
+    const bool ok = row_in1[r] && p >= box1.b2 && p < box1.e2;
+    return load2g(fbase + lf.s1 * grow[r] + lf.s2 * p, ok && in1_a, ok && in1_b);
+  };
+
+  // register pipelines of the two own rows
+  d2 Um[2], Uc[2], Up[2], Upf[2];   // input planes q-1, q, q+1, q+2 (in flight)
+  d2 Vm[2], Vc[2];                  // stage-1 planes m-1, m  (m = q-1); plane q is computed in the step
+  d2 Fq[2], Fqn[2], Fm[2];          // rhs on planes q, q+1 (in flight), m
+  d2 Oc, Opf;                       // outer halo row: planes q+1, q+2
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    Um[r] = load_u(grow[r], row_alloc[r], mb - 2);
+    Uc[r] = load_u(grow[r], row_alloc[r], mb - 1);
+    Up[r] = load_u(grow[r], row_alloc[r], mb);
+    Upf[r] = load_u(grow[r], row_alloc[r], mb + 1);
+    Fq[r] = load_f(r, mb - 1);
+    Fqn[r] = load_f(r, mb);
+    Vm[r] = Um[r];
+    Vc[r] = Um[r];
+    Fm[r] = Fq[r];
+  }
+  d2 Ocur = {0.0, 0.0};
+  if (has_outer) {
+    Ocur = load_u(outer_row, outer_alloc, mb - 1);
+    Oc = load_u(outer_row, outer_alloc, mb);
+    Opf = load_u(outer_row, outer_alloc, mb + 1);
+  }
+  // publish input plane q0 = mb-1
+  {
+    const int pb = (mb - 1) & 1;
+    UB[pb][s0 + 1][lane] = Uc[0];
+    UB[pb][s0 + 2][lane] = Uc[1];
+    if (has_outer) UB[pb][outer_i][lane] = Ocur;
+  }
+  __syncthreads();
+
+  for (int q = mb - 1; q <= me; ++q) {
+    const int m = q - 1;
+    const int ub = q & 1, vb = m & 1;
+    // y-neighbour rows of this step from LDS
+    const d2 ulo = UB[ub][s0][lane];          // input row below the first own row
+    const d2 uhi = UB[ub][s0 + 3][lane];      // input row above the second own row
+    d2 vlo = {0.0, 0.0}, vhi = {0.0, 0.0};
+    if (m >= mb) {
+      if (s0 >= 1) vlo = VB[vb][s0 - 1][lane];
+      if (s0 + 2 <= NS - 1) vhi = VB[vb][s0 + 2][lane];
+    }
+    // prefetch: input plane q+3 of the own rows is not needed yet; plane q+2 is in flight (Upf), rhs q+1 in flight (Fqn)
+    // ---- stage 1 on plane q, own rows ----
+    d2 Vn[2];
+    const bool pin = q >= box1.b2 && q < box1.e2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const d2 c = Uc[r];
+      d2 v = c;
+      if (pin && row_in1[r]) {
+        const d2 ym = r == 0 ? ulo : Uc[0];
+        const d2 yp = r == 0 ? Uc[1] : uhi;
+        const d2 f = Fq[r];
+        const int par = (xpar + grow[r] + q) & 1;
+        if (COL) {
+          if (par == g.first) {
+            const double xl = lane_below(c.y);
+            const double acc = conv7<ORDER>(k, c.x, xl, c.y, ym.x, yp.x, Um[r].x, Up[r].x);
+            const double nv = c.x + w * (f.x - acc);
+            v.x = in1_a ? nv : c.x;
+          } else {
+            const double xr = lane_above(c.x);
+            const double acc = conv7<ORDER>(k, c.y, c.x, xr, ym.y, yp.y, Um[r].y, Up[r].y);
+            const double nv = c.y + w * (f.y - acc);
+            v.y = in1_b ? nv : c.y;
+          }
+        } else {
+          const double xl = lane_below(c.y), xr = lane_above(c.x);
+          const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, ym.x, yp.x, Um[r].x, Up[r].x);
+          const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, ym.y, yp.y, Um[r].y, Up[r].y);
+          const double na = c.x + w * (f.x - acc_a);
+          const double nb = c.y + w * (f.y - acc_b);
+          v.x = in1_a ? na : c.x;
+          v.y = in1_b ? nb : c.y;
+        }
+      }
+      Vn[r] = v;
+    }
+    // ---- stage 2 on plane m = q-1, own rows that are output rows ----
+    if (m >= mb) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if (!row_out[r]) continue;   // wave-uniform
+        const d2 c = Vc[r];
+        const d2 ym = r == 0 ? vlo : Vc[0];
+        const d2 yp = r == 0 ? Vc[1] : vhi;
+        const int par = (xpar + grow[r] + m) & 1;
+        d2 o = c;
+        if (COL) {
+          if (par != g.first) {
+            const double xl = lane_below(c.y);
+            const double acc = conv7<ORDER>(k, c.x, xl, c.y, ym.x, yp.x, Vm[r].x, Vn[r].x);
+            const double nv = c.x + w * (Fm[r].x - acc);
+            o.x = inx_a ? nv : c.x;
+          } else {
+            const double xr = lane_above(c.x);
+            const double acc = conv7<ORDER>(k, c.y, c.x, xr, ym.y, yp.y, Vm[r].y, Vn[r].y);
+            const double nv = c.y + w * (Fm[r].y - acc);
+            o.y = inx_b ? nv : c.y;
+          }
+        } else {
+          const double xl = lane_below(c.y), xr = lane_above(c.x);
+          const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, ym.x, yp.x, Vm[r].x, Vn[r].x);
+          const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, ym.y, yp.y, Vm[r].y, Vn[r].y);
+          const double na = c.x + w * (Fm[r].x - acc_a);
+          const double nb = c.y + w * (Fm[r].y - acc_b);
+          o.x = inx_a ? na : c.x;
+          o.y = inx_b ? nb : c.y;
+        }
+        if (out_lane) {
+          double *qp = obase + lu.s1 * grow[r] + lu.s2 * m;
+          if (inx_a && inx_b) {
+            if (NT) {
+              __builtin_nontemporal_store(o.x, qp);
+              __builtin_nontemporal_store(o.y, qp + 1);
+            } else {
+              d2u_ts sv;
+              sv.a = o.x;
+              sv.b = o.y;
+              *reinterpret_cast<d2u_ts *>(qp) = sv;
+            }
+          } else if (inx_a) {
+            qp[0] = o.x;
+          } else if (inx_b) {
+            qp[1] = o.y;
+          }
+        }
+      }
+    }
+    // ---- publish input plane q+1 and stage-1 plane q; rotate; issue the next loads ----
+    if (q < me) {
+      const int nb = (q + 1) & 1;
+      UB[nb][s0 + 1][lane] = Up[0];
+      UB[nb][s0 + 2][lane] = Up[1];
+      if (has_outer) UB[nb][outer_i][lane] = Oc;
+      VB[q & 1][s0][lane] = Vn[0];
+      VB[q & 1][s0 + 1][lane] = Vn[1];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      Um[r] = Uc[r];
+      Uc[r] = Up[r];
+      Up[r] = Upf[r];
+      Vm[r] = Vc[r];
+      Vc[r] = Vn[r];
+      Fm[r] = Fq[r];
+      Fq[r] = Fqn[r];
+    }
+    if (has_outer) Oc = Opf;
+    if (q < me) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        Upf[r] = load_u(grow[r], row_alloc[r], q + 3);
+        Fqn[r] = load_f(r, q + 2);
+      }
+      if (has_outer) Opf = load_u(outer_row, outer_alloc, q + 3);
+    }
+    __syncthreads();
+  }
+}
+
 static int order7_ts(const examg_stencil_t *st) {
   static const int o0[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
   static const int o1[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
@@ -264,12 +487,16 @@ static int order7_ts(const examg_stencil_t *st) {
   return m0 ? 0 : (m1 ? 1 : -1);
 }
 
-// launch knobs, defaults from tools/tune_two_stage.py on MI355X (512^3: two Jacobi steps 0.89 ms, fused red-black
-// sweep 0.94 ms; 256^3: 0.138 / 0.146 ms): 8 waves per workgroup, ~4096 workgroups, plain tile order
-static int g_ts_blocks = 4096;
+// launch knobs of the register variant (8 waves per workgroup, plain tile order) and the workgroup count target
+static int g_ts_blocks = 2048;
 static int g_ts_disable = 0;
 static int g_ts_remap = 0;
 static int g_ts_wy = 8;
+// Which implementation: 0 = register variant; 5 / 9 = LDS variant with that many waves per workgroup; -2 = by size
+// (tools/tune_two_stage.py on MI355X: 512^3 Jacobi pair 0.87 / 0.88 ms, red-black sweep 0.90 / 0.85 ms for registers /
+// LDS-9; 256^3: 0.150 / 0.140 and 0.145 / 0.133 ms; 128^3: LDS-5 0.036 ms)
+static int g_ts_lds_default = -2;
+static int g_ts_lds = -2;
 
 template <bool COL, int WY>
 static int launch_two_stage_w(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
@@ -305,11 +532,48 @@ static int launch_two_stage_w(const examg_layout_t *lu_, const double *u, const 
   return 0;
 }
 
+template <bool COL, int NW>
+static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
+                                double *out, const examg_stencil_t *st, double w, int first, const Box &box, const Box &box1,
+                                hipStream_t s) {
+  constexpr int NO = 2 * NW - 2;
+  const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
+  TSGeom g;
+  g.ntx = (box.n0() + TS_OUT - 1) / TS_OUT;
+  g.nty = (box.n1() + NO - 1) / NO;
+  const int xy = g.ntx * g.nty;
+  int ntz = (g_ts_blocks + xy - 1) / xy;
+  if (ntz < 1) ntz = 1;
+  int zc = (box.n2() + ntz - 1) / ntz;
+  if (zc < 16) zc = 16;
+  if (zc > box.n2()) zc = box.n2();
+  g.zc = zc;
+  g.ntz = (box.n2() + zc - 1) / zc;
+  g.nblocks = xy * g.ntz;
+  g.remap = 0;
+  g.first = first;
+  g.box1 = box1;
+  g.ax0 = -lu.ref0; g.ax1 = lu.tot0 - lu.ref0;
+  g.ay0 = -lu.ref1; g.ay1 = lu.tot1 - lu.ref1;
+  g.az0 = -lu.ref2; g.az1 = lu.tot2 - lu.ref2;
+  Coef7 k;
+  for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
+  const int ord = order7_ts(st);
+  dim3 block(64, NW, 1), grid(g.nblocks, 1, 1);
+  if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
+  else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
+  EXAMG_CHECK_LAUNCH("k_two_stage7_lds");
+  return 0;
+}
+
 template <bool COL>
 static int launch_two_stage(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
                             double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s,
                             const Box *box1 = nullptr) {
   const Box &b1 = box1 ? *box1 : box;
+  const int impl = g_ts_lds == -2 ? (box.n1() >= 192 ? 9 : 5) : g_ts_lds;
+  if (impl == 9) return launch_two_stage_lds<COL, 9>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
+  if (impl == 5) return launch_two_stage_lds<COL, 5>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
   if (g_ts_wy == 8) return launch_two_stage_w<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
   if (g_ts_wy == 2) return launch_two_stage_w<COL, 2>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
   return launch_two_stage_w<COL, 4>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
@@ -323,6 +587,11 @@ static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, con
 }  // namespace examg
 
 using namespace examg;
+
+extern "C" int examg_debug_two_stage_lds(int nw) {
+  g_ts_lds = nw < 0 ? g_ts_lds_default : nw;
+  return 0;
+}
 
 extern "C" int examg_debug_two_stage(int disable, int blocks, int remap, int wy) {
   g_ts_disable = disable;

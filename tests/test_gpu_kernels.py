@@ -174,10 +174,22 @@ def _two_stage_reference(orc, kind, shape, st, b, e, first=0):
     return [orc.to_host(out), orc.to_host(u)]
 
 
+@pytest.fixture(params=[0, 5, 9], ids=["registers", "lds5", "lds9"])
+def two_stage_variant(request, hip):
+    """Both implementations of the two-stage kernel: register rings (one wave per row pair, halo recomputed) and the
+    LDS variant (5 or 9 waves share a row stack through LDS)."""
+    import ctypes as C
+
+    hip.L.examg_debug_two_stage_lds.argtypes = [C.c_int]
+    hip.L.examg_debug_two_stage_lds(request.param)
+    yield request.param
+    hip.L.examg_debug_two_stage_lds(-1)     # back to the shipped default
+
+
 @pytest.mark.parametrize("kind", ["rbgs", "jacobi2"])
 @pytest.mark.parametrize("order", ["mp", "pm"])
 @pytest.mark.parametrize("n,first", [(65, 0), (130, 1), (200, 0)])
-def test_two_stage_kernel_bit_exact(hip, orc, kind, order, n, first):
+def test_two_stage_kernel_bit_exact(hip, orc, two_stage_variant, kind, order, n, first):
     """Fused red-black sweep / two Jacobi steps in one pass == the two loops run one after the other, bit for bit;
     130 and 200 leave ragged 124-point x windows, row groups and z chunks."""
     st = laplace_fd(3, (1.0 / n,) * 3, order)
@@ -189,7 +201,7 @@ def test_two_stage_kernel_bit_exact(hip, orc, kind, order, n, first):
 
 
 @pytest.mark.parametrize("kind", ["rbgs", "jacobi2"])
-def test_two_stage_interior_faces_anisotropic(hip, orc, kind):
+def test_two_stage_interior_faces_anisotropic(hip, orc, two_stage_variant, kind):
     """Block with neighbours on some faces: the loop includes the duplicate planes (begin 0 / end n+1), so the
     two-point input halo reaches the ghost layer and beyond the allocation (guarded)."""
     shape = (150, 36, 20)
@@ -206,7 +218,7 @@ def test_two_stage_interior_faces_anisotropic(hip, orc, kind):
     ((130, 70, 33), [1, 0, 1], [130, 71, 33], [1, 1, 1], [130, 71, 33]),     # lower y neighbour only
     ((40, 20, 20), [0, 1, 1], [41, 20, 20], [1, 1, 1], [41, 20, 20]),        # small rows: fallback path
 ])
-def test_jacobi2_boxes_bit_exact(hip, orc, shape, b, e, b2, e2):
+def test_jacobi2_boxes_bit_exact(hip, orc, two_stage_variant, shape, b, e, b2, e2):
     """Two Jacobi steps with the first step on the loop's box and the second on the box without the duplicate planes at
     interior faces (what a block with neighbours runs, exastencils_amd/smoothers.py)."""
     st = laplace_unit(3)

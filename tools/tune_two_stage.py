@@ -12,6 +12,7 @@ level = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 ops = HipOps(0)
 L = ops.L
 L.examg_debug_two_stage.argtypes = [C.c_int] * 4
+L.examg_debug_two_stage_lds.argtypes = [C.c_int]
 n = 1 << level
 lu, lf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0)
 u, un, f = ops.new_array(lu.size), ops.new_array(lu.size), ops.new_array(lf.size)
@@ -23,8 +24,11 @@ Ls, Fs = lu.c_struct(), lf.c_struct()
 res = []
 for kind in ("jacobi2", "rbgs"):
     ref = None
-    for wy, remap, blocks in itertools.product((2, 4, 8), (0, 1), (256, 512, 1024, 2048, 4096)):
-        L.examg_debug_two_stage(0, blocks, remap, wy)
+    configs = [(0, wy, remap, blocks) for wy, remap, blocks in itertools.product((4, 8), (0,), (2048, 4096))]
+    configs += [(nw, 0, 0, blocks) for nw in (5, 9) for blocks in (256, 512, 1024, 2048, 4096)]
+    for lds, wy, remap, blocks in configs:
+        L.examg_debug_two_stage_lds(lds)
+        L.examg_debug_two_stage(0, blocks, remap, wy if wy else 8)
         fn = (lambda: ops.jacobi2(Ls, u, un, None, Fs, f, A, w, b, e)) if kind == "jacobi2" else (lambda: ops.rbgs_sweep_fused(Ls, u, un, Fs, f, A, w, 0, b, e))
         un.zero_(); fn(); torch.cuda.synchronize()
         chk = un.clone()
@@ -35,7 +39,7 @@ for kind in ("jacobi2", "rbgs"):
         for _ in range(10): fn()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        r = dict(kind=kind, wy=wy, remap=remap, blocks=blocks, ms=ms, same=same)
+        r = dict(kind=kind, lds=lds, wy=wy, remap=remap, blocks=blocks, ms=ms, same=same)
         res.append(r); print(r, flush=True)
 for kind in ("jacobi2", "rbgs"):
     print("best", kind, sorted([r for r in res if r["kind"] == kind], key=lambda r: r["ms"])[:4])
