@@ -1,0 +1,66 @@
+"""Field output / input of the ExaSlang-4 surface: `printField`, `writeField`, `readField`.
+
+Reference: IR_PrintField with the "lock" interface (Compiler/src/exastencils/field/ir/IR_PrintField.scala:38-110): one
+line per point, node position per dimension then the value, separated by `separator`, std::defaultfloat; points
+DLB..DRE, or GLB..GRE with includeGhostLayers; optional condition.  Binary mode / writeField: the same points as raw
+doubles, x fastest (Compiler/src/exastencils/io/ir/IR_FileAccess_Locking.scala).  Data leave the device once, through the
+kernel layer's `to_host` (not performance-relevant: checkpoint/restart and visual verification).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+from .field import Field
+
+
+def _region(field: Field, include_ghost: bool):
+    lay = field.layout
+    lo = "GLB" if include_ghost else "DLB"
+    hi = "GRE" if include_ghost else "DRE"
+    b = [lay.idx(lo, d) if d < lay.nd else 0 for d in range(3)]
+    e = [lay.idx(hi, d) if d < lay.nd else 1 for d in range(3)]
+    sl = tuple(slice(b[d] + lay.ref(d), e[d] + lay.ref(d)) for d in (2, 1, 0))
+    return b, e, sl
+
+
+def _defaultfloat(v: float) -> str:
+    return "%g" % v      # std::defaultfloat at the default precision 6
+
+
+def print_field(filename: str, field: Field, ops, domain, slot: Optional[int] = None, include_ghost: bool = False,
+                separator: str = " ", condition: Optional[Callable[[int, int, int], bool]] = None, append: bool = False):
+    """printField ( filename, field ): `x [y [z]] value` per point of this block."""
+    b, e, sl = _region(field, include_ghost)
+    a = ops.to_host(field.data(slot)).reshape(field.layout.shape_zyx)[sl]
+    g = domain.geom(field.level)
+    nd = field.layout.nd
+    with open(filename, "a" if append else "w") as f:
+        for k in range(a.shape[0]):
+            for j in range(a.shape[1]):
+                for i in range(a.shape[2]):
+                    i0, i1, i2 = b[0] + i, b[1] + j, b[2] + k
+                    if condition is not None and not condition(i0, i1, i2):
+                        continue
+                    pos = [i0 * g.h[0] + g.pos_begin[0], i1 * g.h[1] + g.pos_begin[1], i2 * g.h[2] + g.pos_begin[2]][:nd]
+                    f.write(separator.join(_defaultfloat(p) for p in pos) + separator + _defaultfloat(float(a[k, j, i])) + "\n")
+
+
+def write_field(filename: str, field: Field, ops, slot: Optional[int] = None, include_ghost: bool = False):
+    """writeField ( filename, field ) in binary mode: raw doubles of DLB..DRE (or GLB..GRE), x fastest."""
+    _, _, sl = _region(field, include_ghost)
+    a = ops.to_host(field.data(slot)).reshape(field.layout.shape_zyx)[sl]
+    np.ascontiguousarray(a, dtype=np.float64).tofile(filename)
+
+
+def read_field(filename: str, field: Field, ops, slot: Optional[int] = None, include_ghost: bool = False):
+    """readField ( filename, field ): the inverse of write_field; points outside the region keep their values."""
+    _, _, sl = _region(field, include_ghost)
+    full = ops.to_host(field.data(slot)).reshape(field.layout.shape_zyx).copy()
+    want = full[sl].shape
+    a = np.fromfile(filename, dtype=np.float64)
+    if a.size != int(np.prod(want)):
+        raise ValueError("%s holds %d values, the field region needs %d" % (filename, a.size, int(np.prod(want))))
+    full[sl] = a.reshape(want)
+    field.data(slot).copy_(ops.from_host(full.reshape(-1)))
