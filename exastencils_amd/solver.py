@@ -158,6 +158,15 @@ class SolverFromL4(_Program):
             b, e = self.bounds(f)
             self.ops.fill_fn(f.lc, f.data(), self.domain.geom(hi), cfg.rhs_fn, (), b, e)
         self.apply_bc(self.Solution[hi])
+        self._init_alt_shells()
+
+    def _init_alt_shells(self):
+        """The second Solution array of the fused red-black sweep carries the same Dirichlet shell as the field."""
+        mask = self.domain.face_mask()
+        for l, alt in self._sol_alt.items():
+            S = self.Solution[l]
+            if S.bc_fn is not None and mask:
+                self.ops.apply_dirichlet(S.lc, alt, self.domain.geom(l), S.bc_fn, S.bc_params, mask)
 
     def reset(self):
         """Back to the state after initFieldsWithZero + setup(): arrays are zeroed in place (device pointers, and with
@@ -207,13 +216,14 @@ class SolverFromL4(_Program):
         w = self.cfg.omega / A.diag           # `0.8 / diag(Laplace)`, folded to a literal by the generator
         b, e = self.bounds(S)
         if self.cfg.fused_rbgs and self._single_block():
-            # one pass per sweep; the exchange is empty on one block and `apply bc` re-writes values that the
-            # sweep copies through unchanged, so the two half sweeps fuse without changing any bit
+            # one pass per sweep; the exchange is empty on one block.  The sweep writes the loop's box only and
+            # `apply bc` would re-write the same position-only Dirichlet values each time: both arrays get their
+            # shell once, the per-colour `apply bc` calls become no-ops and are dropped -- no bit changes
+            # (_init_alt_shells, called from setup())
             for _ in range(self.cfg.n_smooth):
                 alt = self._sol_alt[l]
                 self.ops.rbgs_sweep_fused(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e)
                 self._sol_alt[l], S.slots[0] = S.slots[0], alt
-                self.apply_bc(S)      # the sweep writes the loop's box only; the Dirichlet shell comes from `apply bc`
             return
         for _ in range(self.cfg.n_smooth):
             for colour in (0, 1):

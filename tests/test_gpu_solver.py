@@ -109,6 +109,19 @@ def test_graph_replay_equals_eager(hip):
     assert np.array_equal(hip.to_host(a.Solution[7].data()), hip.to_host(b.Solution[7].data()))
 
 
+def test_graph_solve_after_reset_equals_eager(hip):
+    """bench.py's totalTimeSolve path: capture, reset() to the initial state, Solve with graph replays -- same history
+    as the eager, unfused program."""
+    a = _l4(hip, fused_rbgs=True, max_level=6)
+    a.capture_cycle()
+    a.reset()
+    a.Solve(use_graph=True)
+    b = _l4(hip, fused_rbgs=False, fused_coarse=False, max_level=6)
+    b.Solve()
+    assert a.iterations == b.iterations
+    _close(a.res_history, b.res_history, 1e-12)
+
+
 def test_fused_rbgs_sweep_bit_exact(hip):
     a, b = _l4(hip, fused_rbgs=True), _l4(hip, fused_rbgs=False)
     for P in (a, b):
