@@ -119,6 +119,86 @@ __device__ __forceinline__ double lane_above(double v) {   // lane l receives la
   return __hiloint2double(hi, lo);
 }
 
+// ---- shared by the 7-point kernels (kernels_stencil.hip, kernels_twostage.hip, kernels_stencilfield.hip) ----------
+typedef double d2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(8))) d2u { double a, b; };  // 16-byte access at 8-byte alignment
+
+__device__ __forceinline__ d2 load2(const double *p) {
+  const d2u v = *reinterpret_cast<const d2u *>(p);
+  d2 r;
+  r.x = v.a;
+  r.y = v.b;
+  return r;
+}
+__device__ __forceinline__ void store2(double *p, d2 v) {
+  d2u s;
+  s.a = v.x;
+  s.b = v.y;
+  *reinterpret_cast<d2u *>(p) = s;
+}
+// 16-byte load where both points may be read, scalar loads at the edges of an allocation / box, 0 outside
+__device__ __forceinline__ d2 load2g(const double *p, bool oka, bool okb) {
+  d2 r = {0.0, 0.0};
+  if (oka && okb) return load2(p);
+  if (oka) r.x = p[0];
+  else if (okb) r.y = p[1];
+  return r;
+}
+
+struct Coef7 {
+  double c[7];
+};
+
+// sum_k c_k * u[i + o_k] folded left to right in entry order
+// (Compiler/src/exastencils/stencil/ir/IR_StencilConvolution.scala:65-68).
+// ORDER 0: entries c,-x,+x,-y,+y,-z,+z (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:39-47)
+// ORDER 1: entries c,+x,-x,+y,-y,+z,-z (Testing/Smoothers/Jac.exa4:55-63)
+template <int ORDER>
+__device__ __forceinline__ double conv7(const Coef7 &k, double c, double xm, double xp, double ym, double yp, double zm,
+                                        double zp) {
+  double acc = k.c[0] * c;
+  if (ORDER == 0) {
+    acc = acc + k.c[1] * xm;
+    acc = acc + k.c[2] * xp;
+    acc = acc + k.c[3] * ym;
+    acc = acc + k.c[4] * yp;
+    acc = acc + k.c[5] * zm;
+    acc = acc + k.c[6] * zp;
+  } else {
+    acc = acc + k.c[1] * xp;
+    acc = acc + k.c[2] * xm;
+    acc = acc + k.c[3] * yp;
+    acc = acc + k.c[4] * ym;
+    acc = acc + k.c[5] * zp;
+    acc = acc + k.c[6] * zm;
+  }
+  return acc;
+}
+
+// Which canonical 7-point entry order does a constant stencil use?  -1: none of the two.
+static inline int canonical_order7(const examg_stencil_t *st) {
+  static const int o0[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+  static const int o1[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+  if (st->nent != 7 || st->cfield) return -1;
+  bool m0 = true, m1 = true;
+  for (int k = 0; k < 7; ++k)
+    for (int d = 0; d < 3; ++d) {
+      m0 = m0 && st->off[k][d] == o0[k][d];
+      m1 = m1 && st->off[k][d] == o1[k][d];
+    }
+  return m0 ? 0 : (m1 ? 1 : -1);
+}
+
+static inline int stencil_reach(const examg_stencil_t *st) {
+  int reach = 0;
+  for (int k = 0; k < st->nent; ++k)
+    for (int d = 0; d < 3; ++d) {
+      const int a = st->off[k][d] < 0 ? -st->off[k][d] : st->off[k][d];
+      reach = reach > a ? reach : a;
+    }
+  return reach;
+}
+
 struct Params4 {
   double v[4];
 };

@@ -199,9 +199,7 @@ extern "C" int examg_cg_coarse(const examg_layout_t *lu_, double *sol, const exa
     return 0;
   }
   if (box.count() > (1 << 22)) { set_error("examg_cg_coarse: box too large for the single-workgroup solver"); return 1; }
-  int reach = 0;
-  for (int k = 0; k < st->nent; ++k)
-    for (int d = 0; d < 3; ++d) reach = reach > abs(st->off[k][d]) ? reach : abs(st->off[k][d]);
+  const int reach = stencil_reach(st);
   if (!box_inside(lu_, box, reach) || !box_inside(lp_, box, reach) || !box_inside(lf_, box, 0) || !box_inside(lr_, box, 0) ||
       !box_inside(lq_, box, 0)) {
     set_error("examg_cg_coarse: box leaves an allocation");

@@ -88,51 +88,6 @@ k_stencil_generic(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
 // ---------------------------------------------------------------------------------------------
 // 3-D 7-point constant-coefficient z-marching kernel
 // ---------------------------------------------------------------------------------------------
-typedef double d2 __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(8))) d2u { double a, b; };  // 16-byte load at 8-byte alignment
-
-__device__ __forceinline__ d2 load2(const double *p) {
-  const d2u v = *reinterpret_cast<const d2u *>(p);
-  d2 r;
-  r.x = v.a;
-  r.y = v.b;
-  return r;
-}
-__device__ __forceinline__ void store2(double *p, d2 v) {
-  d2u s;
-  s.a = v.x;
-  s.b = v.y;
-  *reinterpret_cast<d2u *>(p) = s;
-}
-
-struct Coef7 {
-  double c[7];
-};
-
-// ORDER 0: entries c,-x,+x,-y,+y,-z,+z (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:39-47)
-// ORDER 1: entries c,+x,-x,+y,-y,+z,-z (Testing/Smoothers/Jac.exa4:55-63)
-template <int ORDER>
-__device__ __forceinline__ double conv7(const Coef7 &k, double c, double xm, double xp, double ym, double yp, double zm,
-                                        double zp) {
-  double acc = k.c[0] * c;
-  if (ORDER == 0) {
-    acc = acc + k.c[1] * xm;
-    acc = acc + k.c[2] * xp;
-    acc = acc + k.c[3] * ym;
-    acc = acc + k.c[4] * yp;
-    acc = acc + k.c[5] * zm;
-    acc = acc + k.c[6] * zp;
-  } else {
-    acc = acc + k.c[1] * xp;
-    acc = acc + k.c[2] * xm;
-    acc = acc + k.c[3] * yp;
-    acc = acc + k.c[4] * ym;
-    acc = acc + k.c[5] * zp;
-    acc = acc + k.c[6] * zm;
-  }
-  return acc;
-}
-
 template <int MODE>
 __device__ __forceinline__ double finish(double u, double acc, double f, double w) {
   if (MODE == EXAMG_APPLY) return acc;
@@ -310,20 +265,6 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
   }
 }
 
-// Which canonical 7-point entry order (if any) does this stencil use?  -1: none.
-static int order7(const examg_stencil_t *st) {
-  static const int o0[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
-  static const int o1[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
-  if (st->nent != 7 || st->cfield) return -1;
-  bool m0 = true, m1 = true;
-  for (int k = 0; k < 7; ++k)
-    for (int d = 0; d < 3; ++d) {
-      m0 = m0 && st->off[k][d] == o0[k][d];
-      m1 = m1 && st->off[k][d] == o1[k][d];
-    }
-  return m0 ? 0 : (m1 ? 1 : -1);
-}
-
 static int g_force_generic = 0;  // test hook: examg_debug_force_generic
 
 // kernels_stencilfield.hip
@@ -459,9 +400,7 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   if (colour > 1) { set_error("examg_stencil_op: colour must be -1, 0 or 1"); return 1; }
   const Box box = make_box(begin, end);
   if (box.count() == 0) return 0;  // empty iteration space (e.g. coarsest level of one fragment with minLevel 0)
-  int reach = 0;
-  for (int k = 0; k < st->nent; ++k)
-    for (int d = 0; d < 3; ++d) reach = reach > abs(st->off[k][d]) ? reach : abs(st->off[k][d]);
+  const int reach = stencil_reach(st);
   if (!box_inside(lu_, box, reach)) { set_error("examg_stencil_op: box + stencil reach leaves the u allocation"); return 1; }
   if (!box_inside(ld_, box, 0)) { set_error("examg_stencil_op: box leaves the dst allocation"); return 1; }
   if (mode != EXAMG_APPLY && !box_inside(lf_, box, 0)) { set_error("examg_stencil_op: box leaves the rhs allocation"); return 1; }
@@ -472,7 +411,7 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   const LayoutDev lf = lf_ ? make_layout(lf_) : lu;
   hipStream_t s = (hipStream_t)stream;
 
-  const int ord = order7(st);
+  const int ord = canonical_order7(st);
   const bool colour_ok = colour < 0 || (mode == EXAMG_SMOOTH && u == dst && memcmp(lu_, ld_, sizeof(*lu_)) == 0);
   if (!g_force_generic && lu_->nd == 3 && ord >= 0 && colour_ok && box.n0() >= 64) {
     Coef7 k;

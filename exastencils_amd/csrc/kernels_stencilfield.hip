@@ -10,20 +10,9 @@
 
 namespace examg {
 
-typedef double d2 __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(8))) d2u_sf { double a, b; };
-
-__device__ __forceinline__ d2 sf_load2(const double *p) {
-  const d2u_sf v = *reinterpret_cast<const d2u_sf *>(p);
-  d2 r;
-  r.x = v.a;
-  r.y = v.b;
-  return r;
-}
-
 // rhs / coefficient rows have no ghost layer: the lane holding the last point of a row must not read past it
 __device__ __forceinline__ d2 sf_load2g(const double *p, bool both) {
-  if (both) return sf_load2(p);
+  if (both) return load2(p);
   d2 r;
   r.x = p[0];
   r.y = 0.0;
@@ -72,8 +61,8 @@ k_stencilfield7_zmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf,
   d2 um[RY], uc[RY];
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
-    um[r] = sf_load2(ur[r] + lu.s2 * (mb - 1));
-    uc[r] = sf_load2(ur[r] + lu.s2 * mb);
+    um[r] = load2(ur[r] + lu.s2 * (mb - 1));
+    uc[r] = load2(ur[r] + lu.s2 * mb);
   }
   struct Stage {
     d2 up[RY], f[RY], hm, hp, c[RY][7];
@@ -81,13 +70,13 @@ k_stencilfield7_zmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf,
   auto load_stage = [&](Stage &st, int m) {
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-      st.up[r] = sf_load2(ur[r] + lu.s2 * (m + 1));
+      st.up[r] = load2(ur[r] + lu.s2 * (m + 1));
       if (MODE != EXAMG_APPLY) st.f[r] = sf_load2g(fr[r] + lf.s2 * m, vb || !va);
 #pragma unroll
       for (int k = 0; k < 7; ++k) st.c[r][k] = sf_load2g(cr[r] + lc.s2 * m + cplane * k, vb || !va);
     }
-    st.hm = sf_load2(uhm + lu.s2 * m);
-    st.hp = sf_load2(uhp + lu.s2 * m);
+    st.hm = load2(uhm + lu.s2 * m);
+    st.hp = load2(uhp + lu.s2 * m);
   };
   auto compute = [&](const Stage &st, int m) {
 #pragma unroll

@@ -19,35 +19,6 @@
 
 namespace examg {
 
-typedef double d2 __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(8))) d2u_ts { double a, b; };
-
-struct Coef7 {
-  double c[7];
-};
-
-template <int ORDER>
-__device__ __forceinline__ double conv7(const Coef7 &k, double c, double xm, double xp, double ym, double yp, double zm,
-                                        double zp) {
-  double acc = k.c[0] * c;
-  if (ORDER == 0) {
-    acc = acc + k.c[1] * xm;
-    acc = acc + k.c[2] * xp;
-    acc = acc + k.c[3] * ym;
-    acc = acc + k.c[4] * yp;
-    acc = acc + k.c[5] * zm;
-    acc = acc + k.c[6] * zp;
-  } else {
-    acc = acc + k.c[1] * xp;
-    acc = acc + k.c[2] * xm;
-    acc = acc + k.c[3] * yp;
-    acc = acc + k.c[4] * ym;
-    acc = acc + k.c[5] * zp;
-    acc = acc + k.c[6] * zm;
-  }
-  return acc;
-}
-
 struct TSGeom {
   int ntx, nty, ntz, zc, nblocks, remap;
   int first;               // COL: colour updated in stage 1
@@ -56,21 +27,6 @@ struct TSGeom {
 };
 
 constexpr int TS_OUT = 124;  // outputs per 128-point window
-
-// 16-byte load where both points are inside the allocation, scalar loads at the edges, 0 outside
-__device__ __forceinline__ d2 load2g(const double *p, bool oka, bool okb) {
-  d2 r = {0.0, 0.0};
-  if (oka && okb) {
-    const d2u_ts v = *reinterpret_cast<const d2u_ts *>(p);
-    r.x = v.a;
-    r.y = v.b;
-  } else if (oka) {
-    r.x = p[0];
-  } else if (okb) {
-    r.y = p[1];
-  }
-  return r;
-}
 
 template <int ORDER, bool COL, int RY, int WY, bool NT>
 __global__ void __launch_bounds__(64 * WY)
@@ -211,10 +167,10 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
             __builtin_nontemporal_store(o.x, q);
             __builtin_nontemporal_store(o.y, q + 1);
           } else {
-            d2u_ts s;
+            d2u s;
             s.a = o.x;
             s.b = o.y;
-            *reinterpret_cast<d2u_ts *>(q) = s;
+            *reinterpret_cast<d2u *>(q) = s;
           }
         } else if (inx_a) {
           q[0] = o.x;
@@ -429,10 +385,10 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
               __builtin_nontemporal_store(o.x, qp);
               __builtin_nontemporal_store(o.y, qp + 1);
             } else {
-              d2u_ts sv;
+              d2u sv;
               sv.a = o.x;
               sv.b = o.y;
-              *reinterpret_cast<d2u_ts *>(qp) = sv;
+              *reinterpret_cast<d2u *>(qp) = sv;
             }
           } else if (inx_a) {
             qp[0] = o.x;
@@ -474,19 +430,6 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   }
 }
 
-static int order7_ts(const examg_stencil_t *st) {
-  static const int o0[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
-  static const int o1[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
-  if (st->nent != 7 || st->cfield) return -1;
-  bool m0 = true, m1 = true;
-  for (int k = 0; k < 7; ++k)
-    for (int d = 0; d < 3; ++d) {
-      m0 = m0 && st->off[k][d] == o0[k][d];
-      m1 = m1 && st->off[k][d] == o1[k][d];
-    }
-  return m0 ? 0 : (m1 ? 1 : -1);
-}
-
 // launch knobs of the register variant (8 waves per workgroup, plain tile order) and the workgroup count target
 static int g_ts_blocks = 2048;
 static int g_ts_disable = 0;
@@ -524,7 +467,7 @@ static int launch_two_stage_w(const examg_layout_t *lu_, const double *u, const 
   g.az0 = -lu.ref2; g.az1 = lu.tot2 - lu.ref2;
   Coef7 k;
   for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
-  const int ord = order7_ts(st);
+  const int ord = canonical_order7(st);
   dim3 block(64, WY, 1), grid(g.nblocks, 1, 1);
   if (ord == 0) hipLaunchKernelGGL((k_two_stage7<0, COL, RY, WY, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
   else hipLaunchKernelGGL((k_two_stage7<1, COL, RY, WY, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
@@ -558,7 +501,7 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   g.az0 = -lu.ref2; g.az1 = lu.tot2 - lu.ref2;
   Coef7 k;
   for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
-  const int ord = order7_ts(st);
+  const int ord = canonical_order7(st);
   dim3 block(64, NW, 1), grid(g.nblocks, 1, 1);
   if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
   else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
@@ -580,7 +523,7 @@ static int launch_two_stage(const examg_layout_t *lu_, const double *u, const ex
 }
 
 static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
-  return !g_ts_disable && lu->nd == 3 && order7_ts(st) >= 0 && box.n0() >= 64 && box_inside(lu, box, 1) &&
+  return !g_ts_disable && lu->nd == 3 && canonical_order7(st) >= 0 && box.n0() >= 64 && box_inside(lu, box, 1) &&
          box_inside(lf, box, 0);
 }
 
@@ -613,9 +556,7 @@ extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_
   if (two_stage_ok(lu, lf, st, box)) return launch_two_stage<true>(lu, u_in, lf, rhs, u_out, st, w, first, box, (hipStream_t)stream);
   // general stencils / small boxes: bring the box and its one-stencil-reach shell over, then the two half
   // sweeps in place on the copy (the shell of u_out receives u_in's shell values -- see the header)
-  int reach = 0;
-  for (int k = 0; k < st->nent; ++k)
-    for (int d = 0; d < 3; ++d) reach = reach > abs(st->off[k][d]) ? reach : abs(st->off[k][d]);
+  const int reach = stencil_reach(st);
   int32_t b2[3], e2[3];
   for (int d = 0; d < 3; ++d) {
     const bool on = d < lu->nd;
@@ -647,9 +588,7 @@ extern "C" int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in,
   if (two_stage_ok(lu, lf, st, box2) && box_inside(lu, box1, 1) && box_inside(lf, box1, 0))
     return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box2, (hipStream_t)stream, &box1);
   if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2_boxes: fallback needs a distinct tmp array"); return 1; }
-  int reach = 0;
-  for (int k = 0; k < st->nent; ++k)
-    for (int d = 0; d < 3; ++d) reach = reach > abs(st->off[k][d]) ? reach : abs(st->off[k][d]);
+  const int reach = stencil_reach(st);
   int32_t b2[3], e2[3];
   for (int d = 0; d < 3; ++d) {
     const bool on = d < lu->nd;
@@ -675,9 +614,7 @@ extern "C" int examg_jacobi2(const examg_layout_t *lu, const double *u_in, doubl
   if (two_stage_ok(lu, lf, st, box)) return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box, (hipStream_t)stream);
   if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2: fallback needs a distinct tmp array"); return 1; }
   // the intermediate sweep needs the box's shell (Dirichlet / halo values) in tmp
-  int reach = 0;
-  for (int k = 0; k < st->nent; ++k)
-    for (int d = 0; d < 3; ++d) reach = reach > abs(st->off[k][d]) ? reach : abs(st->off[k][d]);
+  const int reach = stencil_reach(st);
   int32_t b2[3], e2[3];
   for (int d = 0; d < 3; ++d) {
     const bool on = d < lu->nd;
