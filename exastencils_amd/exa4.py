@@ -1,0 +1,1665 @@
+"""ExaSlang-4 subset reader and interpreter: run the reference's own multigrid programs on libexamg.
+
+The reference compiles an ExaSlang-4 program (`*.exa4`) plus a `.knowledge` file into C++/CUDA whose hot loops are
+what libexamg implements.  This module reads the same two inputs and executes the program directly:
+declarations become device fields and host stencils, leveled functions are interpreted, and every `loop over` body is
+recognised as one of the emitted-loop kinds and issued as ONE library call on the current HIP stream -- there is no
+per-point interpretation, no generated code and no CPU arithmetic on field data.
+
+Grammar covered (Compiler/src/exastencils/parsers/l4/L4_Parser.scala): `Domain` (:286-296), `Layout` with
+`ghostLayers` / `duplicateLayers [with communication]` (:378-396), `Field name< domain, layout, bc >[slots]@levels`
+(:398-408), `Stencil` with offset entries, `from [...] with` mapping entries and `from default restriction|prolongation`
+(:430-466), `StencilField` (:468-472), `Globals` (:227-233), leveled `Function`s (:235-260) with `Var`/`Val`,
+assignments, `loop over f [only dup [..] on boundary] [where c] [with reduction (op : v)]` (:303-340),
+`communicate [ghost|dup of]`, `apply bc to`, `advance`, `repeat n times [count v]`, `repeat until`, `if/else`,
+`color with`, `return`, level scopes `@(...) { }` (:653-667), declaration level lists `@all`, `@(a to b)`, `@(a, b)`,
+`@(a and b)`, `@(all but x)`, `coarsest + 1`, and access levels `@current|coarser|finer|finest|coarsest|<n>`.
+
+Loop bodies recognised (anything else raises Exa4Unsupported -- nothing is silently approximated):
+  F = c | F = G | F = analytic(x,y,z) | F += a*G | F -= a*G | F = G + b*F            examg_set/fill_fn/axpby
+  R = RHS - A*U | D = A*U                                                            examg_residual / stencil_op(APPLY)
+  U<next> = U<active> + w(diag A) * (RHS - A*U<active>)                              examg_jacobi
+  U += w(diag A) * (RHS - A*U)   inside `color with {(i0+i1+i2) % 2, ...}` or `where (c == (i0+i1+i2) % 2)`
+                                                                                      examg_rbgs_colour
+  RHS@coarser = [s *] Restriction * Residual | U += Prolongation@coarser * U@coarser  examg_restrict / examg_prolong_add
+  s += F*G (reduction +) | s = max(s, fabs(F - analytic)) (reduction max)             examg_dot / examg_max_err_fn
+  A:[o] = -a(x +- h/2)/h^2 ... (7 entries of a stencil field)                         examg_init_varcoeff7
+Analytic point functions (boundary values, right-hand sides, exact solutions, coefficient functions) are matched
+numerically against the built-in function ids of include/examg.h; an expression outside that set is unsupported.
+
+Two deliberate readings of printed-L4 files (Testing/Smoothers/Jac.exa4:43 declares the finest `Solution` without level
+and slot count): a declaration never overrides an earlier one on the same level (the reference's collection lookup
+returns the first match, knowledge/l4/L4_KnowledgeCollection.scala:78-79), and a field name has one slot count, the
+maximum over its declarations.
+"""
+from __future__ import annotations
+
+import math
+import random
+import re
+import time
+from dataclasses import dataclass, field as _dcf
+from typing import Dict, List, Optional, Sequence, Tuple
+
+from . import knowledge as _knowledge
+from .comm import Communicator
+from .domain import RectDomain
+from .field import Field, Stencil
+from .layout import FieldLayout
+
+APPLY, RESIDUAL, SMOOTH = 0, 1, 2
+
+
+class Exa4SyntaxError(ValueError):
+    pass
+
+
+class Exa4Unsupported(NotImplementedError):
+    pass
+
+
+# =====================================================================================================================
+# lexer
+# =====================================================================================================================
+_TOKEN = re.compile(r"""
+    (?P<ws>\s+|//[^\n]*|/\*.*?\*/)
+  | (?P<num>(?:\d+\.\d*|\.\d+|\d+)(?:[eE][+-]?\d+)?)
+  | (?P<id>[A-Za-z_][A-Za-z0-9_]*)
+  | (?P<str>"[^"\n]*"|'[^'\n]*')
+  | (?P<op>=>|\*\*|\+=|-=|\*=|/=|==|!=|<=|>=|&&|\|\||[@()\[\]{}<>,:=+\-*/%!.])
+""", re.X | re.S)
+
+
+@dataclass
+class Tok:
+    kind: str
+    text: str
+    line: int
+
+
+def tokenize(text: str) -> List[Tok]:
+    out, pos, line = [], 0, 1
+    while pos < len(text):
+        m = _TOKEN.match(text, pos)
+        if not m:
+            raise Exa4SyntaxError("line %d: cannot read %r" % (line, text[pos:pos + 20]))
+        kind = m.lastgroup
+        if kind != "ws":
+            out.append(Tok(kind, m.group(), line))
+        line += m.group().count("\n")
+        pos = m.end()
+    out.append(Tok("eof", "", line))
+    return out
+
+
+# =====================================================================================================================
+# declarations
+# =====================================================================================================================
+@dataclass
+class LayoutDecl:
+    name: str
+    datatype: str
+    vec_len: int
+    localization: str
+    levels: object
+    ghost: Tuple[int, ...] = ()
+    dup: Tuple[int, ...] = ()
+    ghost_comm: bool = False
+    dup_comm: bool = False
+
+
+@dataclass
+class FieldDecl:
+    name: str
+    domain: str
+    layout: str
+    bc: object          # None | expression
+    slots: int
+    levels: object
+
+
+@dataclass
+class StencilDecl:
+    name: str
+    levels: object
+    entries: List[Tuple[Tuple[int, ...], object]] = _dcf(default_factory=list)   # (offset, coefficient expression)
+    transfer: Optional[str] = None      # 'restriction' | 'prolongation'
+
+
+@dataclass
+class StencilFieldDecl:
+    name: str
+    field: str
+    stencil: str
+    levels: object
+
+
+@dataclass
+class FunctionDecl:
+    name: str
+    levels: object
+    params: List[str]
+    body: list
+
+
+_STMT_WORDS = {"loop", "communicate", "apply", "advance", "repeat", "if", "Var", "Val", "Variable", "Value", "color", "return",
+               "begin", "finish", "print"}
+_SLOT_WORDS = {"active", "activeSlot", "current", "currentSlot", "next", "nextSlot", "previous", "previousSlot"}
+_LEVEL_WORDS = {"current", "coarser", "finer", "finest", "coarsest", "all"}
+_MATH = {"sqrt": math.sqrt, "fabs": abs, "abs": abs, "sin": math.sin, "cos": math.cos, "tan": math.tan, "exp": math.exp,
+         "sinh": math.sinh, "cosh": math.cosh, "tanh": math.tanh, "log": math.log, "pow": math.pow, "max": max, "min": min,
+         "floor": math.floor, "ceil": math.ceil}
+_COORD = re.compile(r"^vf_(nodePosition|nodePos|boundaryCoord|boundaryPosition|boundaryPos)_([xyz])$")
+_GRIDW = re.compile(r"^vf_gridWidth_([xyz])$")
+
+
+# =====================================================================================================================
+# parser
+# =====================================================================================================================
+class Parser:
+    def __init__(self, text: str):
+        self.toks = tokenize(text)
+        self.p = 0
+        self.field_names = set(re.findall(r"^\s*Field\s+([A-Za-z_]\w*)", text, re.M))
+        self.stencil_names = set(re.findall(r"^\s*Stencil\s+([A-Za-z_]\w*)", text, re.M))
+        self.sfield_names = set(re.findall(r"^\s*StencilField\s+([A-Za-z_]\w*)", text, re.M))
+        self.domain = None
+        self.layouts: List[LayoutDecl] = []
+        self.fields: List[FieldDecl] = []
+        self.stencils: List[StencilDecl] = []
+        self.sfields: List[StencilFieldDecl] = []
+        self.globals: List[Tuple[str, object]] = []
+        self.functions: List[FunctionDecl] = []
+
+    # -- token helpers --------------------------------------------------------------------------------------------
+    def peek(self, k: int = 0) -> Tok:
+        return self.toks[min(self.p + k, len(self.toks) - 1)]
+
+    def next(self) -> Tok:
+        t = self.toks[self.p]
+        self.p += 1
+        return t
+
+    def at(self, text: str, k: int = 0) -> bool:
+        return self.peek(k).text == text and self.peek(k).kind != "str"
+
+    def accept(self, text: str) -> bool:
+        if self.at(text):
+            self.p += 1
+            return True
+        return False
+
+    def expect(self, text: str) -> Tok:
+        if not self.at(text):
+            t = self.peek()
+            raise Exa4SyntaxError("line %d: expected %r, found %r" % (t.line, text, t.text))
+        return self.next()
+
+    def ident(self) -> str:
+        t = self.next()
+        if t.kind != "id":
+            raise Exa4SyntaxError("line %d: expected a name, found %r" % (t.line, t.text))
+        return t.text
+
+    # -- program ----------------------------------------------------------------------------------------------------
+    def parse(self) -> "Parser":
+        while self.peek().kind != "eof":
+            t = self.peek()
+            if t.text == "Domain":
+                self._domain()
+            elif t.text == "Layout":
+                self._layout()
+            elif t.text == "Field":
+                self._field()
+            elif t.text == "Stencil":
+                self._stencil()
+            elif t.text == "StencilField":
+                self._stencil_field()
+            elif t.text == "Globals":
+                self._globals()
+            elif t.text in ("Function", "Func", "Def", "noinline"):
+                self._function()
+            else:
+                raise Exa4SyntaxError("line %d: unexpected %r at top level" % (t.line, t.text))
+        return self
+
+    def _const_list(self) -> list:
+        self.expect("[")
+        out = [self.expr(no_rel=True)]
+        while self.accept(","):
+            out.append(self.expr(no_rel=True))
+        self.expect("]")
+        return out
+
+    def _domain(self):
+        self.expect("Domain")
+        name = self.ident()
+        self.expect("<")
+        lo = self._const_list()
+        self.expect("to")
+        hi = self._const_list()
+        self.expect(">")
+        self.domain = (name, lo, hi)
+
+    def _layout(self):
+        self.expect("Layout")
+        name = self.ident()
+        self.expect("<")
+        dt, vec = self.ident(), 1
+        if self.accept("<"):        # ColumnVector<Real,7>
+            self.ident()
+            self.expect(",")
+            vec = int(self.next().text)
+            self.expect(">")
+        self.expect(",")
+        loc = self.ident()
+        self.expect(">")
+        levels = self.decl_levels()
+        d = LayoutDecl(name, dt, vec, loc, levels)
+        self.expect("{")
+        while not self.accept("}"):
+            key = self.ident()
+            self.expect("=")
+            vals = tuple(int(_const_value(e)) for e in self._const_list())
+            comm = False
+            if self.accept("with"):
+                self.expect("communication")
+                comm = True
+            if key == "ghostLayers":
+                d.ghost, d.ghost_comm = vals, comm
+            elif key == "duplicateLayers":
+                d.dup, d.dup_comm = vals, comm
+            else:
+                raise Exa4Unsupported("layout option %r" % key)
+        self.layouts.append(d)
+
+    def _field(self):
+        self.expect("Field")
+        name = self.ident()
+        self.expect("<")
+        dom = self.ident()
+        self.expect(",")
+        lay = self.ident()
+        self.expect(",")
+        bc = None
+        if self.at("None"):
+            self.next()
+        else:
+            bc = self.expr(no_rel=True)
+        self.expect(">")
+        slots = 1
+        if self.accept("["):
+            slots = int(self.next().text)
+            self.expect("]")
+        self.fields.append(FieldDecl(name, dom, lay, bc, slots, self.decl_levels()))
+
+    def _stencil(self):
+        self.expect("Stencil")
+        name = self.ident()
+        if self.accept("from"):
+            self.expect("default")
+            kind = self.ident()
+            self.expect("on")
+            loc = self.ident()
+            self.expect("with")
+            interp = self.next().text.strip("\"'")
+            if kind not in ("restriction", "prolongation") or loc != "Node" or interp != "linear":
+                raise Exa4Unsupported("default %s on %s with %r" % (kind, loc, interp))
+            self.stencils.append(StencilDecl(name, None, [], kind))
+            return
+        levels = self.decl_levels()
+        d = StencilDecl(name, levels)
+        self.expect("{")
+        mapped = []
+        while not self.accept("}"):
+            lhs = self._const_list()
+            if self.accept("=>"):
+                off = tuple(int(_const_value(e)) for e in lhs)
+                d.entries.append((off, self.expr()))
+            else:
+                self.expect("from")
+                src = self._const_list()
+                self.expect("with")
+                mapped.append((src, self.expr()))
+            self.accept(",")
+        if mapped:
+            d.transfer = _classify_transfer(mapped)
+        self.stencils.append(d)
+
+    def _stencil_field(self):
+        self.expect("StencilField")
+        name = self.ident()
+        self.expect("<")
+        f = self.ident()
+        self.expect("=>")
+        s = self.ident()
+        self.expect(">")
+        self.sfields.append(StencilFieldDecl(name, f, s, self.decl_levels()))
+
+    def _globals(self):
+        self.expect("Globals")
+        self.expect("{")
+        while not self.accept("}"):
+            self.next()                    # Var | Val
+            name = self.ident()
+            self.expect(":")
+            self._datatype()
+            val = self.expr() if self.accept("=") else ("num", 0.0)
+            self.globals.append((name, val))
+
+    def _datatype(self):
+        self.ident()
+        if self.at("<") and self.peek(1).kind == "id":    # Vector<Real, 3>
+            depth = 0
+            while True:
+                t = self.next()
+                depth += t.text == "<"
+                depth -= t.text == ">"
+                if depth == 0:
+                    break
+
+    def _function(self):
+        self.accept("noinline")
+        self.next()
+        name = self.ident()
+        levels = self.decl_levels()
+        params = []
+        if self.accept("("):
+            while not self.accept(")"):
+                params.append(self.ident())
+                self.expect(":")
+                self._datatype()
+                self.accept(",")
+        if self.accept(":"):
+            self._datatype()
+        self.functions.append(FunctionDecl(name, levels, params, self.block()))
+
+    # -- levels -----------------------------------------------------------------------------------------------------
+    def decl_levels(self):
+        if not self.at("@"):
+            return None
+        self.next()
+        return self._level_item()
+
+    def _level_item(self):
+        if self.accept("("):
+            spec = self._level_list()
+            self.expect(")")
+            return spec
+        return self._level_atom()
+
+    def _level_atom(self):
+        t = self.next()
+        if t.kind == "num":
+            return ("single", int(t.text), 0)
+        if t.text == "all":
+            return ("all",)
+        if t.text in _LEVEL_WORDS:
+            return ("single", t.text, 0)
+        raise Exa4SyntaxError("line %d: %r is not a level" % (t.line, t.text))
+
+    def _level_single(self):
+        if self.accept("("):
+            spec = self._level_list()
+            self.expect(")")
+        else:
+            spec = self._level_atom()
+        while self.at("+") or self.at("-"):
+            sign = 1 if self.next().text == "+" else -1
+            delta = sign * int(self.next().text)
+            if spec[0] != "single":
+                raise Exa4SyntaxError("level arithmetic on a level list")
+            spec = ("single", spec[1], spec[2] + delta)
+        return spec
+
+    def _level_list(self):
+        items = [self._level_range()]
+        while self.at(",") or self.at("and"):
+            self.next()
+            items.append(self._level_range())
+        spec = items[0] if len(items) == 1 else ("list", items)
+        if self.accept("but"):
+            spec = ("but", spec, self._level_list())
+        return spec
+
+    def _level_range(self):
+        a = self._level_single()
+        if self.accept("to"):
+            return ("range", a, self._level_single())
+        return a
+
+    # -- statements -------------------------------------------------------------------------------------------------
+    def block(self) -> list:
+        self.expect("{")
+        out = []
+        while not self.accept("}"):
+            out.append(self.stmt())
+        return out
+
+    def stmt(self):
+        t = self.peek()
+        w = t.text
+        if t.kind == "id":
+            if w in ("Var", "Val", "Variable", "Value"):
+                self.next()
+                name = self.ident()
+                self.expect(":")
+                self._datatype()
+                init = self.expr() if self.accept("=") else None
+                return ("decl", name, init)
+            if w == "loop":
+                return self._loop()
+            if w in ("communicate", "begin", "finish"):
+                phase = "sync"
+                if w != "communicate":
+                    phase = self.next().text
+                self.expect("communicate")
+                what = "all"
+                if (self.at("ghost") or self.at("dup") or self.at("all")) and self.at("of", 1):
+                    what = self.next().text
+                    self.next()
+                target = self.postfix()
+                if self.accept("where"):      # conditional exchange (Testing/Smoothers/RBGS.exa4:126): same values, full exchange
+                    self.expr()
+                return ("comm", phase, what, target)
+            if w == "apply":
+                self.next()
+                self.expect("bc")
+                self.expect("to")
+                return ("applybc", self.postfix())
+            if w == "advance":
+                self.next()
+                return ("advance", self.postfix())
+            if w == "repeat":
+                self.next()
+                if self.accept("until"):
+                    cond = self.expr()
+                    return ("until", cond, self.block())
+                n = self.expr()
+                self.expect("times")
+                counter = None
+                if self.accept("count"):
+                    counter = self.ident()
+                if self.at("with"):
+                    raise Exa4Unsupported("line %d: repeat ... with contraction" % t.line)
+                return ("repeat", n, counter, self.block())
+            if w == "if":
+                self.next()
+                cond = self.expr()
+                then = self.block()
+                other = []
+                if self.accept("else"):
+                    other = [self.stmt()] if self.at("if") else self.block()
+                return ("if", cond, then, other)
+            if w == "color":
+                self.next()
+                self.expect("with")
+                self.expect("{")
+                colours = []
+                while True:
+                    colours.append(self.expr())
+                    self.expect(",")
+                    if self.peek().text in _STMT_WORDS:
+                        break
+                body = []
+                while not self.accept("}"):
+                    body.append(self.stmt())
+                return ("color", colours, body)
+            if w == "return":
+                line = self.next().line
+                if self.peek().line == line and not self.at("}"):
+                    return ("return", self.expr())
+                return ("return", None)
+        if w == "@":
+            self.next()
+            spec = self._level_item()
+            return ("levelscope", spec, self.block())
+        lhs = self.postfix()
+        for op in ("=", "+=", "-=", "*=", "/="):
+            if self.at(op):
+                self.next()
+                return ("assign", op, lhs, self.expr())
+        if lhs[0] == "call":
+            return ("callstmt", lhs)
+        raise Exa4SyntaxError("line %d: statement starting with %r not understood" % (t.line, w))
+
+    def _loop(self):
+        self.expect("loop")
+        self.expect("over")
+        target = self.postfix()
+        only = None
+        if self.accept("only"):
+            region = self.ident()
+            direction = tuple(int(_const_value(e)) for e in self._const_list())
+            self.expect("on")
+            self.expect("boundary")
+            only = (region, direction)
+        if self.at("starting") or self.at("ending") or self.at("stepping") or self.at("sequentially"):
+            raise Exa4Unsupported("line %d: loop modifier %r" % (self.peek().line, self.peek().text))
+        where = self.expr() if self.accept("where") else None
+        reduction = None
+        if self.accept("with"):
+            self.expect("reduction")
+            self.expect("(")
+            op = self.next().text
+            self.expect(":")
+            reduction = (op, self.ident())
+            self.expect(")")
+        return ("loop", target, only, where, reduction, self.block())
+
+    # -- expressions ------------------------------------------------------------------------------------------------
+    def expr(self, no_rel: bool = False):
+        return self._or(no_rel)
+
+    def _or(self, nr):
+        a = self._and(nr)
+        while self.at("||"):
+            self.next()
+            a = ("bin", "||", a, self._and(nr))
+        return a
+
+    def _and(self, nr):
+        a = self._cmp(nr)
+        while self.at("&&"):
+            self.next()
+            a = ("bin", "&&", a, self._cmp(nr))
+        return a
+
+    def _cmp(self, nr):
+        a = self._add()
+        while not nr and self.peek().text in ("==", "!=", "<", "<=", ">", ">=") and self.peek().kind == "op":
+            op = self.next().text
+            a = ("bin", op, a, self._add())
+        return a
+
+    def _add(self):
+        a = self._mul()
+        while (self.at("+") or self.at("-")):
+            op = self.next().text
+            a = ("bin", op, a, self._mul())
+        return a
+
+    def _mul(self):
+        a = self._unary()
+        while self.at("*") or self.at("/") or self.at("%"):
+            op = self.next().text
+            a = ("bin", op, a, self._unary())
+        return a
+
+    def _unary(self):
+        if self.at("-"):
+            self.next()
+            if self.peek().kind == "num" and not self.at("**", 1):
+                t = self.next()
+                return _num(t.text, -1)
+            return ("neg", self._unary())
+        if self.at("+"):
+            self.next()
+            return self._unary()
+        if self.at("!"):
+            self.next()
+            return ("not", self._unary())
+        return self._pow()
+
+    def _pow(self):
+        a = self.postfix()
+        if self.at("**"):
+            self.next()
+            return ("bin", "**", a, self._unary())
+        return a
+
+    def postfix(self):
+        t = self.next()
+        if t.kind == "num":
+            return _num(t.text, 1)
+        if t.kind == "str":
+            return ("str", t.text[1:-1])
+        if t.text == "(":
+            e = self.expr()
+            self.expect(")")
+            return e
+        if t.kind != "id":
+            raise Exa4SyntaxError("line %d: unexpected %r in an expression" % (t.line, t.text))
+        name = t.text
+        if name in ("true", "false"):
+            return ("num", name == "true")
+        slot = None
+        if name in self.field_names and self.at("<") and self.at(">", 2) and (
+                self.peek(1).kind == "num" or self.peek(1).text in _SLOT_WORDS):
+            self.next()
+            s = self.next()
+            slot = int(s.text) if s.kind == "num" else s.text
+            self.next()
+        level = None
+        if self.at("@") and not self.at("[", 1):
+            self.next()
+            level = self._level_item()
+        if self.at("@") and self.at("[", 1):
+            raise Exa4Unsupported("line %d: offset access %s@[...]" % (t.line, name))
+        if name in self.field_names:
+            return ("fld", name, slot, level)
+        if name in self.stencil_names or name in self.sfield_names:
+            if self.at(":") and self.at("[", 1):
+                self.next()
+                off = tuple(int(_const_value(e)) for e in self._const_list())
+                return ("sentry", name, level, off)
+            return ("sten", name, level)
+        if self.at("("):
+            self.next()
+            args = []
+            while not self.accept(")"):
+                args.append(self.expr())
+                self.accept(",")
+            return ("call", name, level, args)
+        return ("id", name, level)
+
+
+def _num(text: str, sign: int):
+    if re.fullmatch(r"\d+", text):
+        return ("num", sign * int(text))
+    return ("num", sign * float(text))
+
+
+def _const_value(e, env: Optional[Dict[str, float]] = None):
+    """Value of an expression over literals (and the names in env)."""
+    k = e[0]
+    if k == "num":
+        return e[1]
+    if k == "neg":
+        return -_const_value(e[1], env)
+    if k == "id" and env is not None and e[1] in env:
+        return env[e[1]]
+    if k == "bin":
+        return _arith(e[1], _const_value(e[2], env), _const_value(e[3], env))
+    raise Exa4SyntaxError("constant expected, found %r" % (e,))
+
+
+def _arith(op: str, a, b):
+    if op == "+":
+        return a + b
+    if op == "-":
+        return a - b
+    if op == "*":
+        return a * b
+    if op == "/":
+        if isinstance(a, int) and isinstance(b, int) and not isinstance(a, bool):
+            q = abs(a) // abs(b)          # C integer division truncates towards zero
+            return q if (a >= 0) == (b >= 0) else -q
+        try:
+            return a / b
+        except ZeroDivisionError:       # IEEE semantics of the generated C++
+            return float("nan") if a == 0 or a != a else math.copysign(float("inf"), a)
+    if op == "%":
+        return math.fmod(a, b) if isinstance(a, float) or isinstance(b, float) else int(math.fmod(a, b))
+    if op == "**":
+        return a ** b if not (isinstance(b, float) and b == 2.0) else a ** 2
+    if op == "==":
+        return a == b
+    if op == "!=":
+        return a != b
+    if op == "<":
+        return a < b
+    if op == "<=":
+        return a <= b
+    if op == ">":
+        return a > b
+    if op == ">=":
+        return a >= b
+    if op == "&&":
+        return bool(a) and bool(b)
+    if op == "||":
+        return bool(a) or bool(b)
+    raise Exa4SyntaxError("operator %r" % op)
+
+
+def _classify_transfer(mapped) -> str:
+    """`[i0, i1] from [2.0 * i0 - 1.0, ...] with w` entries: which inter-grid operator, and is it the linear one?"""
+    env = {"i0": 0.0, "i1": 0.0, "i2": 0.0}
+    offs = [tuple(float(_const_value(e, env)) for e in src) for src, _ in mapped]
+    weights = [float(_const_value(w)) for _, w in mapped]
+    prolong = any(abs(o) == 0.5 for off in offs for o in off)
+    nd = len(offs[0])
+    if len(offs) != 3 ** nd:
+        raise Exa4Unsupported("inter-grid stencil with %d entries in %dD" % (len(offs), nd))
+    for off, w in zip(offs, weights):
+        want = 1.0
+        for o in off:
+            far = (abs(o) == 0.5) if prolong else (abs(o) == 1.0)
+            want *= (0.5 if far else 1.0) if prolong else (0.25 if far else 0.5)
+        if abs(w - want) > 1e-15:
+            raise Exa4Unsupported("inter-grid stencil is not the linear %s" % ("prolongation" if prolong else "restriction"))
+    return "prolongation" if prolong else "restriction"
+
+
+# =====================================================================================================================
+# analytic point functions: python mirror of eval_fn (exastencils_amd/csrc/examg_common.h), used for recognition only
+# =====================================================================================================================
+def fn_eval(fn: int, p: Sequence[float], x: float, y: float, z: float) -> float:
+    PI = math.pi
+    k = p[0] if p else 0.0
+    if fn == 0:
+        return 0.0
+    if fn == 1:
+        return ((x * x) - ((0.5 * y) * y)) - ((0.5 * z) * z)
+    if fn == 2:
+        return math.cos(PI * x) - math.sin((2.0 * PI) * y)
+    if fn == 3:
+        return (PI * PI) * math.cos(PI * x) - ((4.0 * (PI * PI)) * math.sin((2.0 * PI) * y))
+    if fn == 4:
+        return k * (((x - (x * x)) * (y - (y * y))) * (z - (z * z)))
+    if fn == 5:
+        return (2.0 * k) * ((((x - (x * x)) * (y - (y * y))) + ((x - (x * x)) * (z - (z * z)))) + ((y - (y * y)) * (z - (z * z))))
+    if fn == 6:
+        return 1.0 - math.exp((-1.0 * k) * (((x - (x * x)) * (y - (y * y))) * (z - (z * z))))
+    if fn == 7:
+        return math.exp(k * (((x - (x * x)) * (y - (y * y))) * (z - (z * z))))
+    if fn == 8:
+        return (math.sin(PI * x) * math.sin(PI * y)) * math.sinh((math.sqrt(2.0) * PI) * z)
+    if fn == 9:
+        return (math.sin(PI * x) * math.sin(PI * y)) * math.sin(PI * z)
+    if fn == 10:
+        return k * ((x - (x * x)) * (y - (y * y)))
+    if fn == 11:
+        return (2.0 * k) * ((x - (x * x)) + (y - (y * y)))
+    if fn == 12:
+        return 1.0 - math.exp((-1.0 * k) * ((x - (x * x)) * (y - (y * y))))
+    if fn == 13:
+        return math.exp(k * ((x - (x * x)) * (y - (y * y))))
+    raise ValueError("function id %d" % fn)
+
+
+_FN_WITH_PARAM = {4, 5, 6, 7, 10, 11, 12, 13}
+_FN_2D_ONLY = {2, 3, 10, 11, 12, 13}     # ignore z
+_N_FN = 14
+
+
+# =====================================================================================================================
+# interpreter
+# =====================================================================================================================
+class _Return(Exception):
+    def __init__(self, value):
+        self.value = value
+
+
+@dataclass
+class _Frame:
+    level: Optional[int]
+    vars: Dict[str, object]
+    colour: Optional[int] = None
+
+
+class Exa4Program:
+    """One ExaSlang-4 program bound to a kernel layer (`ops`: HipOps on the GPU), a block decomposition and a
+    communicator.  `run()` executes `Function Application`; printed lines are collected in `self.out`."""
+
+    def __init__(self, text: str, knowledge: Optional[Dict] = None, ops=None, domain: Optional[RectDomain] = None, comm=None,
+                 echo: bool = False, fuse: bool = True):
+        """fuse: run red-black sweeps and pairs of slotted Jacobi steps as single passes over HBM where the program's
+        statements allow it (bit-identical results; `fuse=False` issues exactly one launch per loop statement)."""
+        self.ast = Parser(text).parse()
+        self.k = dict(knowledge or {})
+        d = _knowledge.derive(self.k)
+        self.nd = d["dimensionality"]
+        self.min_level, self.max_level = d["min_level"], d["max_level"]
+        if ops is None:
+            from .ops import HipOps
+
+            ops = HipOps()              # raises without libexamg.so / GPU: no fallback
+        self.ops = ops
+        lo, hi = (0.0,) * 3, (1.0,) * 3
+        if self.ast.domain:
+            lo = tuple(float(_const_value(e)) for e in self.ast.domain[1]) + (0.0,) * (3 - self.nd)
+            hi = tuple(float(_const_value(e)) for e in self.ast.domain[2]) + (1.0,) * (3 - self.nd)
+        if domain is None:
+            # one process: the reference's blocks x fragments become one fragment of the same global grid
+            flen = tuple(d["frags_total"][i] * d["frag_len"][i] for i in range(3))
+            domain = RectDomain(self.nd, (1, 1, 1), 0, flen, lo[:3], hi[:3])
+        self.domain = domain
+        self.comm = comm or Communicator(domain, ops)
+        self.echo = echo
+        self.out: List[str] = []
+        self.printed_values: List[float] = []     # every Real handed to print / printWithReducedPrec, unrounded
+        self.timers: Dict[str, float] = {}
+        self._timer_start: Dict[str, float] = {}
+        self.launches = 0
+        self._precision = 6
+        self.globals: Dict[str, object] = {}
+        self.fields: Dict[Tuple[str, int], Field] = {}
+        self.stencils: Dict[Tuple[str, int], Stencil] = {}
+        self.transfer: Dict[str, str] = {}
+        self._fn_cache: Dict[Tuple[str, Optional[int]], Tuple[int, Tuple[float, ...]]] = {}
+        self._rng = random.Random(20240229)
+        self.fuse = fuse
+        self.fuse_min_row = 64      # rows shorter than one wavefront's tile stay on the per-colour kernels
+        self._alt: Dict[Tuple[str, int, int], object] = {}
+        self._alt_shell: Dict[Tuple[str, int, int], int] = {}
+        self._bc_epoch: Dict[Tuple[str, int], int] = {}
+        self._pair_tmp: Dict[Tuple[str, int], Field] = {}
+        self._bc_valid = set()      # (field, level, slot) whose physical-boundary planes hold the field's Dirichlet values
+        self._declare()
+
+    # -- declarations -> objects --------------------------------------------------------------------------------------
+    def levels_of(self, spec, cur: Optional[int] = None) -> List[int]:
+        lo, hi = self.min_level, self.max_level
+        if spec is None or spec[0] == "all":
+            return list(range(lo, hi + 1))
+        k = spec[0]
+        if k == "single":
+            base = spec[1]
+            if isinstance(base, str):
+                if base in ("current", "coarser", "finer") and cur is None:
+                    raise Exa4SyntaxError("@%s outside a leveled function" % base)
+                base = {"current": cur, "coarser": None if cur is None else cur - 1, "finer": None if cur is None else cur + 1,
+                        "finest": hi, "coarsest": lo}[base]
+            return [base + spec[2]]
+        if k == "range":
+            a, b = self.levels_of(spec[1], cur)[0], self.levels_of(spec[2], cur)[0]
+            return list(range(min(a, b), max(a, b) + 1))
+        if k == "list":
+            out = []
+            for s in spec[1]:
+                out += self.levels_of(s, cur)
+            return sorted(set(out))
+        if k == "but":
+            drop = set(self.levels_of(spec[2], cur))
+            return [l for l in self.levels_of(spec[1], cur) if l not in drop]
+        raise Exa4SyntaxError("level specification %r" % (spec,))
+
+    def _declare(self):
+        a, nd, dom = self.ast, self.nd, self.domain
+        self.functions: Dict[str, List[FunctionDecl]] = {}
+        for fn in a.functions:
+            self.functions.setdefault(fn.name, []).append(fn)
+        for name, e in a.globals:
+            self.globals[name] = self._eval(e, _Frame(None, {}))
+        layouts = {l.name: l for l in a.layouts}
+        nslots: Dict[str, int] = {}
+        for fd in a.fields:
+            nslots[fd.name] = max(nslots.get(fd.name, 1), fd.slots)
+        self._sfield_of = {}
+        sfield_fields = {s.field for s in a.sfields}
+        for fd in a.fields:
+            ld = layouts.get(fd.layout)
+            if ld is None:
+                raise Exa4SyntaxError("field %s uses the undeclared layout %s" % (fd.name, fd.layout))
+            if ld.localization != "Node":
+                raise Exa4Unsupported("layout %s: localization %s (node fields only)" % (ld.name, ld.localization))
+            if ld.vec_len != 1 and fd.name not in sfield_fields:
+                raise Exa4Unsupported("vector-valued field %s outside a StencilField" % fd.name)
+            for lvl in self.levels_of(fd.levels):
+                if (fd.name, lvl) in self.fields or not (self.min_level <= lvl <= self.max_level):
+                    continue
+                nc = dom.ncells(lvl)
+                ghost = tuple(ld.ghost[i] if i < nd and i < len(ld.ghost) else 0 for i in range(3))
+                dup = tuple((ld.dup[i] if i < len(ld.dup) else 1) if i < nd else 0 for i in range(3))
+                if any(dup[i] != 1 for i in range(nd)):
+                    raise Exa4Unsupported("layout %s: node fields need one duplicate layer" % ld.name)
+                inner = tuple(nc[i] - 1 if i < nd else 1 for i in range(3))
+                lay = FieldLayout(nd, inner, ghost, dup, (0, 0, 0), (0, 0, 0), ld.dup_comm, ld.ghost_comm)
+                bc_fn, bc_par = None, ()
+                if fd.bc is not None:
+                    bc_fn, bc_par = self._recognise(fd.bc, lvl)
+                if ld.vec_len != 1:
+                    f = Field.__new__(Field)     # coefficient planes: allocated by the stencil field below
+                    f.name, f.level, f.layout, f.num_slots, f.bc_fn, f.bc_params = fd.name, lvl, lay, 1, None, ()
+                    f.lc, f.slots, f.current_slot, f.vec_len = lay.c_struct(), [self.ops.new_array(ld.vec_len * lay.size)], 0, ld.vec_len
+                else:
+                    f = Field(fd.name, lvl, lay, self.ops, nslots[fd.name], bc_fn, bc_par)
+                self.fields[(fd.name, lvl)] = f
+        for sd in a.stencils:
+            if sd.transfer:
+                self.transfer[sd.name] = sd.transfer
+        self._stencil_decls = {s.name: s for s in a.stencils if not s.transfer}
+        for sf in a.sfields:
+            sd = self._stencil_decls.get(sf.stencil)
+            if sd is None:
+                raise Exa4SyntaxError("stencil field %s: stencil %s is not declared" % (sf.name, sf.stencil))
+            for lvl in self.levels_of(sf.levels):
+                cf = self.fields.get((sf.field, lvl))
+                if cf is None:
+                    continue
+                offs = [tuple(o) + (0,) * (3 - len(o)) for o, _ in sd.entries]
+                if getattr(cf, "vec_len", 1) != len(offs):
+                    raise Exa4SyntaxError("stencil field %s: %d entries but %d coefficients per point" % (sf.name, len(offs), getattr(cf, "vec_len", 1)))
+                self.stencils[(sf.name, lvl)] = Stencil(offs, [], cf.slots[0], cf.layout)
+
+    def stencil(self, name: str, lvl: int) -> Stencil:
+        s = self.stencils.get((name, lvl))
+        if s is None:
+            sd = self._stencil_decls.get(name)
+            if sd is None:
+                raise Exa4SyntaxError("stencil %s is not declared" % name)
+            if lvl not in self.levels_of(sd.levels):
+                raise Exa4SyntaxError("stencil %s is not declared on level %d" % (name, lvl))
+            fr = _Frame(lvl, {})
+            offs = [tuple(o) + (0,) * (3 - len(o)) for o, _ in sd.entries]
+            s = self.stencils[(name, lvl)] = Stencil(offs, [float(self._eval(e, fr)) for _, e in sd.entries])
+        return s
+
+    # -- analytic function recognition ----------------------------------------------------------------------------------
+    def _point_eval(self, e, lvl: Optional[int], x: float, y: float, z: float):
+        fr = _Frame(lvl, {"__x": x, "__y": y, "__z": z})
+        return float(self._eval(e, fr))
+
+    def _recognise(self, e, lvl: Optional[int]) -> Tuple[int, Tuple[float, ...]]:
+        """Function id and parameters of include/examg.h that reproduce the point expression `e`."""
+        key = (repr(e), lvl)
+        if key in self._fn_cache:
+            return self._fn_cache[key]
+        pts = [(self._rng.uniform(0.05, 0.95), self._rng.uniform(0.05, 0.95), self._rng.uniform(0.05, 0.95)) for _ in range(12)]
+        vals = [self._point_eval(e, lvl, *p) for p in pts]
+        cands = [float(v) for v in self.globals.values() if isinstance(v, (int, float)) and not isinstance(v, bool)]
+        for fn in range(_N_FN):
+            if (fn in _FN_2D_ONLY) != (self.nd == 2) and fn != 0:
+                continue
+            for par in (cands if fn in _FN_WITH_PARAM else [None]):
+                p = (par,) if par is not None else ()
+                if all(abs(fn_eval(fn, p, *pt) - v) <= 1e-12 * max(1.0, abs(v)) for pt, v in zip(pts, vals)):
+                    self._fn_cache[key] = (fn, p)
+                    return fn, p
+        raise Exa4Unsupported("analytic expression is none of the built-in point functions (include/examg.h EXAMG_FN_*)")
+
+    # -- expression evaluation (host scalars) ---------------------------------------------------------------------------
+    def _level_of(self, spec, fr: _Frame) -> int:
+        if spec is None:
+            if fr.level is None:
+                raise Exa4SyntaxError("leveled access without level outside a leveled function")
+            return fr.level
+        lv = self.levels_of(spec, fr.level)
+        if len(lv) != 1:
+            raise Exa4SyntaxError("access needs a single level")
+        return lv[0]
+
+    def _eval(self, e, fr: _Frame):
+        k = e[0]
+        if k == "num" or k == "str":
+            return e[1]
+        if k == "neg":
+            return -self._eval(e[1], fr)
+        if k == "not":
+            return not self._eval(e[1], fr)
+        if k == "bin":
+            return _arith(e[1], self._eval(e[2], fr), self._eval(e[3], fr))
+        if k == "id":
+            name = e[1]
+            if name in fr.vars:
+                return fr.vars[name]
+            if name in self.globals:
+                return self.globals[name]
+            if name == "PI":
+                return math.pi
+            m = _GRIDW.match(name)
+            if m:
+                return self.domain.h(self._level_of(e[2], fr))["xyz".index(m.group(1))]
+            m = _COORD.match(name)
+            if m:
+                v = fr.vars.get("__" + m.group(2))
+                if v is None:
+                    raise Exa4Unsupported("%s outside a point expression" % name)
+                return v
+            raise Exa4SyntaxError("unknown name %r" % name)
+        if k == "call":
+            return self._call(e, fr)
+        if k in ("fld", "sten", "sentry"):
+            raise Exa4Unsupported("field / stencil access %s outside a recognised loop body" % e[1])
+        raise Exa4SyntaxError("expression %r" % (e,))
+
+    def _call(self, e, fr: _Frame):
+        name, lspec, args = e[1], e[2], e[3]
+        if name == "diag":
+            a = args[0]
+            if a[0] != "sten":
+                raise Exa4Unsupported("diag of a non-stencil")
+            st = self.stencil(a[1], self._level_of(a[2], fr))
+            if st.cfield is not None:
+                raise Exa4Unsupported("diag of a stencil field outside the smoother form ((1.0 / diag(A)) * omega)")
+            return st.diag
+        if name in _MATH and name not in self.functions:
+            return _MATH[name](*[self._eval(a, fr) for a in args])
+        if name == "getKnowledge":
+            key = self._eval(args[0], fr)
+            return self.k.get(key, {"testing_enabled": False, "testing_printRes": True, "testing_printErr": True}.get(key, False))
+        if name in self.functions:
+            lvl = None
+            if lspec is not None:
+                lvl = self._level_of(lspec, fr)
+            return self.call(name, lvl if lvl is not None else fr.level, [self._eval(a, fr) for a in args], fr)
+        return self._builtin(name, [self._eval(a, fr) for a in args], fr)
+
+    # -- built-in statements ----------------------------------------------------------------------------------------------
+    def _emit(self, line: str):
+        self.out.append(line)
+        if self.echo and self.domain.rank == 0:
+            print(line, flush=True)
+
+    def _fmt(self, v) -> str:
+        if isinstance(v, bool):
+            return "true" if v else "false"
+        if isinstance(v, float):
+            return "%.*g" % (self._precision, v)
+        return str(v)
+
+    def _builtin(self, name: str, args: list, fr: _Frame):
+        from .solver import reduced_prec
+
+        if name == "print":
+            self.printed_values += [a for a in args if isinstance(a, float)]
+            self._emit(" ".join(self._fmt(a) for a in args))
+        elif name == "printWithReducedPrec":
+            self.printed_values.append(float(args[0]))
+            self._emit(reduced_prec(float(args[0])))
+        elif name == "native":
+            m = re.search(r"cout\.precision\((\w+)\)", str(args[0]))
+            if m and "oldPrec =" not in str(args[0]):
+                self._precision = int(m.group(1)) if m.group(1).isdigit() else 6
+        elif name == "startTimer":
+            self.ops.synchronize()
+            self._timer_start[args[0]] = time.perf_counter()
+        elif name == "stopTimer":
+            self.ops.synchronize()
+            self.timers[args[0]] = self.timers.get(args[0], 0.0) + time.perf_counter() - self._timer_start.pop(args[0])
+        elif name == "printAllTimers":
+            for key, val in self.timers.items():
+                self._emit("Mean mean total time for Timer %s: %g" % (key, val * 1e3))
+        elif name == "getTotalTime" or name == "getTotalFromTimer":
+            return self.timers.get(args[0], 0.0) * 1e3
+        elif name in ("initGlobals", "initDomain", "initGeometry", "destroyGlobals", "initFieldsWithZero"):
+            pass        # fields are allocated zeroed at declaration (initFieldsWithZero)
+        else:
+            raise Exa4Unsupported("function %s" % name)
+        return None
+
+    # -- functions ------------------------------------------------------------------------------------------------------
+    def _resolve(self, name: str, lvl: Optional[int]) -> FunctionDecl:
+        for fn in self.functions[name]:
+            if fn.levels is None:
+                return fn
+            if lvl is not None and lvl in self.levels_of(fn.levels):
+                return fn
+        raise Exa4SyntaxError("function %s is not declared on level %r" % (name, lvl))
+
+    def call(self, name: str, lvl: Optional[int] = None, args: Sequence = (), caller: Optional[_Frame] = None):
+        fn = self._resolve(name, lvl)
+        fr = _Frame(lvl if fn.levels is not None else None, dict(zip(fn.params, args)))
+        if caller is not None and "__x" in caller.vars:      # point expression: coordinates stay visible in callees
+            for c in ("__x", "__y", "__z"):
+                fr.vars.setdefault(c, caller.vars[c])
+        try:
+            self._exec_block(fn.body, fr)
+        except _Return as r:
+            return r.value
+        return None
+
+    def run(self, name: str = "Application"):
+        self.call(name)
+        return self.out
+
+    # -- statements -----------------------------------------------------------------------------------------------------
+    def _exec_block(self, body: list, fr: _Frame):
+        i = 0
+        while i < len(body):
+            self._exec(body[i], fr)
+            i += 1
+
+    def _field(self, e, fr: _Frame) -> Tuple[Field, int]:
+        if e[0] != "fld":
+            raise Exa4SyntaxError("field access expected, found %r" % (e,))
+        lvl = self._level_of(e[3], fr)
+        f = self.fields.get((e[1], lvl))
+        if f is None:
+            raise Exa4SyntaxError("field %s is not declared on level %d" % (e[1], lvl))
+        s = e[2]
+        if s is None or s in ("active", "activeSlot", "current", "currentSlot"):
+            slot = f.active
+        elif s in ("next", "nextSlot"):
+            slot = f.next
+        elif s in ("previous", "previousSlot"):
+            slot = (f.current_slot - 1) % f.num_slots
+        else:
+            slot = int(s) % f.num_slots
+        return f, slot
+
+    def _exec(self, s, fr: _Frame):
+        k = s[0]
+        if k == "decl":
+            fr.vars[s[1]] = self._eval(s[2], fr) if s[2] is not None else 0
+        elif k == "assign":
+            op, lhs, rhs = s[1], s[2], s[3]
+            if lhs[0] != "id":
+                raise Exa4Unsupported("assignment to %s outside a loop" % lhs[0])
+            v = self._eval(rhs, fr)
+            tgt = fr.vars if lhs[1] in fr.vars or lhs[1] not in self.globals else self.globals
+            tgt[lhs[1]] = v if op == "=" else _arith(op[0], tgt[lhs[1]], v)
+        elif k == "callstmt":
+            self._call(s[1], fr)
+        elif k == "loop":
+            self._exec_loop(s, fr)
+        elif k == "comm":
+            if s[1] == "finish":
+                return
+            f, slot = self._field(s[3], fr)
+            self.comm.exchange(f, slot, s[2])
+        elif k == "applybc":
+            f, slot = self._field(s[1], fr)
+            self._apply_bc(f, slot)
+        elif k == "advance":
+            f, _ = self._field(s[1], fr)
+            f.advance()
+        elif k == "repeat":
+            n = int(self._eval(s[1], fr))
+            if self.fuse and s[2] is None and n >= 2 and self._try_jacobi_pairs(s[3], n, fr):
+                return
+            for it in range(n):
+                if s[2]:
+                    fr.vars[s[2]] = it
+                self._exec_block(s[3], fr)
+            if s[2]:
+                fr.vars[s[2]] = n
+        elif k == "until":
+            while not self._eval(s[1], fr):
+                self._exec_block(s[2], fr)
+        elif k == "if":
+            self._exec_block(s[2] if self._eval(s[1], fr) else s[3], fr)
+        elif k == "color":
+            if len(s[1]) != 1:
+                raise Exa4Unsupported("color with more than one colour expression")
+            shift = _parity_expr(s[1][0], self.nd)
+            if shift is None:
+                raise Exa4Unsupported("colour expression other than (i0 + i1 [+ i2]) % 2")
+            if self.fuse and self._try_fused_sweep(s[2], (0 - shift) % 2, fr):
+                return
+            saved = fr.colour
+            for c in (0, 1):
+                fr.colour = (c - shift) % 2
+                self._exec_block(s[2], fr)
+            fr.colour = saved
+        elif k == "levelscope":
+            if fr.level in self.levels_of(s[1], fr.level):
+                self._exec_block(s[2], fr)
+        elif k == "return":
+            raise _Return(self._eval(s[1], fr) if s[1] is not None else None)
+        else:
+            raise Exa4SyntaxError("statement %r" % (k,))
+
+    # -- peepholes: same results bit for bit, fewer passes over HBM ---------------------------------------------------------
+    def _match_smoother(self, st, fr: _Frame):
+        """(D, dslot, U, uslot, F, fslot, A, w) if `st` is a damped-residual update  D = U + w * (F - A * U)."""
+        if st[0] != "assign" or st[2][0] != "fld":
+            return None
+        op, lhs, rhs = st[1], st[2], st[3]
+        src = wexpr = r = None
+        if op == "+=" and rhs[0] == "bin" and rhs[1] == "*":
+            src, wexpr, r = lhs, rhs[2], self._residual_form(rhs[3], fr)
+        elif op == "=" and rhs[0] == "bin" and rhs[1] == "+" and rhs[2][0] == "fld" and rhs[3][0] == "bin" and rhs[3][1] == "*":
+            src, wexpr, r = rhs[2], rhs[3][2], self._residual_form(rhs[3][3], fr)
+        if r is None or not self._same_access(src, r[2], fr):
+            return None
+        D, ds = self._field(lhs, fr)
+        U, us = self._field(src, fr)
+        F, fs = self._field(r[0], fr)
+        return D, ds, U, us, F, fs, r[1], self._smoother_weight(wexpr, r[1], fr)
+
+    @staticmethod
+    def _canonical7(A: Stencil, nd: int) -> bool:
+        return nd == 3 and A.cfield is None and len(A.offsets) == 7 and all(sum(1 for c in o if c) <= 1 for o in A.offsets)
+
+    def _try_fused_sweep(self, body, first: int, fr: _Frame) -> bool:
+        """`color with { (i0+i1+i2) % 2, [communicate u] loop over u { u += w (f - A u) } [apply bc to u] }` on one block:
+        both half sweeps in one pass (examg_rbgs_sweep_fused), out of place into a second array that carries the same
+        boundary shell, then the two arrays change roles.  `apply bc` re-writes position-only Dirichlet values the sweep
+        never touches, so it is a no-op here."""
+        if self.domain.world_size != 1:
+            return False
+        loops = [st for st in body if st[0] == "loop"]
+        if len(loops) != 1 or any(st[0] not in ("loop", "comm", "applybc") for st in body):
+            return False
+        lp = loops[0]
+        if lp[2] is not None or lp[3] is not None or lp[4] is not None or len(lp[5]) != 1:
+            return False
+        m = self._match_smoother(lp[5][0], fr)
+        if m is None:
+            return False
+        D, ds, U, us, F, fs, A, w = m
+        if D is not U or ds != us or not self._canonical7(A, self.nd) or U.layout.inner[0] < self.fuse_min_row:
+            return False
+        for st in body:
+            if st[0] in ("comm", "applybc") and self._field(st[-1], fr)[0] is not U:
+                return False
+        if U.bc_fn is not None and (U.name, U.level, us) not in self._bc_valid:
+            return False        # boundary planes not known to hold the Dirichlet values yet: the plain path applies them
+        b, e = self.domain.loop_bounds(self._field(lp[1], fr)[0].layout)
+        key = (U.name, U.level, us)
+        alt = self._alt.get(key)
+        if alt is None:
+            alt = self._alt[key] = self.ops.new_array(U.layout.size)
+        if self._alt_shell.get(key) != self._bc_epoch.get((U.name, U.level), 0):
+            lay = U.layout      # the shell (everything outside the loop's box) comes from the field itself
+            gb = [lay.idx("GLB", d) if d < self.nd else 0 for d in range(3)]
+            ge = [lay.idx("GRE", d) if d < self.nd else 1 for d in range(3)]
+            self.ops.axpby(U.lc, U.data(us), U.lc, alt, 1.0, 0.0, gb, ge)
+            self._alt_shell[key] = self._bc_epoch.get((U.name, U.level), 0)
+            self.launches += 1
+        self.launches += 1
+        self.ops.rbgs_sweep_fused(U.lc, U.data(us), alt, F.lc, F.data(fs), A, w, first, b, e)
+        self._alt[key], U.slots[us] = U.slots[us], alt
+        return True
+
+    def _try_jacobi_pairs(self, body, n: int, fr: _Frame) -> bool:
+        """`repeat n times { Smoother ( ) }` with Smoother = [communicate ghost of u<active>; loop over u { u<next> =
+        u<active> + w (f - A u<active>) }; advance u]: consecutive pairs as one pass over HBM (exastencils_amd/smoothers.py)."""
+        if len(body) != 1 or body[0][0] != "callstmt":
+            return False
+        c = body[0][1]
+        if c[1] not in self.functions or c[3]:
+            return False
+        lvl = self._level_of(c[2], fr) if c[2] is not None else fr.level
+        fn = self._resolve(c[1], lvl)
+        fb = fn.body
+        if len(fb) != 3 or fb[0][0] != "comm" or fb[1][0] != "loop" or fb[2][0] != "advance":
+            return False
+        cfr = _Frame(lvl if fn.levels is not None else None, {})
+        lp = fb[1]
+        if lp[2] is not None or lp[3] is not None or lp[4] is not None or len(lp[5]) != 1:
+            return False
+        m = self._match_smoother(lp[5][0], cfr)
+        if m is None:
+            return False
+        D, ds, U, us, F, fs, A, w = m
+        if D is not U or U.num_slots != 2 or us != U.active or ds != U.next or A.cfield is not None:
+            return False
+        if self._field(fb[0][3], cfr) != (U, us) or self._field(fb[2][1], cfr)[0] is not U or self._field(lp[1], cfr)[0] is not U:
+            return False
+        # the pair reads the boundary planes of <active> in both steps; the two plain steps read those of <next> in the
+        # second: only equal when both slots are known to hold the same boundary values
+        if U.bc_fn is not None:
+            if not all((U.name, U.level, sl) in self._bc_valid for sl in range(2)):
+                return False
+        elif self._bc_epoch.get((U.name, U.level), 0) != 0:
+            return False
+        from .smoothers import jacobi_pair
+
+        key = (U.name, U.level)
+        tmp = self._pair_tmp.get(key)
+        if tmp is None:
+            tmp = self._pair_tmp[key] = Field(U.name + "Tmp", U.level, U.layout, self.ops, 1, None)
+        k = n
+        while k >= 2:
+            self.launches += 1
+            jacobi_pair(self.ops, self.comm, self.domain, U, F, A, w, tmp)
+            k -= 2
+        if k:
+            self._exec_block(body, fr)
+        return True
+
+    def _apply_bc(self, f: Field, slot: int):
+        if f.bc_fn is None:
+            return
+        self._bc_valid.add((f.name, f.level, slot))
+        mask = self.domain.face_mask()
+        if mask:
+            self.launches += 1
+            self.ops.apply_dirichlet(f.lc, f.data(slot), self.domain.geom(f.level), f.bc_fn, f.bc_params, mask)
+
+    # -- loops ----------------------------------------------------------------------------------------------------------
+    def _loop_boxes(self, f: Field, only, where, reduction, fr: _Frame):
+        """Iteration boxes of the loop and the colour its condition selects (None: all points)."""
+        dom, lay, nd = self.domain, f.layout, self.nd
+        colour = fr.colour
+        lower = [False] * 3
+        if where is not None:
+            for c in _conjuncts(where):
+                par = _colour_cond(c, nd)
+                d = _lower_cond(c)
+                if par is not None:
+                    colour = par
+                elif d is not None:
+                    lower[d] = True
+                else:
+                    raise Exa4Unsupported("loop condition other than a colour test or (i_d > 0)")
+        if only is not None:
+            region, direction = only
+            if region != "dup":
+                raise Exa4Unsupported("loop ... only %s" % region)
+            nz = [d for d in range(len(direction)) if direction[d] != 0]
+            if len(nz) != 1:
+                raise Exa4Unsupported("loop only dup: axis directions only")
+            d, side = nz[0], direction[nz[0]]
+            if dom.neighbor(d, side) is not None:
+                return [], colour
+            b, e = [0, 0, 0], [1, 1, 1]
+            for t in range(nd):
+                if t == d:
+                    b[t], e[t] = (lay.idx("DLB", t), lay.idx("DLE", t)) if side < 0 else (lay.idx("DRB", t), lay.idx("DRE", t))
+                else:
+                    b[t], e[t] = lay.idx("DLB", t), lay.idx("DRE", t)
+            return [(b, e)], colour
+        b, e = dom.loop_bounds(lay, reduction is not None)
+        for d in range(nd):
+            if lower[d]:
+                b[d] = max(b[d], 1)
+        return [(b, e)], colour
+
+    def _exec_loop(self, s, fr: _Frame):
+        _, target, only, where, reduction, body = s
+        f, _ = self._field(target, fr)
+        boxes, colour = self._loop_boxes(f, only, where, reduction, fr)
+        if reduction is not None:
+            return self._exec_reduction(f, boxes, reduction, body, fr)
+        if body and all(st[0] == "assign" and st[2][0] == "sentry" for st in body):
+            return self._exec_stencil_field_init(body, boxes, fr)
+        for st in body:
+            if st[0] != "assign":
+                raise Exa4Unsupported("statement %r inside a loop body" % st[0])
+            if only is not None and st[2][0] == "fld":      # boundary planes rewritten: second arrays of fused sweeps are stale
+                tf = self._field(st[2], fr)[0]
+                self._bc_epoch[(tf.name, tf.level)] = self._bc_epoch.get((tf.name, tf.level), 0) + 1
+                self._bc_valid -= {(tf.name, tf.level, sl) for sl in range(tf.num_slots)}
+            for b, e in boxes:
+                self._exec_point_assign(st, b, e, colour, fr)
+
+    # pattern helpers ---------------------------------------------------------------------------------------------------
+    def _is_scalar(self, e) -> bool:
+        return not _contains(e, ("fld", "sten", "sentry")) and not _has_coord(e, self.functions)
+
+    def _same_access(self, a, b, fr: _Frame) -> bool:
+        if a[0] != "fld" or b[0] != "fld":
+            return False
+        fa, sa = self._field(a, fr)
+        fb, sb = self._field(b, fr)
+        return fa is fb and sa == sb
+
+    def _sten_times_field(self, e, fr: _Frame):
+        """(scale, kind, stencil-or-name, stencil level, field expr) for `[s *] S * F`."""
+        if e[0] != "bin" or e[1] != "*" or e[3][0] != "fld":
+            return None
+        s, scale = e[2], 1.0
+        if s[0] == "bin" and s[1] == "*" and s[3][0] == "sten" and self._is_scalar(s[2]):
+            scale, s = float(self._eval(s[2], fr)), s[3]
+        if s[0] != "sten":
+            return None
+        if s[1] in self.transfer:
+            return scale, self.transfer[s[1]], s[1], None, e[3]
+        return scale, "stencil", self.stencil(s[1], self._level_of(s[2], fr)), None, e[3]
+
+    def _residual_form(self, e, fr: _Frame):
+        """(F, A, U) for `F - A * U`."""
+        if e[0] != "bin" or e[1] != "-" or e[2][0] != "fld":
+            return None
+        m = self._sten_times_field(e[3], fr)
+        if m is None or m[1] != "stencil" or m[0] != 1.0:
+            return None
+        return e[2], m[2], m[4]
+
+    def _smoother_weight(self, w, A: Stencil, fr: _Frame) -> float:
+        if A.cfield is None:
+            return float(self._eval(w, fr))
+        # stencil field: the kernel forms ((1.0 / diag) * omega) per point (Testing/SISC/3D_VarCoeff.exa4:145)
+        if (w[0] == "bin" and w[1] == "*" and w[2][0] == "bin" and w[2][1] == "/" and w[2][2] == ("num", 1.0)
+                and w[2][3][0] == "call" and w[2][3][1] == "diag" and self._is_scalar(w[3])):
+            return float(self._eval(w[3], fr))
+        raise Exa4Unsupported("smoother weight on a stencil field must read ((1.0 / diag(A)) * omega)")
+
+    def _exec_point_assign(self, st, b, e, colour, fr: _Frame):
+        op, lhs, rhs = st[1], st[2], st[3]
+        ops = self.ops
+        if lhs[0] != "fld":
+            raise Exa4Unsupported("loop body assigns to %s" % lhs[0])
+        D, ds = self._field(lhs, fr)
+        self.launches += 1
+        if op == "=":
+            if self._is_scalar(rhs):
+                return ops.set(D.lc, D.data(ds), float(self._eval(rhs, fr)), b, e)
+            if not _contains(rhs, ("fld", "sten", "sentry")):
+                fn, par = self._recognise(rhs, D.level)
+                return ops.fill_fn(D.lc, D.data(ds), self.domain.geom(D.level), fn, par, b, e)
+            if rhs[0] == "fld":
+                X, xs = self._field(rhs, fr)
+                return ops.axpby(X.lc, X.data(xs), D.lc, D.data(ds), 1.0, 0.0, b, e)
+            r = self._residual_form(rhs, fr)
+            if r is not None:
+                F, fs = self._field(r[0], fr)
+                U, us = self._field(r[2], fr)
+                return ops.stencil_op(RESIDUAL, U.lc, U.data(us), F.lc, F.data(fs), D.lc, D.data(ds), r[1], 0.0, -1, b, e)
+            m = self._sten_times_field(rhs, fr)
+            if m is not None:
+                X, xs = self._field(m[4], fr)
+                if m[1] == "restriction":
+                    if X.level != D.level + 1:
+                        raise Exa4Unsupported("restriction between levels %d and %d" % (X.level, D.level))
+                    return ops.restrict(X.lc, X.data(xs), D.lc, D.data(ds), m[0], b, e)
+                if m[1] == "stencil" and m[0] == 1.0:
+                    return ops.stencil_op(APPLY, X.lc, X.data(xs), None, None, D.lc, D.data(ds), m[2], 0.0, -1, b, e)
+            if rhs[0] == "bin" and rhs[1] == "+" and rhs[2][0] == "fld":
+                # U_src + w * (F - A * U_src)   |   G + beta * D
+                t = rhs[3]
+                if t[0] == "bin" and t[1] == "*":
+                    r = self._residual_form(t[3], fr)
+                    if r is not None and self._same_access(rhs[2], r[2], fr):
+                        return self._smooth(D, ds, rhs[2], t[2], r, b, e, colour, fr)
+                    if t[3][0] == "fld" and self._same_access(lhs, t[3], fr) and self._is_scalar(t[2]):
+                        X, xs = self._field(rhs[2], fr)
+                        return ops.axpby(X.lc, X.data(xs), D.lc, D.data(ds), 1.0, float(self._eval(t[2], fr)), b, e)
+        elif op in ("+=", "-="):
+            sign = 1.0 if op == "+=" else -1.0
+            if rhs[0] == "bin" and rhs[1] == "*":
+                if rhs[3][0] == "fld" and self._is_scalar(rhs[2]):
+                    X, xs = self._field(rhs[3], fr)
+                    return ops.axpby(X.lc, X.data(xs), D.lc, D.data(ds), sign * float(self._eval(rhs[2], fr)), 1.0, b, e)
+                r = self._residual_form(rhs[3], fr)
+                if r is not None and op == "+=" and self._same_access(lhs, r[2], fr):
+                    return self._smooth(D, ds, lhs, rhs[2], r, b, e, colour, fr)
+                m = self._sten_times_field(rhs, fr)
+                if m is not None and m[1] == "prolongation" and op == "+=" and m[0] == 1.0:
+                    X, xs = self._field(m[4], fr)
+                    if X.level != D.level - 1:
+                        raise Exa4Unsupported("prolongation between levels %d and %d" % (X.level, D.level))
+                    return ops.prolong_add(X.lc, X.data(xs), D.lc, D.data(ds), b, e)
+        self.launches -= 1
+        raise Exa4Unsupported("loop body statement is none of the recognised kernels: %s %s ..." % (lhs[1], op))
+
+    def _smooth(self, D: Field, ds: int, src, w, r, b, e, colour, fr: _Frame):
+        F, fs = self._field(r[0], fr)
+        U, us = self._field(src, fr)
+        A = r[1]
+        wv = self._smoother_weight(w, A, fr)
+        in_place = D is U and ds == us
+        if in_place and colour is None:
+            raise Exa4Unsupported("in-place smoother update without colouring (lexicographic Gauss-Seidel)")
+        if not in_place and colour is not None:
+            raise Exa4Unsupported("coloured update into another slot")
+        return self.ops.stencil_op(SMOOTH, U.lc, U.data(us), F.lc, F.data(fs), D.lc, D.data(ds), A, wv,
+                                   -1 if colour is None else colour, b, e)
+
+    def _exec_reduction(self, f: Field, boxes, reduction, body, fr: _Frame):
+        op, var = reduction
+        locals_: Dict[str, object] = {}
+        for st in body:
+            if st[0] == "decl":
+                locals_[st[1]] = st[2]
+                continue
+            if st[0] != "assign" or st[2] != ("id", var, None):
+                raise Exa4Unsupported("reduction loop body")
+            rhs = st[3]
+            if op == "+" and st[1] == "+=" and rhs[0] == "bin" and rhs[1] == "*" and rhs[2][0] == "fld" and rhs[3][0] == "fld":
+                X, xs = self._field(rhs[2], fr)
+                Y, ys = self._field(rhs[3], fr)
+                acc = 0.0
+                for b, e in boxes:
+                    self.launches += 1
+                    t = self.ops.dot(X.lc, X.data(xs), Y.lc, Y.data(ys), b, e)
+                    acc += self.ops.scalar_value(self.comm.allreduce(t, "sum"))
+                fr.vars[var] = fr.vars[var] + acc
+                continue
+            if op == "max" and st[1] == "=" and rhs[0] == "call" and rhs[1] == "max" and len(rhs[3]) == 2:
+                other = [a for a in rhs[3] if a != ("id", var, None)]
+                if len(other) == 1:
+                    t = other[0]
+                    if t[0] == "id" and t[1] in locals_:
+                        t = locals_[t[1]]
+                    if t[0] == "call" and t[1] in ("fabs", "abs") and t[3][0][0] == "bin" and t[3][0][1] == "-" and t[3][0][2][0] == "fld":
+                        X, xs = self._field(t[3][0][2], fr)
+                        fn, par = self._recognise(t[3][0][3], X.level)
+                        acc = fr.vars[var]
+                        for b, e in boxes:
+                            self.launches += 1
+                            r = self.ops.max_err_fn(X.lc, X.data(xs), self.domain.geom(X.level), fn, par, b, e)
+                            acc = max(acc, self.ops.scalar_value(self.comm.allreduce(r, "max")))
+                        fr.vars[var] = acc
+                        continue
+            raise Exa4Unsupported("reduction %s over this loop body" % op)
+
+    def _exec_stencil_field_init(self, body, boxes, fr: _Frame):
+        """`A:[o] = expr` for every entry of a 7/5-entry stencil field: -div(a grad) with a at the half points."""
+        name = body[0][2][1]
+        lvl = self._level_of(body[0][2][2], fr)
+        A = self.stencil(name, lvl)
+        if A.cfield is None:
+            raise Exa4Unsupported("%s is not a stencil field" % name)
+        nd = self.nd
+        want = [(0, 0, 0)]
+        for d in range(nd):
+            for sgn in (1, -1):
+                o = [0, 0, 0]
+                o[d] = sgn
+                want.append(tuple(o))
+        got = {tuple(st[2][3]) + (0,) * (3 - len(st[2][3])): st[3] for st in body}
+        if [tuple(o) for o in A.offsets] != want or set(got) != set(want) or any(st[1] != "=" for st in body):
+            raise Exa4Unsupported("stencil field initialisation: entries must be c,+x,-x,+y,-y[,+z,-z]")
+        calls = [c for c in _find_calls(got[want[1]]) if c[1] in self.functions]
+        if not calls:
+            raise Exa4Unsupported("stencil field initialisation without a coefficient function")
+        cfn = self.functions[calls[0][1]][0]
+        coef_expr = ("call", cfn.name, None, [("id", "vf_nodePosition_" + "xyz"[i], None) for i in range(len(cfn.params))])
+        fn, par = self._recognise(coef_expr, lvl)
+        h = self.domain.h(lvl)
+        for _ in range(6):      # check the seven expressions against the kernel's formula at random points
+            x, y, z = (self._rng.uniform(0.1, 0.9) for _ in range(3))
+            a = lambda dx, dy, dz: fn_eval(fn, par, x + dx, y + dy, z + dz)
+            ref = {}
+            diag = None
+            for d in range(nd):
+                off = [0.0, 0.0, 0.0]
+                off[d] = 0.5 * h[d]
+                ap, am = a(*off), a(*[-v for v in off])
+                term = (ap + am) / (h[d] * h[d])
+                diag = term if diag is None else diag + term
+                ref[want[1 + 2 * d]] = (-1.0 * ap) / (h[d] * h[d])
+                ref[want[2 + 2 * d]] = (-1.0 * am) / (h[d] * h[d])
+            ref[want[0]] = diag
+            for o in want:
+                v = self._point_eval(got[o], lvl, x, y, z)
+                if abs(v - ref[o]) > 1e-11 * max(1.0, abs(ref[o])):
+                    raise Exa4Unsupported("stencil field entry %r is not -a(x +- h/2)/h^2" % (o,))
+        for b, e in boxes:
+            self.launches += 1
+            self.ops.init_varcoeff7(A.clayout.c_struct(), A.cfield, self.domain.geom(lvl), fn, par, b, e)
+
+
+# -- AST helpers ----------------------------------------------------------------------------------------------------------
+def _walk(e):
+    if isinstance(e, tuple):
+        yield e
+        for c in e[1:]:
+            if isinstance(c, tuple):
+                yield from _walk(c)
+            elif isinstance(c, list):
+                for x in c:
+                    if isinstance(x, tuple):
+                        yield from _walk(x)
+
+
+def _contains(e, kinds) -> bool:
+    return any(n[0] in kinds for n in _walk(e) if n and isinstance(n[0], str))
+
+
+def _find_calls(e):
+    return [n for n in _walk(e) if n and n[0] == "call"]
+
+
+def _has_coord(e, functions) -> bool:
+    for n in _walk(e):
+        if n and n[0] == "id" and isinstance(n[1], str) and (_COORD.match(n[1]) or re.fullmatch(r"i[012]", n[1])):
+            return True
+    return False
+
+
+def _conjuncts(e):
+    if e[0] == "bin" and e[1] == "&&":
+        return _conjuncts(e[2]) + _conjuncts(e[3])
+    return [e]
+
+
+def _index_sum(e, nd: int):
+    """constant c if e == c + i0 + i1 [+ i2] (each index once), else None."""
+    seen, const = [], 0
+
+    def rec(x):
+        nonlocal const
+        if x[0] == "bin" and x[1] == "+":
+            return rec(x[2]) and rec(x[3])
+        if x[0] == "id" and re.fullmatch(r"i[012]", x[1]):
+            seen.append(x[1])
+            return True
+        if x[0] == "num" and isinstance(x[1], int):
+            const += x[1]
+            return True
+        return False
+
+    if rec(e) and sorted(seen) == ["i%d" % d for d in range(nd)]:
+        return const
+    return None
+
+
+def _parity_expr(e, nd: int):
+    """shift s if e == (s + i0 + i1 [+ i2]) % 2."""
+    if e[0] == "bin" and e[1] == "%" and e[3] == ("num", 2):
+        return _index_sum(e[2], nd)
+    return None
+
+
+def _colour_cond(e, nd: int):
+    """colour selected by `c == (s + i0 + ...) % 2` (either side)."""
+    if e[0] != "bin" or e[1] != "==":
+        return None
+    for a, b in ((e[2], e[3]), (e[3], e[2])):
+        if a[0] == "num" and isinstance(a[1], int):
+            s = _parity_expr(b, nd)
+            if s is not None:
+                return (a[1] - s) % 2
+    return None
+
+
+def _lower_cond(e):
+    """d if e == (i_d > 0)."""
+    if e[0] == "bin" and e[1] == ">" and e[2][0] == "id" and re.fullmatch(r"i[012]", e[2][1]) and e[3] == ("num", 0):
+        return int(e[2][1][1])
+    return None
+
+
+# =====================================================================================================================
+def load(exa4_path: str, knowledge_path: Optional[str] = None, **kw) -> Exa4Program:
+    with open(exa4_path) as f:
+        text = f.read()
+    k = _knowledge.parse_file(knowledge_path) if knowledge_path else {}
+    return Exa4Program(text, k, **kw)
+
+
+def main(argv=None):
+    import argparse
+
+    ap = argparse.ArgumentParser(description="run an ExaSlang-4 multigrid program on libexamg (MI355X)")
+    ap.add_argument("exa4")
+    ap.add_argument("knowledge", nargs="?")
+    ap.add_argument("--set", action="append", default=[], metavar="key=value", help="override a knowledge flag")
+    args = ap.parse_args(argv)
+    k = _knowledge.parse_file(args.knowledge) if args.knowledge else {}
+    for kv in args.set:
+        _knowledge.parse_text(kv, None, k)
+    with open(args.exa4) as f:
+        prog = Exa4Program(f.read(), k, echo=True)
+    prog.run()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -61,6 +61,18 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool =
 
     def shell():
         comm.exchange(S, src, "ghost", axis_only)
+        # tmp's duplicate planes on PHYSICAL faces are read by the second step of the slabs (tangential neighbours) and
+        # written by nobody: bring them over from the source slot, whatever boundary values the program put there
+        # (Dirichlet function, or SetFuncDir values during an FMG start)
+        lay = S.layout
+        for d in range(nd):
+            for side in (-1, 1):
+                if domain.neighbor(d, side) is not None:
+                    continue
+                pb = [lay.idx("DLB", t) if t < nd else 0 for t in range(3)]
+                pe = [lay.idx("DRE", t) if t < nd else 1 for t in range(3)]
+                pb[d], pe[d] = (lay.idx("DLB", d), lay.idx("DLE", d)) if side < 0 else (lay.idx("DRB", d), lay.idx("DRE", d))
+                ops.axpby(S.lc, S.data(src), tmp_field.lc, tmp_field.data(), 1.0, 0.0, pb, pe)
         for d, side in faces:
             sb, se = slab(d, side, 3)
             ops.stencil_op(SMOOTH, S.lc, S.data(src), F.lc, F.data(), tmp_field.lc, tmp_field.data(), A, w, -1, sb, se)

@@ -1,0 +1,244 @@
+"""ExaSlang-4 subset reader / interpreter (exastencils_amd/exa4.py) on the CPU: the interpreter
+issues kernel-layer calls, the oracle's loops stand in for the HIP kernels (tests/oracle_ops.py).
+
+ * the reference's own programs (read from /root/reference when it is present -- they are its sources and are not
+   copied into this repository) reproduce the reference's checked-in *.results files line by line;
+ * this repository's example programs (examples/exa4/*.exa4) reproduce the oracle programs bit for bit;
+ * parser details and the refusal of constructs outside the subset."""
+import os
+import socket
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from golden_cases import golden_text  # noqa: E402
+from oracle_ops import OracleOps  # noqa: E402
+
+from exastencils_amd import exa4, knowledge  # noqa: E402
+
+REF = "/root/reference"
+EX = os.path.join(ROOT, "examples", "exa4")
+
+# golden name -> (program, knowledge) relative to the reference checkout
+REFERENCE_PROGRAMS = {
+    "Poisson_2D_FD_Poisson_fromL4": ("Examples/Poisson/2D_FD_Poisson_fromL4.exa4", "Testing/Poisson/2D_FD_Poisson_fromL4.knowledge"),
+    "CommBasic_PureMPI": ("Testing/CommBasic/PureMPI.exa4", "Testing/CommBasic/PureMPI.knowledge"),
+    "SISC_3D_ConstCoeff": ("Testing/SISC/3D_ConstCoeff.exa4", "Testing/SISC/3D_ConstCoeff.knowledge"),
+    "SISC_3D_VarCoeff": ("Testing/SISC/3D_VarCoeff.exa4", "Testing/SISC/3D_VarCoeff.knowledge"),
+    "FMG_3D_Trigonometric": ("Testing/FMG/3D_Trigonometric.exa4", "Testing/FMG/3D_Trigonometric.knowledge"),
+    "FMG_3D_VarCoeff": ("Testing/FMG/3D_VarCoeff.exa4", "Testing/FMG/3D_VarCoeff.knowledge"),
+    "Smoothers_RBGS": ("Testing/Smoothers/RBGS.exa4", "Testing/Smoothers/RBGS.knowledge"),
+    "Smoothers_Jac": ("Testing/Smoothers/Jac.exa4", "Testing/Smoothers/Jac.knowledge"),
+}
+SLOW = {"Smoothers_RBGS", "Smoothers_Jac"}      # 576^3 on the CPU
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("name", sorted(REFERENCE_PROGRAMS))
+def test_reference_program_reproduces_its_results_file(name):
+    if name in SLOW and not os.environ.get("EXAMG_SLOW"):
+        pytest.skip("576^3 on the CPU: set EXAMG_SLOW=1")
+    prog, know = REFERENCE_PROGRAMS[name]
+    k = knowledge.parse_file(os.path.join(REF, know))
+    k["testing_enabled"] = True             # what Testing/run_test.py adds to every knowledge file
+    with open(os.path.join(REF, prog)) as f:
+        P = exa4.Exa4Program(f.read(), k, ops=OracleOps())
+    out = P.run()
+    want = [l.strip() for l in golden_text(name).splitlines() if l.strip()]
+    assert out == want
+    assert P.launches > 100
+
+
+def _oracle_a(lo, hi):
+    from oracle import mg
+
+    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=lo, max_level=hi, tol=1e-6))
+    O.setup()
+    O.Solve()
+    return O
+
+
+def _oracle_b(lo, hi, **kw):
+    from oracle import mg
+
+    O = mg.ProgramB(mg.ConfigB(nd=3, min_level=lo, max_level=hi, **kw))
+    O.setup()
+    O.Solve()
+    return O
+
+
+VARCOEFF = dict(omega=0.85, stencil="varcoeff", restrict_scale=1.0, cg_max=1024, bc_fn=6, rhs_fn=5, sol_fn=6, coef_fn=7, kappa=10.0)
+
+
+def example(name, lo, hi, ops=None, **kw):
+    with open(os.path.join(EX, name)) as f:
+        return exa4.Exa4Program(f.read(), dict(dimensionality=3, minLevel=lo, maxLevel=hi), ops=ops or OracleOps(), **kw)
+
+
+def test_example_rbgs_program_matches_oracle_bitwise():
+    P = example("poisson3d_rbgs.exa4", 2, 5)
+    P.run()
+    O = _oracle_a(2, 5)
+    assert P.printed_values == O.res_history
+    assert P.out[0].startswith("initial residual") and P.out[-1].startswith("cycle %d residual" % O.iterations)
+    assert "solve" in P.timers
+
+
+def test_example_jacobi_program_matches_oracle_bitwise():
+    P = example("jacobi3d_slots.exa4", 0, 4)
+    P.run()
+    O = _oracle_b(0, 4)
+    assert P.printed_values == O.res_history
+    assert P.out == O.log
+
+
+def test_example_varcoeff_program_matches_oracle_bitwise():
+    P = example("varcoeff3d.exa4", 0, 4)
+    P.run()
+    O = _oracle_b(0, 4, **VARCOEFF)
+    res, err = P.printed_values[:1] + P.printed_values[1::2], P.printed_values[2::2]
+    assert res == O.res_history
+    assert err == O.err_history
+    assert P.out[-1] == str(O.iterations)
+
+
+def test_fused_passes_change_no_bit():
+    """Red-black sweeps as one out-of-place pass and slotted Jacobi steps in pairs: same printed values, fewer launches."""
+    for name, lo, hi in (("poisson3d_rbgs.exa4", 2, 5), ("jacobi3d_slots.exa4", 1, 4)):
+        plain = example(name, lo, hi, fuse=False)
+        plain.run()
+        fused = example(name, lo, hi)
+        fused.fuse_min_row = 8
+        fused.run()
+        assert fused.printed_values == plain.printed_values
+        assert fused.launches < plain.launches
+
+
+# -- parser -----------------------------------------------------------------------------------------------------------
+def _levels(text, lo=0, hi=6, cur=None):
+    pr = exa4.Parser("Function F@%s { }" % text).parse()
+    P = exa4.Exa4Program.__new__(exa4.Exa4Program)
+    P.min_level, P.max_level = lo, hi
+    return P.levels_of(pr.functions[0].levels, cur)
+
+
+def test_level_specifications():
+    assert _levels("all") == [0, 1, 2, 3, 4, 5, 6]
+    assert _levels("finest") == [6]
+    assert _levels("(coarsest and finest)") == [0, 6]
+    assert _levels("(finest, coarsest)") == [0, 6]
+    assert _levels("(all but finest)") == [0, 1, 2, 3, 4, 5]
+    assert _levels("(all but (finest))") == [0, 1, 2, 3, 4, 5]
+    assert _levels("((coarsest + 1) to finest)") == [1, 2, 3, 4, 5, 6]
+    assert _levels("(1 to (finest - 1))") == [1, 2, 3, 4, 5]
+    assert _levels("(coarsest to 0)") == [0]
+    assert _levels("(all but ((finest - 1)))") == [0, 1, 2, 3, 4, 6]
+    assert _levels("3") == [3]
+
+
+def test_expression_precedence_and_slots():
+    pr = exa4.Parser("Field u< global, L, None >[2]@all\nFunction F@all { Var a : Real = -1.0 / ( h ** 2 ) + 2 * 3 % 2\n"
+                     "loop over u { u<next> = u<active>@current + 0.5 * u<0> } }").parse()
+    decl, loop = pr.functions[0].body
+    assert decl[2] == ("bin", "+", ("bin", "/", ("num", -1.0), ("bin", "**", ("id", "h", None), ("num", 2))),
+                       ("bin", "%", ("bin", "*", ("num", 2), ("num", 3)), ("num", 2)))
+    st = loop[5][0]
+    assert st[2] == ("fld", "u", "next", None)
+    assert st[3][2] == ("fld", "u", "active", ("single", "current", 0))
+    assert st[3][3][3] == ("fld", "u", 0, None)
+
+
+def test_colour_conditions():
+    pr = exa4.Parser("Function F { loop over u where ( 1 == ( ( ( ( 64 + i0 ) + i1 ) + i2 ) % 2 ) ) { } }").parse()
+    assert exa4._colour_cond(pr.functions[0].body[0][3], 3) == 1
+    pr = exa4.Parser("Function F { loop over u where 0 == ((i0 + i1 + i2) % 2) { } }").parse()
+    assert exa4._colour_cond(pr.functions[0].body[0][3], 3) == 0
+    pr = exa4.Parser("Function F { loop over u where ( ( i0 > 0 ) && ( i1 > 0 ) ) { } }").parse()
+    assert [exa4._lower_cond(c) for c in exa4._conjuncts(pr.functions[0].body[0][3])] == [0, 1]
+
+
+HEADER = """
+Domain global< [0.0, 0.0, 0.0] to [1.0, 1.0, 1.0] >
+Layout L< Real, Node >@all { duplicateLayers = [1, 1, 1] with communication
+ ghostLayers = [1, 1, 1] with communication }
+Field u< global, L, %s >@all
+Field f< global, L, None >@all
+Stencil A@all { [0, 0, 0] => 6.0
+ [1, 0, 0] => -1.0
+ [-1, 0, 0] => -1.0
+ [0, 1, 0] => -1.0
+ [0, -1, 0] => -1.0
+ [0, 0, 1] => -1.0
+ [0, 0, -1] => -1.0 }
+"""
+
+
+@pytest.mark.parametrize("bc,body,what", [
+    ("0.0", "loop over u@finest { u@finest += 0.8 / diag ( A@finest ) * ( f@finest - A@finest * u@finest ) }", "without colouring"),
+    ("0.0", "loop over u@finest { u@finest = u@finest * f@finest }", "none of the recognised kernels"),
+    ("0.0", "loop over u@finest { u@finest = sin ( vf_nodePosition_x ) * 3.0 }", "built-in point functions"),
+    ("tan ( vf_boundaryCoord_x )", "", "built-in point functions"),
+    ("0.0", "repeat 2 times with contraction [1, 1, 1] { }", "contraction"),
+])
+def test_constructs_outside_the_subset_are_refused(bc, body, what):
+    text = HEADER % bc + "Function Application { %s }" % body
+    with pytest.raises(exa4.Exa4Unsupported, match=what):
+        exa4.Exa4Program(text, dict(dimensionality=3, minLevel=0, maxLevel=2), ops=OracleOps()).run()
+
+
+def test_syntax_errors_carry_the_line():
+    with pytest.raises(exa4.Exa4SyntaxError, match="line 2"):
+        exa4.Parser("Function F {\n loop under u { } }").parse()
+
+
+# -- two blocks over gloo ------------------------------------------------------------------------------------------------
+def _worker(rank, world, port, out_dir):
+    import json
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import mg
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+
+    mg.lib().orc_set_num_threads(2)
+    ops = OracleOps()
+    dom = RectDomain(3, (2, 1, 1), rank, (1, 2, 2))
+    P = example("poisson3d_rbgs.exa4", 1, 4, ops=ops, domain=dom, comm=Communicator(dom, ops))
+    P.run()
+    json.dump({"values": P.printed_values, "messages": P.comm.stats["messages"]}, open(os.path.join(out_dir, "r%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_interpreter_on_two_blocks_matches_single_block(tmp_path):
+    import json
+
+    import torch.multiprocessing as mp
+
+    from exastencils_amd.domain import RectDomain
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    single = example("poisson3d_rbgs.exa4", 1, 4, domain=RectDomain(3, (1, 1, 1), 0, (2, 2, 2)))
+    single.run()
+    for r in range(2):
+        meta = json.load(open(tmp_path / ("r%d.json" % r)))
+        assert meta["messages"] > 0
+        assert len(meta["values"]) == len(single.printed_values)
+        for x, y in zip(meta["values"], single.printed_values):
+            assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * single.printed_values[0]

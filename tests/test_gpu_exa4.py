@@ -1,0 +1,79 @@
+"""ExaSlang-4 programs interpreted onto libexamg on the MI355X: every `loop over` of the example
+programs is one HIP kernel launch through the C ABI; histories are checked against the CPU oracle programs."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, r0):
+    assert len(got) == len(want), (got, want)
+    for x, y in zip(got, want):
+        assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * r0, (got, want)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from exastencils_amd.ops import HipOps
+
+    return HipOps(0)
+
+
+def test_rbgs_program_on_gpu(hip):
+    from test_exa4 import _oracle_a, example
+
+    P = example("poisson3d_rbgs.exa4", 2, 7, ops=hip)
+    P.run()
+    O = _oracle_a(2, 7)
+    _close(P.printed_values, O.res_history, O.res_history[0])   # norms: the device reduction tree sums in another order
+    assert P.launches > 300
+    plain = example("poisson3d_rbgs.exa4", 2, 7, ops=hip, fuse=False)
+    plain.run()
+    assert plain.printed_values == P.printed_values              # fused sweeps change no bit
+    assert plain.launches > P.launches
+
+
+def test_jacobi_program_on_gpu(hip):
+    from test_exa4 import _oracle_b, example
+
+    P = example("jacobi3d_slots.exa4", 1, 6, ops=hip)
+    P.run()
+    O = _oracle_b(1, 6)
+    _close(P.printed_values, O.res_history, O.res_history[0])
+    assert P.out == O.log
+    plain = example("jacobi3d_slots.exa4", 1, 6, ops=hip, fuse=False)
+    plain.run()
+    assert plain.printed_values == P.printed_values              # paired Jacobi steps change no bit
+
+
+def test_varcoeff_program_on_gpu(hip):
+    from test_exa4 import VARCOEFF, _oracle_b, example
+
+    P = example("varcoeff3d.exa4", 1, 6, ops=hip)
+    P.run()
+    O = _oracle_b(1, 6, **VARCOEFF)
+    res, err = P.printed_values[:1] + P.printed_values[1::2], P.printed_values[2::2]
+    _close(res, O.res_history, O.res_history[0])          # exp() in coefficients and boundary values: device libm
+    assert len(err) == len(O.err_history)
+    for x, y in zip(err, O.err_history):
+        assert abs(x - y) <= 1e-12
+    assert P.out[-1] == str(O.iterations)
+
+
+def test_command_line_runs_a_program():
+    r = subprocess.run([sys.executable, "-m", "exastencils_amd.exa4", os.path.join(ROOT, "examples", "exa4", "poisson3d_rbgs.exa4"),
+                        "--set", "dimensionality=3", "--set", "minLevel=2", "--set", "maxLevel=5"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "initial residual 39640.6"
+    assert lines[-1].startswith("cycle 6 residual 0.0207")
