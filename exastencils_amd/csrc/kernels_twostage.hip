@@ -215,8 +215,11 @@ k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const dou
 // 2*NW - 2 output rows) instead of three times, the first stage is evaluated on 2*NW rows instead of 4*NW - 4, and a
 // wave needs ~100 instead of 250 registers, so two workgroups share a CU.  One barrier per plane (double-buffered LDS).
 // ---------------------------------------------------------------------------------------------------------------
-template <int ORDER, bool COL, int NW, bool NT>
-__global__ void __launch_bounds__(64 * NW)
+#ifndef TS_SCALAR_WV
+#define TS_SCALAR_WV 1
+#endif
+template <int ORDER, bool COL, int NW, bool NT, int WPE>
+__global__ void __launch_bounds__(64 * NW, WPE)
 k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs,
                  double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g) {
   constexpr int NS = 2 * NW;        // stage-1 rows of the workgroup: s = 0 .. NS-1, global row rw0 - 1 + s
@@ -224,7 +227,8 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   constexpr int NO = NS - 2;        // output rows: stage-1 rows 1 .. NS-2
   __shared__ d2 UB[2][NI][64];      // input plane p in UB[p & 1]
   __shared__ d2 VB[2][NS][64];      // stage-1 plane p in VB[p & 1]
-  const int lane = threadIdx.x, wv = threadIdx.y;
+  // threadIdx.y is the same for all lanes of a wave: as a scalar it keeps row predicates and LDS row addresses on the SALU
+  const int lane = threadIdx.x, wv = TS_SCALAR_WV ? __builtin_amdgcn_readfirstlane(threadIdx.y) : threadIdx.y;
   int t = blockIdx.x;
   const int tx = t % g.ntx;
   t /= g.ntx;
@@ -236,35 +240,50 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   const int mb = box.b2 + tz * g.zc;
   const int me = min(mb + g.zc, box.e2);
   const Box &box1 = g.box1;
-  const bool alloc_a = xa >= g.ax0 && xa < g.ax1, alloc_b = xa + 1 >= g.ax0 && xa + 1 < g.ax1;
   const bool inx_a = xa >= box.b0 && xa < box.e0, inx_b = xa + 1 >= box.b0 && xa + 1 < box.e0;
   const bool in1_a = xa >= box1.b0 && xa < box1.e0, in1_b = xa + 1 >= box1.b0 && xa + 1 < box1.e0;
   const bool out_lane = lane >= 1 && lane <= 62;
+  const bool st_a = out_lane && inx_a, st_b = out_lane && inx_b;
 
   // this wave: stage-1 rows s0 = 2*wv, s0 + 1; their centre input rows i = s + 1; global rows
   const int s0 = 2 * wv;
   const int grow[2] = {rw0 - 1 + s0, rw0 + s0};
-  const bool row_alloc[2] = {grow[0] >= g.ay0 && grow[0] < g.ay1, grow[1] >= g.ay0 && grow[1] < g.ay1};
   const bool row_in1[2] = {grow[0] >= box1.b1 && grow[0] < box1.e1, grow[1] >= box1.b1 && grow[1] < box1.e1};
   // output rows: stage-1 rows 1 .. NS-2 inside the box
   const bool row_out[2] = {s0 >= 1 && grow[0] >= box.b1 && grow[0] < box.e1, s0 + 1 <= NS - 2 && grow[1] >= box.b1 && grow[1] < box.e1};
   // the two outermost input rows (i = 0 and i = NI-1) are nobody's centre row: wave 0 / wave NW-1 carry them along
   const bool has_outer = wv == 0 || wv == NW - 1;
   const int outer_i = wv == 0 ? 0 : NI - 1;
-  const int outer_row = rw0 - 2 + outer_i;
-  const bool outer_alloc = outer_row >= g.ay0 && outer_row < g.ay1;
 
-  const double *ubase = u + lu.origin + xa;
-  const double *fbase = rhs + lf.origin + xa;
   double *obase = out + lu.origin + xa;
 
-  auto load_u = [&](int row, bool rok, int p) {
-    const bool ok = rok && p >= g.az0 && p < g.az1;
-    return load2g(ubase + lu.s1 * row + lu.s2 * p, ok && alloc_a, ok && alloc_b);
+  // Loads are unconditional (no exec-mask branches in the plane loop): offsets are 32-bit, relative to the workgroup's
+  // lowest address, and clamped into the array.  A window that sticks out of the allocation then reads some other
+  // in-bounds value, which no valid output depends on (the first and the last element of an array, which the clamp
+  // can substitute for their neighbours, are corner points that no 7-point update and no pass-through reads).
+  const long long org_u = lu.origin + (long long)(box.b0 - 2 + TS_OUT * tx) + lu.s1 * (rw0 - 2) + lu.s2 * (mb - 2);
+  const long long orc_u = min(max(org_u, 0LL), lu.size - 2);
+  const double *ub = u + orc_u;
+  const int hi_u = (int)min(lu.size - 2 - orc_u, 2147483000LL);
+  const int s1u = (int)lu.s1, s2u = (int)lu.s2;
+  const int lane_u = (int)(org_u - orc_u) + 2 * lane;
+  const long long org_f = lf.origin + (long long)(box.b0 - 2 + TS_OUT * tx) + lf.s1 * (rw0 - 1) + lf.s2 * (mb - 1);
+  const long long orc_f = min(max(org_f, 0LL), lf.size - 2);
+  const double *fb = rhs + orc_f;
+  const int hi_f = (int)min(lf.size - 2 - orc_f, 2147483000LL);
+  const int s1f = (int)lf.s1, s2f = (int)lf.s2;
+  const int lane_f = (int)(org_f - orc_f) + 2 * lane;
+  const int urow[2] = {lane_u + s1u * (grow[0] - rw0 + 2), lane_u + s1u * (grow[1] - rw0 + 2)};
+  const int frow[2] = {lane_f + s1f * (grow[0] - rw0 + 1), lane_f + s1f * (grow[1] - rw0 + 1)};
+  const int uouter = lane_u + s1u * outer_i;
+
+  auto load_u = [&](int rowoff, int p) {
+    const int rel = min(max(rowoff + s2u * (p - mb + 2), 0), hi_u);
+    return load2(ub + rel);
   };
   auto load_f = [&](int r, int p) {
-    const bool ok = row_in1[r] && p >= box1.b2 && p < box1.e2;
-    return load2g(fbase + lf.s1 * grow[r] + lf.s2 * p, ok && in1_a, ok && in1_b);
+    const int rel = min(max(frow[r] + s2f * (p - mb + 1), 0), hi_f);
+    return load2(fb + rel);
   };
 
   // register pipelines of the two own rows
@@ -274,10 +293,10 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   d2 Oc, Opf;                       // outer halo row: planes q+1, q+2
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    Um[r] = load_u(grow[r], row_alloc[r], mb - 2);
-    Uc[r] = load_u(grow[r], row_alloc[r], mb - 1);
-    Up[r] = load_u(grow[r], row_alloc[r], mb);
-    Upf[r] = load_u(grow[r], row_alloc[r], mb + 1);
+    Um[r] = load_u(urow[r], mb - 2);
+    Uc[r] = load_u(urow[r], mb - 1);
+    Up[r] = load_u(urow[r], mb);
+    Upf[r] = load_u(urow[r], mb + 1);
     Fq[r] = load_f(r, mb - 1);
     Fqn[r] = load_f(r, mb);
     Vm[r] = Um[r];
@@ -286,9 +305,9 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   }
   d2 Ocur = {0.0, 0.0};
   if (has_outer) {
-    Ocur = load_u(outer_row, outer_alloc, mb - 1);
-    Oc = load_u(outer_row, outer_alloc, mb);
-    Opf = load_u(outer_row, outer_alloc, mb + 1);
+    Ocur = load_u(uouter, mb - 1);
+    Oc = load_u(uouter, mb);
+    Opf = load_u(uouter, mb + 1);
   }
   // publish input plane q0 = mb-1
   {
@@ -378,23 +397,23 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
           o.x = inx_a ? na : c.x;
           o.y = inx_b ? nb : c.y;
         }
-        if (out_lane) {
+        // full pairs leave under ONE exec region (two adjacent 8-byte non-temporal stores back to back): splitting them
+        // into two separately predicated stores costs 14 % of the kernel
+        if (st_a && st_b) {
           double *qp = obase + lu.s1 * grow[r] + lu.s2 * m;
-          if (inx_a && inx_b) {
-            if (NT) {
-              __builtin_nontemporal_store(o.x, qp);
-              __builtin_nontemporal_store(o.y, qp + 1);
-            } else {
-              d2u sv;
-              sv.a = o.x;
-              sv.b = o.y;
-              *reinterpret_cast<d2u *>(qp) = sv;
-            }
-          } else if (inx_a) {
-            qp[0] = o.x;
-          } else if (inx_b) {
-            qp[1] = o.y;
+          if (NT) {
+            __builtin_nontemporal_store(o.x, qp);
+            __builtin_nontemporal_store(o.y, qp + 1);
+          } else {
+            d2u sv;
+            sv.a = o.x;
+            sv.b = o.y;
+            *reinterpret_cast<d2u *>(qp) = sv;
           }
+        } else if (st_a) {
+          obase[lu.s1 * grow[r] + lu.s2 * m] = o.x;
+        } else if (st_b) {
+          obase[lu.s1 * grow[r] + lu.s2 * m + 1] = o.y;
         }
       }
     }
@@ -421,23 +440,25 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     if (q < me) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        Upf[r] = load_u(grow[r], row_alloc[r], q + 3);
+        Upf[r] = load_u(urow[r], q + 3);
         Fqn[r] = load_f(r, q + 2);
       }
-      if (has_outer) Opf = load_u(outer_row, outer_alloc, q + 3);
+      if (has_outer) Opf = load_u(uouter, q + 3);
     }
     __syncthreads();
   }
 }
 
 // launch knobs of the register variant (8 waves per workgroup, plain tile order) and the workgroup count target
-static int g_ts_blocks = 2048;
+static int g_ts_blocks = 3072;
 static int g_ts_disable = 0;
 static int g_ts_remap = 0;
 static int g_ts_wy = 8;
-// Which implementation: 0 = register variant; 5 / 9 = LDS variant with that many waves per workgroup; -2 = by size
-// (tools/tune_two_stage.py on MI355X: 512^3 Jacobi pair 0.87 / 0.88 ms, red-black sweep 0.90 / 0.85 ms for registers /
-// LDS-9; 256^3: 0.150 / 0.140 and 0.145 / 0.133 ms; 128^3: LDS-5 0.036 ms)
+// Which implementation: 0 = register variant; 5 / 8 / 9 = LDS variant with that many waves per workgroup; -2 = by size.
+// tools/tune_two_stage.py on MI355X, ms for a Jacobi pair / a red-black sweep (all variants bit-identical):
+//   512^3: registers 0.97 / 0.93, LDS-5 0.79 / 0.77, LDS-8 0.717 / 0.716 (3072 workgroups), LDS-9 0.87 / 0.85
+//   256^3: LDS-5 0.138, LDS-8 0.119-0.124;  128^3: LDS-5 0.028, LDS-8 0.031
+// ~120 VGPRs -> 4 waves per SIMD = 16 per CU: two 8-wave workgroups fill a CU (a 9-wave workgroup runs alone)
 static int g_ts_lds_default = -2;
 static int g_ts_lds = -2;
 
@@ -475,7 +496,7 @@ static int launch_two_stage_w(const examg_layout_t *lu_, const double *u, const 
   return 0;
 }
 
-template <bool COL, int NW>
+template <bool COL, int NW, int WPE = 1>
 static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
                                 double *out, const examg_stencil_t *st, double w, int first, const Box &box, const Box &box1,
                                 hipStream_t s) {
@@ -503,8 +524,8 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
   const int ord = canonical_order7(st);
   dim3 block(64, NW, 1), grid(g.nblocks, 1, 1);
-  if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
-  else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
+  if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, WPE>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
+  else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, WPE>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
   EXAMG_CHECK_LAUNCH("k_two_stage7_lds");
   return 0;
 }
@@ -514,8 +535,9 @@ static int launch_two_stage(const examg_layout_t *lu_, const double *u, const ex
                             double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s,
                             const Box *box1 = nullptr) {
   const Box &b1 = box1 ? *box1 : box;
-  const int impl = g_ts_lds == -2 ? (box.n1() >= 192 ? 9 : 5) : g_ts_lds;
+  const int impl = g_ts_lds == -2 ? (box.n1() >= 192 ? 8 : 5) : g_ts_lds;
   if (impl == 9) return launch_two_stage_lds<COL, 9>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
+  if (impl == 8) return launch_two_stage_lds<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
   if (impl == 5) return launch_two_stage_lds<COL, 5>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
   if (g_ts_wy == 8) return launch_two_stage_w<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
   if (g_ts_wy == 2) return launch_two_stage_w<COL, 2>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libexamg.so")
+LIB_PATH = os.environ.get("EXAMG_LIB", os.path.join(_HERE, "libexamg.so"))   # EXAMG_LIB: experimental builds (tools/)
 MAXE = 27
 
 

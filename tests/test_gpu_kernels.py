@@ -174,7 +174,7 @@ def _two_stage_reference(orc, kind, shape, st, b, e, first=0):
     return [orc.to_host(out), orc.to_host(u)]
 
 
-@pytest.fixture(params=[0, 5, 9], ids=["registers", "lds5", "lds9"])
+@pytest.fixture(params=[0, 5, 8, 9], ids=["registers", "lds5", "lds8", "lds9"])
 def two_stage_variant(request, hip):
     """Both implementations of the two-stage kernel: register rings (one wave per row pair, halo recomputed) and the
     LDS variant (5 or 9 waves share a row stack through LDS)."""

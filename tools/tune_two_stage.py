@@ -24,8 +24,8 @@ Ls, Fs = lu.c_struct(), lf.c_struct()
 res = []
 for kind in ("jacobi2", "rbgs"):
     ref = None
-    configs = [(0, wy, remap, blocks) for wy, remap, blocks in itertools.product((4, 8), (0,), (2048, 4096))]
-    configs += [(nw, 0, 0, blocks) for nw in (5, 9) for blocks in (256, 512, 1024, 2048, 4096)]
+    configs = [(0, 8, 0, 4096)]
+    configs += [(nw, 0, 0, blocks) for nw in (4, 5, 6, 7, 8, 16) for blocks in (512, 1024, 2048, 3072, 4096, 6144)]
     for lds, wy, remap, blocks in configs:
         L.examg_debug_two_stage_lds(lds)
         L.examg_debug_two_stage(0, blocks, remap, wy if wy else 8)
