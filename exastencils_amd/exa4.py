@@ -793,7 +793,7 @@ class Exa4Program:
     communicator.  `run()` executes `Function Application`; printed lines are collected in `self.out`."""
 
     def __init__(self, text: str, knowledge: Optional[Dict] = None, ops=None, domain: Optional[RectDomain] = None, comm=None,
-                 echo: bool = False, fuse: bool = True):
+                 echo: bool = False, fuse: bool = True, fuse_coarse_solver: Optional[bool] = None):
         """fuse: run red-black sweeps and pairs of slotted Jacobi steps as single passes over HBM where the program's
         statements allow it (bit-identical results; `fuse=False` issues exactly one launch per loop statement)."""
         self.ast = Parser(text).parse()
@@ -830,6 +830,11 @@ class Exa4Program:
         self._fn_cache: Dict[Tuple[str, Optional[int]], Tuple[int, Tuple[float, ...]]] = {}
         self._rng = random.Random(20240229)
         self.fuse = fuse
+        # a coarsest-level function that is exactly the generated conjugate-gradient solver runs as ONE persistent kernel
+        # (examg_cg_coarse; single block).  Same algorithm and statement order; the in-kernel reductions sum in another
+        # (fixed) order, so iterates agree with the statement-by-statement run to rounding, not bit for bit.
+        self.fuse_coarse_solver = fuse if fuse_coarse_solver is None else fuse_coarse_solver
+        self._cg_plans: Dict[Tuple[str, int], object] = {}
         self.fuse_min_row = 64      # rows shorter than one wavefront's tile stay on the per-colour kernels
         self._alt: Dict[Tuple[str, int, int], object] = {}
         self._alt_shell: Dict[Tuple[str, int, int], int] = {}
@@ -1080,6 +1085,10 @@ class Exa4Program:
 
     def call(self, name: str, lvl: Optional[int] = None, args: Sequence = (), caller: Optional[_Frame] = None):
         fn = self._resolve(name, lvl)
+        if self.fuse_coarse_solver and fn.levels is not None and lvl == self.min_level and not fn.params:
+            plan = self._coarse_cg_plan(fn, lvl)
+            if plan is not None:
+                return self._run_coarse_cg(plan)
         fr = _Frame(lvl if fn.levels is not None else None, dict(zip(fn.params, args)))
         if caller is not None and "__x" in caller.vars:      # point expression: coordinates stay visible in callees
             for c in ("__x", "__y", "__z"):
@@ -1089,6 +1098,37 @@ class Exa4Program:
         except _Return as r:
             return r.value
         return None
+
+    # -- hipGraph capture of a function call ----------------------------------------------------------------------------------
+    def _roles(self):
+        st = [(k, tuple(t.data_ptr() for t in f.slots), f.current_slot) for k, f in sorted(self.fields.items())]
+        return st, sorted((k, v.data_ptr()) for k, v in self._alt.items())
+
+    def capture(self, name: str, lvl: Optional[int] = None, args: Sequence = ()):
+        """Record one call of a function (typically the cycle function on the finest level) into a hipGraph and return it;
+        `graph.replay()` then re-issues all its kernels without host work.  The call must be free of host-visible
+        reductions (a generated coarse-grid CG qualifies through examg_cg_coarse) and must leave every array in the role
+        it had before (an even number of out-of-place sweeps / slot advances)."""
+        torch = self.ops.torch
+        dev = self.ops.device
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        # twice outside the capture: lazily created second arrays / scratch fields exist and carry their boundary planes
+        for _ in range(2):
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.call(name, lvl, args)
+            cur.wait_stream(side)
+        before = self._roles()
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                self.call(name, lvl, args)
+        except RuntimeError as ex:
+            raise Exa4Unsupported("%s cannot be captured (host-visible reduction or allocation inside?): %s" % (name, ex))
+        if self._roles() != before:
+            raise Exa4Unsupported("%s leaves arrays in other roles than it found them: a replay would read stale data" % name)
+        return g
 
     def run(self, name: str = "Application"):
         self.call(name)
@@ -1290,6 +1330,201 @@ class Exa4Program:
         if k:
             self._exec_block(body, fr)
         return True
+
+    # -- coarse-grid CG as one kernel ---------------------------------------------------------------------------------------
+    def _inline(self, body, lvl: int, depth: int = 0):
+        """Statement list with calls to parameterless, value-less functions of the same level replaced by their bodies."""
+        out = []
+        for st in body:
+            if st[0] == "callstmt" and st[1][1] in self.functions and not st[1][3] and depth < 4:
+                c = st[1]
+                clvl = self._level_of(c[2], _Frame(lvl, {})) if c[2] is not None else lvl
+                fn = self._resolve(c[1], clvl)
+                if clvl != lvl or fn.params or any(x[0] == "return" for x in fn.body):
+                    return None
+                sub = self._inline(fn.body, lvl, depth + 1)
+                if sub is None:
+                    return None
+                out += sub
+            else:
+                out.append(st)
+        return out
+
+    def _norm_of(self, e, fr: _Frame):
+        """Field R if `e` is a call of a function  { Var s = 0; loop over R with reduction(+ : s) { s += R * R }; return sqrt(s) }."""
+        if e[0] != "call" or e[1] not in self.functions or e[3]:
+            return None
+        lvl = self._level_of(e[2], fr) if e[2] is not None else fr.level
+        b = self._resolve(e[1], lvl).body
+        if len(b) != 3 or b[0][0] != "decl" or b[1][0] != "loop" or b[2][0] != "return":
+            return None
+        var, lp = b[0][1], b[1]
+        if lp[2] is not None or lp[4] != ("+", var) or len(lp[5]) != 1 or b[2][1] != ("call", "sqrt", None, [("id", var, None)]):
+            return None
+        if lp[3] is not None and any(_lower_cond(c) is None for c in _conjuncts(lp[3])):
+            return None
+        st = lp[5][0]
+        if st[0] != "assign" or st[1] != "+=" or st[2] != ("id", var, None):
+            return None
+        r = st[3]
+        cfr = _Frame(lvl, {})
+        if r[0] == "bin" and r[1] == "*" and self._same_access(r[2], r[3], cfr) and self._same_access(r[2], lp[1], cfr):
+            return self._field(r[2], cfr)[0]
+        return None
+
+    def _coarse_cg_plan(self, fn: FunctionDecl, lvl: int):
+        key = (fn.name, lvl)
+        if key not in self._cg_plans:
+            try:
+                self._cg_plans[key] = self._match_coarse_cg(fn, lvl)
+            except (Exa4SyntaxError, Exa4Unsupported, IndexError, KeyError, TypeError):
+                self._cg_plans[key] = None
+        return self._cg_plans[key]
+
+    def _match_coarse_cg(self, fn: FunctionDecl, lvl: int):
+        """The conjugate-gradient solver the reference's generator emits for `mgCycle@coarsest`
+        (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:152-201), recognised statement by statement."""
+        if self.domain.world_size != 1 or not hasattr(self.ops, "cg_coarse"):
+            return None
+        body = self._inline(fn.body, lvl)
+        if body is None:
+            return None
+        fr = _Frame(lvl, {})
+        pos = [0]
+
+        def peek():
+            return body[pos[0]] if pos[0] < len(body) else ("end",)
+
+        def take():
+            pos[0] += 1
+            return body[pos[0] - 1]
+
+        def loop1(st):        # plain loop with one assignment
+            if st[0] == "loop" and st[2] is None and st[3] is None and st[4] is None and len(st[5]) == 1 and st[5][0][0] == "assign":
+                return st[5][0]
+            return None
+
+        def fld(e):
+            return self._field(e, fr)[0]
+
+        def opt_comm(F):
+            if peek()[0] == "comm" and fld(peek()[3]) is F:
+                take()
+
+        def opt_bc(F):
+            if peek()[0] == "applybc" and fld(peek()[1]) is F:
+                take()
+                return True
+            return False
+
+        # communicate u; r = f - A u; apply bc to r
+        if peek()[0] == "comm":
+            take()
+        a = loop1(take())
+        rf = self._residual_form(a[3], fr) if a and a[1] == "=" else None
+        if rf is None:
+            return None
+        R, F, A, U = fld(a[2]), fld(rf[0]), rf[1], fld(rf[2])
+        bc_r = opt_bc(R)
+        opt_comm(R)
+        # Var rr = Norm(); Var rr0 = rr
+        d1, d2 = take(), take()
+        if d1[0] != "decl" or self._norm_of(d1[2], fr) is not R or d2[0] != "decl" or d2[2] != ("id", d1[1], None):
+            return None
+        rr, rr0 = d1[1], d2[1]
+        # p = r; apply bc to p
+        a = loop1(take())
+        if not a or a[1] != "=" or a[3][0] != "fld" or fld(a[3]) is not R:
+            return None
+        P = fld(a[2])
+        bc_p = opt_bc(P)
+        if peek()[0] == "decl" and pos[0] + 1 < len(body) and body[pos[0] + 1][0] == "repeat" and body[pos[0] + 1][2] == peek()[1]:
+            take()                                          # Var curStep : Integer = 0 -- the repeat's counter
+        rep = take()
+        if rep[0] != "repeat" or pos[0] < len(body) and not all(x[0] == "callstmt" and x[1][1] == "print" for x in body[pos[0]:]):
+            return None
+        max_it = int(self._eval(rep[1], fr))
+        body, pos[0] = self._inline(rep[3], lvl), 0
+        if body is None:
+            return None
+        opt_comm(P)
+        a = loop1(take())                                   # q = A p
+        m = self._sten_times_field(a[3], fr) if a and a[1] == "=" else None
+        if m is None or m[1] != "stencil" or m[0] != 1.0 or m[2] is not A or fld(m[4]) is not P:
+            return None
+        Q = fld(a[2])
+
+        def reduction(x, y):                                # Var v = 0; loop ... reduction(+ : v) { v += x * y }; [Var w = v]
+            d = take()
+            lp = take()
+            if d[0] != "decl" or lp[0] != "loop" or lp[2] is not None or lp[4] != ("+", d[1]) or len(lp[5]) != 1:
+                return None
+            if lp[3] is not None and any(_lower_cond(c) is None for c in _conjuncts(lp[3])):
+                return None
+            st = lp[5][0]
+            if st[0] != "assign" or st[1] != "+=" or st[2] != ("id", d[1], None) or st[3][0] != "bin" or st[3][1] != "*":
+                return None
+            if {id(fld(st[3][2])), id(fld(st[3][3]))} != {id(x), id(y)}:
+                return None
+            name = d[1]
+            if peek()[0] == "decl" and peek()[2] == ("id", name, None):
+                name = take()[1]
+            return name
+
+        num = reduction(R, R)
+        den = reduction(P, Q) if num else None
+        d = take()
+        if not den or d[0] != "decl" or d[2] != ("bin", "/", ("id", num, None), ("id", den, None)):
+            return None
+        alpha = d[1]
+        a = loop1(take())                                   # u += alpha p
+        if not a or a[1] != "+=" or fld(a[2]) is not U or a[3] != ("bin", "*", ("id", alpha, None), a[3][3]) or fld(a[3][3]) is not P:
+            return None
+        bc_u = opt_bc(U)
+        a = loop1(take())                                   # r -= alpha q
+        if not a or a[1] != "-=" or fld(a[2]) is not R or a[3] != ("bin", "*", ("id", alpha, None), a[3][3]) or fld(a[3][3]) is not Q:
+            return None
+        if opt_bc(R) != bc_r:
+            return None
+        d = take()                                          # Var rrNew = Norm()
+        if d[0] != "decl" or self._norm_of(d[2], fr) is not R:
+            return None
+        new = d[1]
+        c = take()                                          # if ( rrNew <= tol * rr0 ) { return }
+        if (c[0] != "if" or c[3] or len(c[2]) != 1 or c[2][0] != ("return", None) or c[1][0] != "bin" or c[1][1] != "<="
+                or c[1][2] != ("id", new, None) or c[1][3][0] != "bin" or c[1][3][1] != "*" or c[1][3][3] != ("id", rr0, None)):
+            return None
+        tol = float(self._eval(c[1][3][2], fr))
+        d = take()                                          # Var beta = (rrNew * rrNew) / (rr * rr)
+        sq = lambda v: ("bin", "*", ("id", v, None), ("id", v, None))
+        if d[0] != "decl" or d[2] != ("bin", "/", sq(new), sq(rr)):
+            return None
+        beta = d[1]
+        a = loop1(take())                                   # p = r + beta p
+        if (not a or a[1] != "=" or fld(a[2]) is not P or a[3][0] != "bin" or a[3][1] != "+" or a[3][2][0] != "fld" or fld(a[3][2]) is not R
+                or a[3][3] != ("bin", "*", ("id", beta, None), a[3][3][3]) or fld(a[3][3][3]) is not P):
+            return None
+        if opt_bc(P) != bc_p:
+            return None
+        if take() != ("assign", "=", ("id", rr, None), ("id", new, None)) or pos[0] != len(body):
+            return None
+        # the kernel applies homogeneous Dirichlet values to r, p and u on every face: the program must do the same
+        for fld_, has in ((R, bc_r), (P, bc_p), (U, bc_u)):
+            if not has or fld_.bc_fn != 0:
+                return None
+        if any(x.num_slots != 1 for x in (U, F, R, P, Q)):
+            return None
+        return U, F, R, P, Q, A, max_it, tol
+
+    def _run_coarse_cg(self, plan):
+        U, F, R, P, Q, A, max_it, tol = plan
+        b, e = self.domain.loop_bounds(U.layout)
+        if not hasattr(self, "_cg_info"):
+            self._cg_info = self.ops.new_array(4)
+        self.launches += 1
+        self.ops.cg_coarse(U.lc, U.data(), F.lc, F.data(), R.lc, R.data(), P.lc, P.data(), Q.lc, Q.data(), A,
+                           self.domain.geom(U.level), self.domain.face_mask(), max_it, tol, b, e, self._cg_info)
+        return None
 
     def _apply_bc(self, f: Field, slot: int):
         if f.bc_fn is None:

@@ -109,6 +109,42 @@ class OracleOps:
         out[0] = self.L.orc_dot(_lp(lx), self.ptr(x), _lp(ly), self.ptr(y), _iv(begin), _iv(end))
         return out
 
+    def cg_coarse(self, lu, sol, lf, rhs, lr, res, lp, p, lq, ap, st, geom, face_mask, max_it, rel_tol, begin, end, info):
+        """The statements examg_cg_coarse fuses (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:152-201), one oracle loop each."""
+        import math
+
+        def bc(l, x):
+            if face_mask:
+                self.apply_dirichlet(l, x, geom, 0, (), face_mask)
+
+        def norm():
+            return math.sqrt(self.scalar_value(self.dot(lr, res, lr, res, begin, end)))
+
+        self.stencil_op(1, lu, sol, lf, rhs, lr, res, st, 0.0, -1, begin, end)
+        bc(lr, res)
+        cur = init = norm()
+        self.axpby(lr, res, lp, p, 1.0, 0.0, begin, end)
+        bc(lp, p)
+        steps = max_it
+        for it in range(max_it):
+            self.stencil_op(0, lp, p, None, None, lq, ap, st, 0.0, -1, begin, end)
+            num = self.scalar_value(self.dot(lr, res, lr, res, begin, end))
+            den = self.scalar_value(self.dot(lp, p, lq, ap, begin, end))
+            alpha = num / den if den != 0.0 else float("nan")
+            self.axpby(lp, p, lu, sol, alpha, 1.0, begin, end)
+            bc(lu, sol)
+            self.axpby(lq, ap, lr, res, -alpha, 1.0, begin, end)
+            bc(lr, res)
+            nxt = norm()
+            if nxt <= rel_tol * init:
+                steps = it + 1
+                break
+            beta = (nxt * nxt) / (cur * cur)
+            self.axpby(lr, res, lp, p, 1.0, beta, begin, end)
+            bc(lp, p)
+            cur = nxt
+        info[0] = steps
+
     def max_err_fn(self, l, x, geom, fn, params, begin, end, out=None):
         out = self.new_scalar() if out is None else out
         out[0] = self.L.orc_max_err_fn(_lp(l), self.ptr(x), _gp(geom), int(fn), _p4(params), _iv(begin), _iv(end))

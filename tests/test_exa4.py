@@ -120,6 +120,27 @@ def test_fused_passes_change_no_bit():
         assert fused.launches < plain.launches
 
 
+def test_generated_cg_solver_is_recognised():
+    """`Cycle@coarsest` of the example (and the reference's mgCycle@coarsest, when present) is the generated CG solver
+    and becomes one examg_cg_coarse call; the slotted program's CG (alpha from the squared norm) is left alone."""
+    P = example("poisson3d_rbgs.exa4", 2, 5)
+    assert P._coarse_cg_plan(P._resolve("Cycle", 2), 2) is not None
+    P.run()
+    Q = example("poisson3d_rbgs.exa4", 2, 5, fuse_coarse_solver=False)
+    Q.run()
+    assert P.printed_values == Q.printed_values          # on the CPU ops the fused call runs the same loops
+    assert P.launches < Q.launches
+    J = example("jacobi3d_slots.exa4", 0, 4)
+    assert J._coarse_cg_plan(J._resolve("Cycle", 0), 0) is None
+    if os.path.isdir(REF):
+        for prog, know in (("Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4", None),
+                           ("Examples/Poisson/2D_FD_Poisson_fromL4.exa4", "Testing/Poisson/2D_FD_Poisson_fromL4.knowledge")):
+            k = knowledge.parse_file(os.path.join(REF, know)) if know else dict(dimensionality=3, minLevel=2, maxLevel=4)
+            with open(os.path.join(REF, prog)) as f:
+                R = exa4.Exa4Program(f.read(), k, ops=OracleOps())
+            assert R._coarse_cg_plan(R._resolve("mgCycle", R.min_level), R.min_level) is not None
+
+
 # -- parser -----------------------------------------------------------------------------------------------------------
 def _levels(text, lo=0, hi=6, cur=None):
     pr = exa4.Parser("Function F@%s { }" % text).parse()

@@ -35,11 +35,13 @@ def timed(fn, n=5):
 l0 = P.launches
 t_int = timed(lambda: P.call("Cycle", hi))
 per_cycle = (P.launches - l0) // 6
+g = P.capture("Cycle", hi)
+t_graph = timed(g.replay)
 S = SolverFromL4(ConfigL4(nd=3, min_level=lo, max_level=hi, tol=1e-6, fused_coarse=False), ops)
 S.setup()
 t_drv = timed(lambda: S.mgCycle(hi))
 S2 = SolverFromL4(ConfigL4(nd=3, min_level=lo, max_level=hi, tol=1e-6, fused_coarse=True, fused_rbgs=True), ops)
 S2.setup()
 t_fused = timed(lambda: S2.mgCycle(hi))
-print(json.dumps({"levels": [lo, hi], "interpreted_cycle_ms": t_int, "launches_per_cycle": per_cycle, "driver_cycle_ms": t_drv,
+print(json.dumps({"levels": [lo, hi], "interpreted_cycle_ms": t_int, "launches_per_cycle": per_cycle, "interpreted_cycle_graph_replay_ms": t_graph, "driver_cycle_ms": t_drv,
                   "driver_fused_cycle_ms": t_fused}))
