@@ -27,6 +27,13 @@ Loop bodies recognised (anything else raises Exa4Unsupported -- nothing is silen
 Analytic point functions (boundary values, right-hand sides, exact solutions, coefficient functions) are matched
 numerically against the built-in function ids of include/examg.h; an expression outside that set is unsupported.
 
+Fewer passes than statements, where the statements allow it (`fuse=True`, bit-identical): a `color with` red-black
+sweep is one out-of-place pass (examg_rbgs_sweep_fused), `repeat n times { Smoother ( ) }` with a slotted Jacobi body runs
+as n/2 two-step passes (examg_jacobi2_boxes) -- both only while the boundary planes involved are known to hold the
+field's Dirichlet values.  A coarsest-level function that is statement for statement the generated CG solver becomes one
+persistent kernel (examg_cg_coarse; `fuse_coarse_solver`, agrees to reduction-order rounding); a cycle is then free of host
+synchronisation and `capture()` records it into a hipGraph.
+
 Two deliberate readings of printed-L4 files (Testing/Smoothers/Jac.exa4:43 declares the finest `Solution` without level
 and slot count): a declaration never overrides an earlier one on the same level (the reference's collection lookup
 returns the first match, knowledge/l4/L4_KnowledgeCollection.scala:78-79), and a field name has one slot count, the
