@@ -207,6 +207,10 @@ def main():
     }
     if not args.no_vcycle:
         try:
+            extra.update(config1(ops, world))
+        except Exception as ex:
+            extra["config1_error"] = repr(ex)[:300]
+        try:
             extra.update(vcycle(ops, dom, comm, L, world))
         except Exception as ex:  # the headline number must not depend on the extra measurement
             extra["vcycle_error"] = repr(ex)[:300]
@@ -263,6 +267,43 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def config1(ops, world):
+    """BASELINE.json configs[1]: the same smoother step on a 256^3 block (single GPU), events on the launch stream."""
+    import torch
+
+    from exastencils_amd.field import laplace_fd
+    from exastencils_amd.layout import FieldLayout
+
+    if world != 1:
+        return {}
+    n = 256
+    lu, lf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0, False, False)
+    u, un, f = ops.new_array(lu.size), ops.new_array(lu.size), ops.new_array(lf.size)
+    ops.fill_random(u, 31)
+    ops.fill_random(f, 32)
+    A = laplace_fd(3, (1.0 / n,) * 3, "mp")
+    w = 0.8 / A.diag
+    b, e = [1, 1, 1], [n, n, n]
+    Lu, Lf = lu.c_struct(), lf.c_struct()
+    stream = torch.cuda.current_stream()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {}
+    for name, fn, steps in (("single_step", lambda x, y: ops.stencil_op(2, Lu, x, Lf, f, Lu, y, A, w, -1, b, e), 1),
+                            ("two_step", lambda x, y: ops.jacobi2(Lu, x, y, None, Lf, f, A, w, b, e), 2)):
+        fn(u, un)
+        torch.cuda.synchronize()
+        ev0.record(stream)
+        for _ in range(50):
+            fn(u, un)
+            u, un = un, u
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / 50
+        out["jacobi_256cube_%s_kernel_ms" % name] = ms
+        out["jacobi_256cube_%s_lups" % name] = steps * (n - 1) ** 3 / (ms * 1e-3)
+    return out
 
 
 def vcycle(ops, dom, comm, L, world):
