@@ -67,8 +67,14 @@ class _Program:
         return self.domain.loop_bounds(f.layout, reduction)
 
     # `communicate [dup|ghost of] <field>`  ->  exch<Field>_<level>(slot)
-    def communicate(self, f: Field, slot: Optional[int] = None, what: str = "all"):
-        self.comm.exchange(f, slot, what)
+    def communicate(self, f: Field, slot: Optional[int] = None, what: str = "all", axis_only: bool = False):
+        """axis_only: the loop that follows reads face ghosts only (5/7-point stencil) -- a communicator created with
+        concurrent_ghost_axes then sends all axes in one batch (exastencils_amd/comm.py)."""
+        self.comm.exchange(f, slot, what, axis_only)
+
+    @staticmethod
+    def _faces_only(A: Stencil) -> bool:
+        return all(sum(1 for c in o if c != 0) <= 1 for o in A.offsets)
 
     # `apply bc to <field>`  ->  applyBCs<Field>_<level>(slot)
     def apply_bc(self, f: Field, slot: Optional[int] = None):
@@ -144,7 +150,7 @@ class SolverFromL4(_Program):
 
     def _update_residual(self, l: int):
         S, R = self.Solution[l], self.Residual[l]
-        self.communicate(S)
+        self.communicate(S, axis_only=self._faces_only(self.Laplace[l]))
         b, e = self.bounds(R)
         self.ops.stencil_op(RESIDUAL, S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), R.lc, R.data(), self.Laplace[l],
                             0.0, -1, b, e)
@@ -227,7 +233,7 @@ class SolverFromL4(_Program):
             return
         for _ in range(self.cfg.n_smooth):
             for colour in (0, 1):
-                self.communicate(S)
+                self.communicate(S, axis_only=self._faces_only(A))
                 self.ops.stencil_op(SMOOTH, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, w, colour, b, e)
                 self.apply_bc(S)
 
@@ -269,7 +275,7 @@ class SolverFromL4(_Program):
         ops.axpby(Res.lc, Res.data(), p_.lc, p_.data(), 1.0, 0.0, b, e)        # cgTmp0 = Residual
         self.apply_bc(p_)
         for step in range(self.cfg.cg_max):
-            self.communicate(p_)
+            self.communicate(p_, axis_only=self._faces_only(A))
             b, e = self.bounds(Ap)
             ops.stencil_op(APPLY, p_.lc, p_.data(), None, None, Ap.lc, Ap.data(), A, 0.0, -1, b, e)
             alphaNom = self._dot_host(Res, Res, Res)

@@ -132,7 +132,7 @@ def _reference_single(case):
 
 @pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"),
                                          ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
-                                         ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 1, 1), "fmg_varcoeff"), ((2, 2, 1), "helmholtz27")])
+                                         ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 2, 1), "rbgs_l4_cg"), ((2, 1, 1), "fmg_varcoeff"), ((2, 2, 1), "helmholtz27")])
 def test_decomposed_solve_matches_single_block(tmp_path, blocks, case):
     world = blocks[0] * blocks[1] * blocks[2]
     port = _free_port()
