@@ -123,6 +123,33 @@ k_dot_partial(LayoutDev lx, const double *__restrict__ x, LayoutDev ly, const do
   if (threadIdx.x == 0) part[blockIdx.x] = r;
 }
 
+// Long rows: a wave streams whole rows, two points per lane with 16-byte loads, no index divisions per element; the rows a
+// wave takes and the order it adds them in depend only on the launch geometry, so the sum is reproducible run to run.
+__global__ void __launch_bounds__(RED_BLOCK)
+k_dot_rows(LayoutDev lx, const double *__restrict__ x, LayoutDev ly, const double *__restrict__ y, Box box, double *part) {
+  const int lane = threadIdx.x & 63;
+  const int n1 = box.n1();
+  const long long nrows = (long long)n1 * box.n2();
+  const long long wave = (long long)blockIdx.x * (RED_BLOCK / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (RED_BLOCK / 64);
+  double s = 0.0;
+  for (long long r = wave; r < nrows; r += nwaves) {
+    const int i1 = box.b1 + (int)(r % n1), i2 = box.b2 + (int)(r / n1);
+    const double *px = x + lidx(lx, 0, i1, i2), *py = y + lidx(ly, 0, i1, i2);
+    for (int i0 = box.b0 + 2 * lane; i0 < box.e0; i0 += 128) {
+      if (i0 + 1 < box.e0) {
+        const d2 a = load2(px + i0), b = load2(py + i0);
+        s = s + a.x * b.x;
+        s = s + a.y * b.y;
+      } else {
+        s = s + px[i0] * py[i0];
+      }
+    }
+  }
+  const double r = block_reduce<false>(s);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
 __global__ void __launch_bounds__(RED_BLOCK)
 k_maxerr_partial(LayoutDev l, const double *__restrict__ x, Geom g, int fn, Params4 p, Box box, double *part) {
   const long long total = box.count();
@@ -303,7 +330,10 @@ extern "C" int examg_dot(const examg_layout_t *lx_, const double *x, const examg
   if (box.count() == 0) return check_hip(hipMemsetAsync(result, 0, sizeof(double), s), "examg_dot memset");
   if (!box_inside(lx_, box, 0) || !box_inside(ly_, box, 0)) { set_error("examg_dot: box leaves an allocation"); return 1; }
   const int nb = red_blocks(box.count());
-  hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(RED_BLOCK), 0, s, make_layout(lx_), x, make_layout(ly_), y, box, (double *)work);
+  if (box.n0() >= 128)
+    hipLaunchKernelGGL(k_dot_rows, dim3(nb), dim3(RED_BLOCK), 0, s, make_layout(lx_), x, make_layout(ly_), y, box, (double *)work);
+  else
+    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(RED_BLOCK), 0, s, make_layout(lx_), x, make_layout(ly_), y, box, (double *)work);
   hipLaunchKernelGGL((k_reduce_final<false>), dim3(1), dim3(RED_BLOCK), 0, s, (const double *)work, nb, result);
   EXAMG_CHECK_LAUNCH("k_dot");
   return 0;

@@ -49,6 +49,76 @@ k_restrict(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, double 
   }
 }
 
+
+// 3-D restriction on long rows: one coarse point per lane, the fine pair (2I, 2I+1) of each of the nine fine rows with
+// one 16-byte load, the (2I-1) column from the lane below (DPP; lane 0 reads it).  A wave owns 64 coarse points of one
+// coarse row and marches in coarse z: fine plane 2K+1 serves coarse planes K and K+1, so a step loads 6 rows, not 9.
+// Same 27 products in the same order as k_restrict (x offset outermost, then y, then z).
+__global__ void __launch_bounds__(256)
+k_restrict3_wide(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, double *__restrict__ fc, double scale, Box box,
+                 int ntx, int zc, int nwaves) {
+  const int lane = threadIdx.x;
+  long long t = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+  if (t >= nwaves) return;
+  const int tx = (int)(t % ntx);
+  t /= ntx;
+  const int n1 = box.n1();
+  const int I1 = box.b1 + (int)(t % n1);
+  const int kb = box.b2 + (int)(t / n1) * zc;
+  const int ke = min(kb + zc, box.e2);
+  int I0 = box.b0 + tx * 64 + lane;
+  const bool valid = I0 < box.e0;
+  if (!valid) I0 = box.e0 - 1;
+  const double *row[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) row[b] = rf + lfine.origin + 2 * I0 + lfine.s1 * (2 * I1 + b - 1);
+  double *out = fc + lc.origin + I0 + lc.s1 * I1;
+  const double w1[3] = {0.25, 0.5, 0.25};
+  d2 P[3][3];      // [plane slot: 2K-1, 2K, 2K+1][row: 2J-1, 2J, 2J+1]
+  double E[3][3];  // lane 0: the column 2I-1
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    P[0][b] = load2(row[b] + lfine.s2 * (2 * kb - 1));
+    E[0][b] = lane == 0 ? row[b][lfine.s2 * (2 * kb - 1) - 1] : 0.0;
+  }
+  for (int K = kb; K < ke; ++K) {
+#pragma unroll
+    for (int c = 1; c < 3; ++c)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) P[c][b] = load2(row[b] + lfine.s2 * (2 * K + c - 1));
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 1; c < 3; ++c)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) E[c][b] = row[b][lfine.s2 * (2 * K + c - 1) - 1];
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          double v;
+          if (a == 0) {
+            v = lane_below(P[c][b].y);
+            if (lane == 0) v = E[c][b];
+          } else {
+            v = a == 1 ? P[c][b].x : P[c][b].y;
+          }
+          const double wgt = scale * ((w1[a] * w1[b]) * w1[c]);
+          const double tv = wgt * v;
+          acc = (a == 0 && b == 0 && c == 0) ? tv : acc + tv;
+        }
+    if (valid) out[lc.s2 * K] = acc;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      P[0][b] = P[2][b];
+      E[0][b] = E[2][b];
+    }
+  }
+}
+
 // One thread per fine point.
 template <int ND>
 __global__ void __launch_bounds__(256)
@@ -163,6 +233,8 @@ k_prolong_add3_pairs(LayoutDev lc, const double *__restrict__ uc, LayoutDev lfin
   }
 }
 
+static int g_restrict_wide = 1;   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
+
 static inline dim3 grid_for(long long total) {
   long long nb = (total + 255) / 256;
   if (nb > 8192) nb = 8192;
@@ -173,6 +245,11 @@ static inline dim3 grid_for(long long total) {
 }  // namespace examg
 
 using namespace examg;
+
+extern "C" int examg_debug_restrict(int wide) {
+  examg::g_restrict_wide = wide;
+  return 0;
+}
 
 extern "C" int examg_restrict(const examg_layout_t *lfine_, const double *rf, const examg_layout_t *lc_, double *fc,
                               double scale, const int32_t *begin, const int32_t *end, examg_stream_t stream) {
@@ -188,7 +265,19 @@ extern "C" int examg_restrict(const examg_layout_t *lfine_, const double *rf, co
   if (!box_inside(lfine_, fb, 1)) { set_error("examg_restrict: fine footprint leaves the fine allocation"); return 1; }
   const LayoutDev lf = make_layout(lfine_), lc = make_layout(lc_);
   hipStream_t s = (hipStream_t)stream;
-  if (lfine_->nd == 3) hipLaunchKernelGGL((k_restrict<3>), grid_for(box.count()), dim3(256), 0, s, lf, rf, lc, fc, scale, box);
+  if (lfine_->nd == 3 && box.n0() >= 32 && g_restrict_wide) {
+    const int ntx = (box.n0() + 63) / 64;
+    const long long cols = (long long)ntx * box.n1();
+    int ntz = (int)((4096 + cols - 1) / cols);
+    if (ntz < 1) ntz = 1;
+    int zc = (box.n2() + ntz - 1) / ntz;
+    if (zc < 8) zc = 8;
+    if (zc > box.n2()) zc = box.n2();
+    ntz = (box.n2() + zc - 1) / zc;
+    const long long nwaves = cols * ntz;
+    hipLaunchKernelGGL(k_restrict3_wide, dim3((unsigned)((nwaves + 3) / 4)), dim3(64, 4, 1), 0, s, lf, rf, lc, fc, scale, box, ntx, zc,
+                       (int)nwaves);
+  } else if (lfine_->nd == 3) hipLaunchKernelGGL((k_restrict<3>), grid_for(box.count()), dim3(256), 0, s, lf, rf, lc, fc, scale, box);
   else if (lfine_->nd == 2) hipLaunchKernelGGL((k_restrict<2>), grid_for(box.count()), dim3(256), 0, s, lf, rf, lc, fc, scale, box);
   else { set_error("examg_restrict: nd must be 2 or 3"); return 1; }
   EXAMG_CHECK_LAUNCH("k_restrict");

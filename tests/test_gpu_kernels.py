@@ -336,7 +336,7 @@ def test_empty_iteration_space_is_a_noop(hip, orc):
     assert_same(g, c, "empty")
 
 
-@pytest.mark.parametrize("nd,n", [(3, 64), (3, 50), (2, 256)])
+@pytest.mark.parametrize("nd,n", [(3, 64), (3, 50), (3, 130), (3, 200), (2, 256)])
 @pytest.mark.parametrize("scale", [1.0, 4.0])
 def test_restrict_and_prolong_bit_exact(hip, orc, nd, n, scale):
     shape_f = tuple(n if d < nd else 0 for d in range(3))
@@ -357,6 +357,22 @@ def test_restrict_and_prolong_bit_exact(hip, orc, nd, n, scale):
 
     g, c = both(hip, orc, f)
     assert_same(g, c, "transfer")
+
+
+def test_restrict_on_a_block_with_interior_faces(hip, orc):
+    """Coarse loop bounds of a block with neighbours (iteration offsets 0): the fine footprint reaches the ghost layers;
+    long rows take the wide kernel, a partial last tile included."""
+    n = 136
+
+    def f(ops):
+        lfi, lrh = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n // 2,) * 3, 0)
+        r, fc = ops.new_array(lfi.size), ops.new_array(lrh.size)
+        ops.fill_random(r, 11)
+        ops.restrict(lfi.c_struct(), r, lrh.c_struct(), fc, 1.0, [0, 1, 0], [n // 2 + 1, n // 2, n // 2 + 1])
+        return [fc]
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "restrict, interior faces")
 
 
 def test_blas1_forms_bit_exact(hip, orc):
