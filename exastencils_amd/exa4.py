@@ -42,6 +42,7 @@ maximum over its declarations.
 from __future__ import annotations
 
 import math
+import os
 import random
 import re
 import time
@@ -826,6 +827,8 @@ class Exa4Program:
         self.echo = echo
         self.out: List[str] = []
         self.printed_values: List[float] = []     # every Real handed to print / printWithReducedPrec, unrounded
+        self.json_results: Dict[str, Dict] = {}
+        self.json_dir: Optional[str] = None       # where printJSON writes its file (None: keep it in json_results only)
         self.timers: Dict[str, float] = {}
         self._timer_start: Dict[str, float] = {}
         self.launches = 0
@@ -1077,6 +1080,17 @@ class Exa4Program:
             return self.timers.get(args[0], 0.0) * 1e3
         elif name in ("initGlobals", "initDomain", "initGeometry", "destroyGlobals", "initFieldsWithZero"):
             pass        # fields are allocated zeroed at declaration (initFieldsWithZero)
+        elif name in ("benchmarkStart", "benchmarkStop"):
+            pass        # likwid / time markers of Benchmark/run_benchmark.py: the timers around them carry the numbers
+        elif name == "printJSON":
+            # printJSON ( "file", 'key', value, ... ) (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:273-276)
+            doc = {str(args[i]): args[i + 1] for i in range(1, len(args) - 1, 2)}
+            self.json_results[str(args[0])] = doc
+            if self.json_dir is not None and self.domain.rank == 0:
+                import json
+
+                with open(os.path.join(self.json_dir, str(args[0])), "w") as fh:
+                    json.dump(doc, fh)
         else:
             raise Exa4Unsupported("function %s" % name)
         return None
@@ -1899,6 +1913,7 @@ def main(argv=None):
         _knowledge.parse_text(kv, None, k)
     with open(args.exa4) as f:
         prog = Exa4Program(f.read(), k, echo=True)
+    prog.json_dir = os.getcwd()
     prog.run()
     return 0
 

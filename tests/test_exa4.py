@@ -55,6 +55,23 @@ def test_reference_program_reproduces_its_results_file(name):
     assert P.launches > 100
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_reference_benchmark_program_runs_end_to_end():
+    """Benchmark/Poisson3D (the program behind BASELINE's V-cycle metric) at a reduced depth: same histories as the oracle
+    program, timers and the printJSON record are there."""
+    k = knowledge.parse_file(os.path.join(REF, "Benchmark/Poisson3D/3D_FD_Poisson_fromL4.knowledge"))
+    k.update(minLevel=2, maxLevel=5)
+    with open(os.path.join(REF, "Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4")) as f:
+        P = exa4.Exa4Program(f.read(), k, ops=OracleOps())
+    P.run()
+    O = _oracle_a(2, 5)
+    # prints: starting residual, then (residual, convergence factor) per cycle
+    assert P.printed_values[:1] + P.printed_values[1::2] == O.res_history
+    assert P.out[0].startswith("Starting residual") and any(l.startswith("Mean") for l in P.out)
+    assert set(P.json_results["results.json"]) == {"totalTimeSolve", "totalSetupTime"}
+    assert P.json_results["results.json"]["totalTimeSolve"] > 0.0
+
+
 def _oracle_a(lo, hi):
     from oracle import mg
 
