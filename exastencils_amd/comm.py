@@ -23,7 +23,8 @@ from .field import Field
 
 
 class Communicator:
-    def __init__(self, domain: RectDomain, ops, group=None, concurrent_ghost_axes: bool = False):
+    def __init__(self, domain: RectDomain, ops, group=None, concurrent_ghost_axes: bool = False,
+                 consistent_duplicates: bool = False):
         """concurrent_ghost_axes: where the caller declares that only face ghosts will be read (`axis_only=True`:
         5/7-point stencil loops), send the ghost planes of all axes in ONE point-to-point batch instead of axis by axis.
         Face ghosts are identical; edge/corner ghosts -- which only the axis-by-axis order makes valid and which
@@ -31,6 +32,11 @@ class Communicator:
         number of dimensions."""
         self.domain, self.ops, self.group = domain, ops, group
         self.concurrent_ghost_axes = concurrent_ghost_axes
+        # consistent_duplicates: every loop of the multigrid programs computes the duplicate (shared) planes on BOTH blocks
+        # from the same inputs (iteration offsets 0 at interior faces) with the same kernel, i.e. to the same bits; the
+        # upstream duplicate exchange of `communicate` then rewrites values with themselves and can be left out.  Opt-in:
+        # a caller that writes one side only (external data, different arithmetic per block) must keep it.
+        self.consistent_duplicates = consistent_duplicates
         self.dist = None
         if domain.world_size > 1:
             import torch.distributed as dist
@@ -99,7 +105,7 @@ class Communicator:
             return   # single block, non-periodic: no neighbours, the generated exch function is empty
         lay, dom, nd = f.layout, self.domain, self.domain.nd
         x = f.data(slot)
-        if what in ("all", "dup") and lay.communicates_dup and max(lay.dup) > 0:
+        if what in ("all", "dup") and lay.communicates_dup and max(lay.dup) > 0 and not self.consistent_duplicates:
             for d in range(nd):
                 plus, minus = dom.neighbor(d, +1), dom.neighbor(d, -1)
                 sbox, rbox = self.dup_ranges(lay, nd, d)

@@ -73,7 +73,7 @@ def _worker_solver(rank, world, port, blocks, case, out_dir):
     ops = OracleOps()
     flen = tuple(2 // blocks[d] if d < 3 else 1 for d in range(3))
     dom = RectDomain(3, blocks, rank, flen)
-    comm = Communicator(dom, ops, concurrent_ghost_axes=case.endswith("_cg"))
+    comm = Communicator(dom, ops, concurrent_ghost_axes=case.endswith("_cg"), consistent_duplicates="_nodup" in case)
     if case in ("jacobi_l3", "jacobi_l3_tb", "jacobi_l3_tb_cg"):
         P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="jacobi", omega=0.8, stencil="unit",
                                   restrict_scale=4.0, tol=1e-5, cg_max=512, temporal_blocking="_tb" in case), ops, dom, comm)
@@ -132,7 +132,7 @@ def _reference_single(case):
 
 @pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"),
                                          ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
-                                         ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 2, 1), "rbgs_l4_cg"), ((2, 1, 1), "fmg_varcoeff"), ((2, 2, 1), "helmholtz27")])
+                                         ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 2, 1), "rbgs_l4_cg"), ((2, 2, 1), "rbgs_l4_nodup_cg"), ((2, 1, 1), "fmg_varcoeff"), ((2, 2, 1), "helmholtz27")])
 def test_decomposed_solve_matches_single_block(tmp_path, blocks, case):
     world = blocks[0] * blocks[1] * blocks[2]
     port = _free_port()
