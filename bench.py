@@ -314,7 +314,7 @@ def vcycle(ops, dom, comm, L, world):
 
     from exastencils_amd.solver import ConfigL4, SolverFromL4
 
-    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=(world == 1))
+    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True)
     P = SolverFromL4(cfg, ops, dom, comm)
     P.setup()
     P._update_residual(L)
@@ -358,7 +358,7 @@ def vcycle(ops, dom, comm, L, world):
         "solve_iterations": its,
         "solve_residual_reduction": (Q.res_history[-1] / Q.res_history[0]) if Q.res_history and Q.res_history[0] else None,
         "vcycle_graph": use_graph,
-        "vcycle_fused_rbgs": world == 1,
+        "vcycle_fused_rbgs": True,
     }
 
 

@@ -592,6 +592,41 @@ extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_
   return examg_rbgs_colour(lu, u_out, lf, rhs, st, w, 1 - first, begin, end, stream);
 }
 
+// One red-black sweep with separate boxes (blocks with neighbours): colour `first` on [begin1,end1) (points outside keep
+// u_in's value), then the other colour of that field on [begin2,end2), inside box 1; u_out receives the result on box 2.
+extern "C" int examg_rbgs_sweep_fused_boxes(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp,
+                                            const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w,
+                                            int first, const int32_t *begin1, const int32_t *end1, const int32_t *begin2,
+                                            const int32_t *end2, examg_stream_t stream) {
+  if (!lu || !u_in || !u_out || !lf || !rhs || !st || !begin1 || !end1 || !begin2 || !end2) { set_error("examg_rbgs_sweep_fused_boxes: null argument"); return 1; }
+  if (u_in == u_out) { set_error("examg_rbgs_sweep_fused_boxes: out of place only"); return 1; }
+  if (first != 0 && first != 1) { set_error("examg_rbgs_sweep_fused_boxes: first colour must be 0 or 1"); return 1; }
+  const Box box1 = make_box(begin1, end1), box2 = make_box(begin2, end2);
+  if (box2.count() == 0) return 0;
+  if (box2.b0 < box1.b0 || box2.b1 < box1.b1 || box2.b2 < box1.b2 || box2.e0 > box1.e0 || box2.e1 > box1.e1 || box2.e2 > box1.e2) {
+    set_error("examg_rbgs_sweep_fused_boxes: the second box must lie inside the first");
+    return 1;
+  }
+  if (two_stage_ok(lu, lf, st, box2) && box_inside(lu, box1, 1) && box_inside(lf, box1, 0))
+    return launch_two_stage<true>(lu, u_in, lf, rhs, u_out, st, w, first, box2, (hipStream_t)stream, &box1);
+  if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_rbgs_sweep_fused_boxes: fallback needs a distinct tmp array"); return 1; }
+  const int reach = stencil_reach(st);
+  int32_t b2[3], e2[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool on = d < lu->nd;
+    b2[d] = begin1[d] - (on ? reach : 0);
+    e2[d] = end1[d] + (on ? reach : 0);
+  }
+  int rc = examg_axpby(lu, u_in, lu, tmp, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_rbgs_colour(lu, tmp, lf, rhs, st, w, first, begin1, end1, stream);     // in place on the copy
+  if (rc) return rc;
+  rc = examg_axpby(lu, tmp, lu, u_out, 1.0, 0.0, begin2, end2, stream);
+  if (rc) return rc;
+  // other colour: reads the copy, writes that colour's points of u_out
+  return examg_stencil_op(EXAMG_SMOOTH, lu, tmp, lf, rhs, lu, u_out, st, w, 1 - first, begin2, end2, stream);
+}
+
 // Two Jacobi steps with separate boxes: stage 1 = J on [begin1,end1) (points outside keep u_in's value), stage 2 = J of
 // that field on [begin2,end2) (inside box 1), written to u_out.  A block with neighbours uses box 2 = box 1 minus the
 // duplicate planes at interior faces: everything stage 2 needs there is local (exastencils_amd/solver.py: Smoothers).

@@ -73,6 +73,12 @@ class HipOps:
                                             C.byref(sc), float(w), int(first), ivec(begin), ivec(end), self._stream()),
               "examg_rbgs_sweep_fused")
 
+    def rbgs_sweep_fused_boxes(self, lu, u_in, u_out, tmp, lf, rhs, st: Stencil, w: float, first: int, begin1, end1, begin2, end2):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_rbgs_sweep_fused_boxes(C.byref(lu), self.ptr(u_in), self.ptr(u_out), self.ptr(tmp) if tmp is not None else None,
+                                                  C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), int(first), ivec(begin1), ivec(end1),
+                                                  ivec(begin2), ivec(end2), self._stream()), "examg_rbgs_sweep_fused_boxes")
+
     def jacobi2(self, lu, u_in, u_out, tmp, lf, rhs, st: Stencil, w: float, begin, end):
         sc = st.c_struct(self.ptr)
         check(self.L.examg_jacobi2(C.byref(lu), self.ptr(u_in), self.ptr(u_out), self.ptr(tmp) if tmp is not None else None,

@@ -105,3 +105,88 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool =
         interior()
         shell()
     S.advance()
+
+
+def rbgs_sweep(ops, comm, domain, S, F, A, w: float, alt, tmp_field, first: int = 0, overlap: bool = True):
+    """One red-black sweep of `repeat { color with { (i0+i1+i2) % 2, communicate S; loop over S { S += w (F - A S) };
+    apply bc to S } }` (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:204-213) on a block WITH neighbours, out of place
+    from S's array into `alt`; returns the array that is free afterwards (S's former one) -- the two change roles.
+
+    Deep interior (loop box shrunk by one point for the first colour, two for the second): one fused pass that needs no
+    ghost value.  Two-point shell along the interior faces: exchange S, first colour on three planes into tmp, exchange
+    tmp, second colour on two planes into alt -- thin launches on a side stream, concurrent with the interior pass.
+    Both arrays and tmp carry S's Dirichlet values on the physical faces (caller: once, `apply bc` values are
+    position-only); results are bit-identical to the two in-place half sweeps."""
+    nd = domain.nd
+    b, e = domain.loop_bounds(S.layout)
+    src = S.data()
+    faces = [(d, side) for d in range(nd) for side in (-1, 1) if domain.neighbor(d, side) is not None]
+    axis_only = all(sum(1 for c in o if c != 0) <= 1 for o in A.offsets)
+    if not faces:
+        comm.exchange(S, None, "ghost", axis_only)
+        ops.rbgs_sweep_fused(S.lc, src, alt, F.lc, F.data(), A, w, first, b, e)
+        S.slots[S.active] = alt
+        return src
+
+    def shrunk(k):
+        bb, ee = list(b), list(e)
+        for d, side in faces:
+            if side < 0:
+                bb[d] = b[d] + k
+            else:
+                ee[d] = e[d] - k
+        return bb, ee
+
+    def slab(d, side, k):
+        sb, se = list(b), list(e)
+        if side < 0:
+            se[d] = min(b[d] + k, e[d])
+        else:
+            sb[d] = max(e[d] - k, b[d])
+        return sb, se
+
+    b1, e1 = shrunk(1)
+    b2, e2 = shrunk(2)
+    canonical7 = nd == 3 and A.cfield is None and len(A.offsets) == 7 and axis_only
+    fused = canonical7 and (e2[0] - b2[0]) >= 64
+
+    def interior(scratch):
+        if all(e2[d] > b2[d] for d in range(nd)):
+            ops.rbgs_sweep_fused_boxes(S.lc, src, alt, scratch, F.lc, F.data(), A, w, first, b1, e1, b2, e2)
+
+    def shell():
+        lay, tmp = S.layout, tmp_field.data()
+        comm.exchange(S, None, "ghost", axis_only)
+        for d in range(nd):                      # tmp's physical-face planes: S's (read tangentially by the second colour)
+            for side in (-1, 1):
+                if domain.neighbor(d, side) is not None:
+                    continue
+                pb = [lay.idx("DLB", t) if t < nd else 0 for t in range(3)]
+                pe = [lay.idx("DRE", t) if t < nd else 1 for t in range(3)]
+                pb[d], pe[d] = (lay.idx("DLB", d), lay.idx("DLE", d)) if side < 0 else (lay.idx("DRB", d), lay.idx("DRE", d))
+                ops.axpby(S.lc, src, S.lc, tmp, 1.0, 0.0, pb, pe)
+        for d, side in faces:                    # first colour on three planes: tmp = S, then the colour's points (reads S only)
+            sb, se = slab(d, side, 3)
+            ops.axpby(S.lc, src, S.lc, tmp, 1.0, 0.0, sb, se)
+            ops.stencil_op(SMOOTH, S.lc, src, F.lc, F.data(), S.lc, tmp, A, w, first, sb, se)
+        comm.exchange(tmp_field, None, "ghost", axis_only)
+        for d, side in faces:                    # second colour on two planes: alt = tmp, then the colour's points (reads tmp only)
+            sb, se = slab(d, side, 2)
+            ops.axpby(S.lc, tmp, S.lc, alt, 1.0, 0.0, sb, se)
+            ops.stencil_op(SMOOTH, S.lc, tmp, F.lc, F.data(), S.lc, alt, A, w, 1 - first, sb, se)
+
+    side_stream = ops.side_stream() if (overlap and fused and hasattr(ops, "side_stream")) else None
+    if side_stream is not None:
+        torch = ops.torch
+        main = torch.cuda.current_stream(ops.device)
+        side_stream.wait_stream(main)
+        with torch.cuda.stream(side_stream):
+            shell()
+        interior(None)
+        main.wait_stream(side_stream)
+    else:
+        # the fallback of the fused pass uses tmp as scratch for its first half sweep: it finishes before the shell writes tmp
+        interior(tmp_field.data())
+        shell()
+    S.slots[S.active] = alt
+    return src

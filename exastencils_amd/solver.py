@@ -129,6 +129,7 @@ class SolverFromL4(_Program):
         self.Residual: Dict[int, Field] = {}
         self.Laplace: Dict[int, Stencil] = {}
         self._sol_alt: Dict[int, object] = {}
+        self._sweep_tmp: Dict[int, Field] = {}
         for l in self.levels:
             nc = dom.ncells(l)
             with_comm = FieldLayout.node(nd, nc, 1, True, True, cfg.align)     # Layout NodeWithComm (...exa4:13-16)
@@ -230,6 +231,17 @@ class SolverFromL4(_Program):
                 alt = self._sol_alt[l]
                 self.ops.rbgs_sweep_fused(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e)
                 self._sol_alt[l], S.slots[0] = S.slots[0], alt
+            return
+        if self.cfg.fused_rbgs:
+            # blocks with neighbours: fused deep interior + two-point shell with its two exchanges on a side stream
+            # (exastencils_amd/smoothers.py: rbgs_sweep); the three arrays carry the Dirichlet planes of the physical faces
+            from .smoothers import rbgs_sweep
+
+            tmp = self._sweep_tmp.get(l)
+            if tmp is None:
+                tmp = self._sweep_tmp[l] = Field("SolutionSweepTmp", l, S.layout, self.ops, 1, S.bc_fn, S.bc_params)
+            for _ in range(self.cfg.n_smooth):
+                self._sol_alt[l] = rbgs_sweep(self.ops, self.comm, self.domain, S, F, A, w, self._sol_alt[l], tmp, 0)
             return
         for _ in range(self.cfg.n_smooth):
             for colour in (0, 1):

@@ -134,6 +134,17 @@ int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_in, double 
                            const double *rhs, const examg_stencil_t *st, double w, int first, const int32_t *begin,
                            const int32_t *end, examg_stream_t stream);
 
+/* As examg_rbgs_sweep_fused with separate boxes, for blocks with neighbours: colour `first` on [begin1,end1) (points
+ * outside keep u_in's value), then the other colour of that field on [begin2,end2), inside box 1; u_out receives both
+ * colours on box 2 and is not touched elsewhere.  Box 1 = the loop's box shrunk by one point at interior faces, box 2 by
+ * two: everything inside is independent of the halo exchange between the two half sweeps
+ * (communicate inside `color with`, Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:204-213).  `tmp` is used by the fallback
+ * path only (general stencils, short rows) and may be NULL otherwise. */
+int examg_rbgs_sweep_fused_boxes(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp,
+                                 const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w, int first,
+                                 const int32_t *begin1, const int32_t *end1, const int32_t *begin2, const int32_t *end2,
+                                 examg_stream_t stream);
+
 /* Two Jacobi steps (Smoother called twice, Testing/Smoothers/Jac.exa4:125-131) in ONE pass: temporal blocking in the
  * sense of baseExt/ir/IR_ContractingLoop.scala.  u_out[box] = J(J(u_in)); bit-identical to two examg_jacobi calls
  * u_in -> tmp -> u_out.  Only valid when no halo exchange is needed between the two steps (single block, or ghost

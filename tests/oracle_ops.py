@@ -83,6 +83,12 @@ class OracleOps:
         for c in (first, 1 - first):
             self.stencil_op(2, lu, u_out, lf, rhs, lu, u_out, st, w, c, begin, end)
 
+    def rbgs_sweep_fused_boxes(self, lu, u_in, u_out, tmp, lf, rhs, st, w, first, begin1, end1, begin2, end2):
+        tmp.copy_(u_in)
+        self.stencil_op(2, lu, tmp, lf, rhs, lu, tmp, st, w, first, begin1, end1)
+        self.axpby(lu, tmp, lu, u_out, 1.0, 0.0, begin2, end2)
+        self.stencil_op(2, lu, tmp, lf, rhs, lu, u_out, st, w, 1 - first, begin2, end2)
+
     def jacobi2(self, lu, u_in, u_out, tmp, lf, rhs, st, w, begin, end):
         self.stencil_op(2, lu, u_in, lf, rhs, lu, tmp, st, w, -1, begin, end)
         self.stencil_op(2, lu, tmp, lf, rhs, lu, u_out, st, w, -1, begin, end)

@@ -236,6 +236,30 @@ def test_jacobi2_boxes_bit_exact(hip, orc, two_stage_variant, shape, b, e, b2, e
     assert_same(g, c, "jacobi2_boxes")
 
 
+@pytest.mark.parametrize("first", [0, 1])
+@pytest.mark.parametrize("shape,b1,e1,b2,e2", [
+    ((150, 36, 40), [1, 1, 1], [150, 36, 40], [2, 1, 2], [149, 36, 39]),     # neighbours in x and z
+    ((130, 70, 33), [1, 1, 1], [130, 71, 33], [1, 2, 1], [130, 71, 33]),     # lower y neighbour only
+    ((40, 20, 20), [1, 1, 1], [41, 20, 20], [2, 1, 1], [41, 20, 20]),        # short rows: fallback path
+])
+def test_rbgs_sweep_fused_boxes_bit_exact(hip, orc, two_stage_variant, shape, b1, e1, b2, e2, first):
+    """Red-black sweep of a block with neighbours: first colour on the box shrunk by one point at interior faces, second
+    colour on the box shrunk by two; u_out is written on the second box only (exastencils_amd/smoothers.py: rbgs_sweep)."""
+    st = laplace_fd(3, tuple(1.0 / s_ for s_ in shape))
+
+    def f(ops):
+        lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+        u, fr, out, tmp = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size)
+        ops.fill_random(u, 12345)
+        ops.fill_random(fr, 4711)
+        ops.fill_random(out, 5)
+        ops.rbgs_sweep_fused_boxes(lu.c_struct(), u, out, tmp, lf.c_struct(), fr, st, 0.8 / st.diag, first, b1, e1, b2, e2)
+        return [out]
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "rbgs_sweep_fused_boxes")
+
+
 def test_two_stage_fallback_small_and_2d(hip, orc):
     """Boxes the fused kernel does not take (rows < 64 points) go through copy + two loops: same result."""
     n = 24

@@ -212,6 +212,43 @@ def test_jacobi_pair_overlap_equals_sequential(hip, rank):
     assert np.array_equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("rank", [0, 5])
+def test_rbgs_sweep_overlap_equals_sequential(hip, rank):
+    """rbgs_sweep on a block with interior faces (2x2x2 decomposition, loop-back neighbours): fused deep interior with the
+    shell's exchanges on the side stream == sequential order == the two in-place half sweeps with an exchange before each."""
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.field import Field, laplace_fd
+    from exastencils_amd.layout import FieldLayout
+    from exastencils_amd.smoothers import rbgs_sweep
+
+    dom = RectDomain(3, (2, 2, 2), rank)
+    L = 7
+    lay, layf = FieldLayout.node(3, dom.ncells(L), 1), FieldLayout.node(3, dom.ncells(L), 0, True, False)
+    A = laplace_fd(3, dom.h(L))
+    w = 0.8 / A.diag
+    b, e = dom.loop_bounds(lay)
+    outs = []
+    for mode in ("overlap", "sequential", "plain"):
+        S, F, T = Field("S", L, lay, hip, 1, None), Field("F", L, layf, hip, 1, None), Field("T", L, lay, hip, 1, None)
+        hip.fill_random(S.data(), 1)
+        alt = S.data().clone()          # the second array and the scratch field carry the same boundary planes
+        hip.fill_random(F.data(), 3)
+        comm = _LoopbackComm(dom, hip)
+        for _ in range(3):
+            if mode == "plain":
+                for colour in (0, 1):
+                    comm.exchange(S, None, "ghost")
+                    hip.stencil_op(2, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, w, colour, b, e)
+            else:
+                alt = rbgs_sweep(hip, comm, dom, S, F, A, w, alt, T, 0, overlap=(mode == "overlap"))
+        hip.synchronize()
+        v = hip.to_host(S.data()).reshape(lay.shape_zyx)
+        outs.append(v[b[2] + 1:e[2] + 1, b[1] + 1:e[1] + 1, b[0] + 1:e[0] + 1].copy())
+        assert comm.calls > 0
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[2])
+
+
 def test_config4_helmholtz27_on_gpu(hip):
     """27-entry variable-coefficient Helmholtz V-cycles (config 4's operator) against the oracle program."""
     from test_host_logic import HELMHOLTZ27

@@ -9,7 +9,7 @@ from exastencils_amd.domain import RectDomain
 from exastencils_amd.field import Field, laplace_fd
 from exastencils_amd.layout import FieldLayout
 from exastencils_amd.ops import HipOps
-from exastencils_amd.smoothers import jacobi_pair
+from exastencils_amd.smoothers import jacobi_pair, rbgs_sweep
 from exastencils_amd.comm import Communicator
 
 
@@ -51,3 +51,23 @@ for blocks, rank in (((1, 1, 1), 0), ((2, 1, 1), 0), ((2, 2, 2), 0), ((2, 2, 2),
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         print("blocks %s rank %d overlap %d: %.3f ms per pair = %.3f ms per step" % (blocks, rank, overlap, dt * 1e3, dt * 5e2), flush=True)
+    # red-black sweep of the V-cycle program: fused interior + shell against the two in-place half sweeps
+    alt = S.data().clone()
+    b, e = dom.loop_bounds(lay)
+    for mode in ("plain", "sequential", "overlap"):
+        def sweep():
+            global alt
+            if mode == "plain":
+                for colour in (0, 1):
+                    comm.exchange(S, None, "ghost")
+                    ops.stencil_op(2, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, w, colour, b, e)
+            else:
+                alt = rbgs_sweep(ops, comm, dom, S, F, A, w, alt, T, 0, overlap=(mode == "overlap"))
+        for _ in range(5):
+            sweep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); n = 50
+        for _ in range(n):
+            sweep()
+        torch.cuda.synchronize()
+        print("blocks %s rank %d red-black sweep, %s: %.3f ms" % (blocks, rank, mode, (time.perf_counter() - t0) / n * 1e3), flush=True)
