@@ -314,7 +314,9 @@ def vcycle(ops, dom, comm, L, world):
 
     from exastencils_amd.solver import ConfigL4, SolverFromL4
 
-    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True)
+    # more than one block: the three coarsest levels are gathered and solved redundantly on every rank (solver.py: _agg_cycle)
+    agg = L - 3 if world > 1 else None
+    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, agglomerate_level=agg)
     P = SolverFromL4(cfg, ops, dom, comm)
     P.setup()
     P._update_residual(L)
@@ -359,6 +361,7 @@ def vcycle(ops, dom, comm, L, world):
         "solve_residual_reduction": (Q.res_history[-1] / Q.res_history[0]) if Q.res_history and Q.res_history[0] else None,
         "vcycle_graph": use_graph,
         "vcycle_fused_rbgs": True,
+        "vcycle_agglomerate_level": agg,
     }
 
 

@@ -116,6 +116,7 @@ class ConfigL4:
     align: int = 0
     fused_coarse: bool = True     # single block: mgCycle@coarsest as one persistent kernel
     fused_rbgs: bool = False      # one-pass red-black sweep (out of place, pointer swap)
+    agglomerate_level: Optional[int] = None   # blocks > 1: levels <= this are solved redundantly on every rank (see _agg_cycle)
 
 
 class SolverFromL4(_Program):
@@ -144,6 +145,55 @@ class SolverFromL4(_Program):
         self.cgTmp0 = Field("cgTmp0", lo, FieldLayout.node(nd, nc, 1, True, True, cfg.align), ops, 1, FN_ZERO)   # :32
         self.cgTmp1 = Field("cgTmp1", lo, FieldLayout.node(nd, nc, 0, True, False, cfg.align), ops, 1, None)     # :33
         self._cg_info = ops.new_array(4)
+        self._agg = None
+        k = cfg.agglomerate_level
+        if k is not None and dom.world_size > 1 and lo <= k < hi:
+            # The coarse levels of a decomposed hierarchy are latency-bound (a 64^3 block per GPU and six exchanges per
+            # sweep): from level k down every rank gathers the whole level (one all-gather of the restricted right-hand
+            # side, a few MB over xGMI) and runs the remaining cycle on it as ONE block -- fused sweeps, persistent CG
+            # kernel, no further communication -- then keeps its own part of the correction.  Same statements as the
+            # distributed cycle; only the order in which the coarse-grid CG's reductions add differs.
+            whole = RectDomain(nd, (1, 1, 1), 0, tuple(dom.num_blocks[d] * dom.frag_len[d] for d in range(3)), dom.lo, dom.hi)
+            acfg = ConfigL4(nd=nd, min_level=lo, max_level=k, frag_len=whole.frag_len, omega=cfg.omega, n_smooth=cfg.n_smooth,
+                            cg_max=cfg.cg_max, cg_tol=cfg.cg_tol, bc_fn=FN_ZERO, align=cfg.align, fused_coarse=True,
+                            fused_rbgs=cfg.fused_rbgs)
+            self._agg = SolverFromL4(acfg, ops, whole, Communicator(whole, ops))
+            self._agg.setup()
+            nc = dom.ncells(k)
+            n_own = 1
+            n_halo = 1
+            for d in range(nd):
+                n_own *= nc[d] + 1
+                n_halo *= nc[d] + 3
+            self._agg_send = ops.new_array(n_own)
+            self._agg_recv = [ops.new_array(n_own) for _ in range(dom.world_size)]
+            self._agg_back = ops.new_array(n_halo)
+
+    def _agg_cycle(self, k: int):
+        dom, ops, A = self.domain, self.ops, self._agg
+        nd, nc = dom.nd, dom.ncells(k)
+        F, S = self.RHS[k], self.Solution[k]
+        own_b = [0, 0, 0]
+        own_e = [nc[d] + 1 if d < nd else 1 for d in range(3)]
+        ops.pack(F.lc, F.data(), self._agg_send, own_b, own_e)
+        self.comm.dist.all_gather(self._agg_recv, self._agg_send, group=self.comm.group)
+        AF, AS = A.RHS[k], A.Solution[k]
+        for r in range(dom.world_size):
+            pos = RectDomain(nd, dom.num_blocks, r, dom.frag_len).pos
+            gb = [pos[d] * nc[d] if d < nd else 0 for d in range(3)]
+            ge = [gb[d] + nc[d] + 1 if d < nd else 1 for d in range(3)]
+            ops.unpack(AF.lc, AF.data(), self._agg_recv[r], gb, ge)
+        b, e = A.bounds(AS)
+        ops.set(AS.lc, AS.data(), 0.0, b, e)
+        A.apply_bc(AS)
+        A.mgCycle(k)
+        # own part of the correction, ghost layers included (the neighbours' inner planes come straight from the whole level)
+        lb = [-S.layout.ghost[d] if d < nd else 0 for d in range(3)]
+        le = [nc[d] + 1 + S.layout.ghost[d] if d < nd else 1 for d in range(3)]
+        gb = [dom.pos[d] * nc[d] + lb[d] if d < nd else 0 for d in range(3)]
+        ge = [dom.pos[d] * nc[d] + le[d] if d < nd else 1 for d in range(3)]
+        ops.pack(AS.lc, AS.data(), self._agg_back, gb, ge)
+        ops.unpack(S.lc, S.data(), self._agg_back, lb, le)
 
     # Function ResNorm@(coarsest and finest) : Real  (...exa4:113-119)
     def ResNorm(self, l: int) -> float:
@@ -251,6 +301,8 @@ class SolverFromL4(_Program):
 
     # Function mgCycle@(all but coarsest) (...exa4:203-249)
     def mgCycle(self, l: int):
+        if self._agg is not None and l == self.cfg.agglomerate_level:
+            return self._agg_cycle(l)
         if l == self.cfg.min_level:
             return self.mgCycle_coarsest(l)
         ops = self.ops

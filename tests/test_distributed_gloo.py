@@ -88,7 +88,7 @@ def _worker_solver(rank, world, port, blocks, case, out_dir):
         P = SolverFromL3(ConfigL3(**HELMHOLTZ27, frag_len=flen), ops, dom, comm)
     else:
         P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, frag_len=flen, tol=1e-6, fused_coarse=False,
-                                  fused_rbgs="_fused" in case), ops, dom, comm)
+                                  fused_rbgs="_fused" in case, agglomerate_level=2 if "_agg" in case else None), ops, dom, comm)
     P.setup()
     P.Solve()
     S = P.Solution[4]
@@ -134,7 +134,8 @@ def _reference_single(case):
 @pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"),
                                          ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
                                          ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 2, 1), "rbgs_l4_cg"), ((2, 2, 1), "rbgs_l4_nodup_cg"), ((2, 1, 1), "rbgs_l4_fused"),
-                                         ((2, 2, 1), "rbgs_l4_fused_nodup_cg"), ((2, 1, 1), "fmg_varcoeff"), ((2, 2, 1), "helmholtz27")])
+                                         ((2, 2, 1), "rbgs_l4_fused_nodup_cg"), ((2, 1, 1), "rbgs_l4_agg"),
+                                         ((2, 2, 1), "rbgs_l4_fused_agg_nodup_cg"), ((2, 1, 1), "fmg_varcoeff"), ((2, 2, 1), "helmholtz27")])
 def test_decomposed_solve_matches_single_block(tmp_path, blocks, case):
     world = blocks[0] * blocks[1] * blocks[2]
     port = _free_port()
