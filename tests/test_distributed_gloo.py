@@ -215,3 +215,41 @@ def test_corner_ghosts_with_six_neighbours(tmp_path):
         mask = np.zeros_like(want, dtype=bool)
         mask[max(1 - z0, 0):min(n, z1) - z0, max(1 - y0, 0):min(n, y1) - y0, max(1 - x0, 0):min(n, x1) - x0] = True
         assert np.array_equal(v[mask], want[mask])
+
+
+# -------------------------------------------------------------------------------------------------
+def _worker_bench_vcycle(rank, world, port, out_dir):
+    """bench.py's V-cycle leg exactly as it runs at N > 1 (fused sweeps with shells, agglomerated coarse levels, Solve
+    from the zero state), with the oracle's loops standing in for the kernels and gloo for RCCL."""
+    _init(rank, world, port)
+    import bench
+    from oracle_ops import OracleOps
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+
+    torch.cuda.synchronize = lambda *a, **k: None      # CPU stand-in: nothing is asynchronous here
+    ops = OracleOps()
+    dom = RectDomain(3, RectDomain.blocks_for(world, 3), rank)
+    comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
+    out = bench.vcycle(ops, dom, comm, 6, world)
+    json.dump(out, open(os.path.join(out_dir, "v_%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_vcycle_leg_on_two_blocks(tmp_path):
+    from oracle import mg
+
+    port = _free_port()
+    mp.spawn(_worker_bench_vcycle, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # the same global problem on one block: 2 x 1 x 1 blocks of 64^3 cells = one fragment of 128 x 64 x 64 cells
+    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=1, max_level=6, tol=1e-6, nfrag=(1, 1, 1), frag_len=(2, 1, 1)))
+    O.setup()
+    O.Solve()
+    for r in range(2):
+        v = json.load(open(tmp_path / ("v_%d.json" % r)))
+        assert v["vcycle_agglomerate_level"] == 3 and v["vcycle_fused_rbgs"]
+        assert v["solve_iterations"] == O.iterations
+        want = O.res_history[-1] / O.res_history[0]
+        assert abs(v["solve_residual_reduction"] - want) <= 1e-8 * want
