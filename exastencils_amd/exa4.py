@@ -1269,8 +1269,9 @@ class Exa4Program:
         both half sweeps in one pass (examg_rbgs_sweep_fused), out of place into a second array that carries the same
         boundary shell, then the two arrays change roles.  `apply bc` re-writes position-only Dirichlet values the sweep
         never touches, so it is a no-op here."""
-        if self.domain.world_size != 1:
-            return False
+        multi = self.domain.world_size != 1
+        if multi and not any(st[0] == "comm" and st[2] in ("all", "ghost") for st in body):
+            return False        # blocks with neighbours: the fused form contains the exchanges of the statement list
         loops = [st for st in body if st[0] == "loop"]
         if len(loops) != 1 or any(st[0] not in ("loop", "comm", "applybc") for st in body):
             return False
@@ -1282,6 +1283,8 @@ class Exa4Program:
             return False
         D, ds, U, us, F, fs, A, w = m
         if D is not U or ds != us or not self._canonical7(A, self.nd) or U.layout.inner[0] < self.fuse_min_row:
+            return False
+        if multi and U.num_slots != 1:
             return False
         for st in body:
             if st[0] in ("comm", "applybc") and self._field(st[-1], fr)[0] is not U:
@@ -1301,6 +1304,15 @@ class Exa4Program:
             self._alt_shell[key] = self._bc_epoch.get((U.name, U.level), 0)
             self.launches += 1
         self.launches += 1
+        if multi:
+            # fused deep interior + two-point shell with its exchanges on a side stream (exastencils_amd/smoothers.py)
+            from .smoothers import rbgs_sweep
+
+            tmp = self._pair_tmp.get((U.name, U.level))
+            if tmp is None:
+                tmp = self._pair_tmp[(U.name, U.level)] = Field(U.name + "Tmp", U.level, U.layout, self.ops, 1, None)
+            self._alt[key] = rbgs_sweep(self.ops, self.comm, self.domain, U, F, A, w, alt, tmp, first)
+            return True
         self.ops.rbgs_sweep_fused(U.lc, U.data(us), alt, F.lc, F.data(fs), A, w, first, b, e)
         self._alt[key], U.slots[us] = U.slots[us], alt
         return True
