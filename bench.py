@@ -92,6 +92,7 @@ def cpu_baseline(seconds: float):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between the ranks of this host
     import torch
     import torch.distributed as dist
 
