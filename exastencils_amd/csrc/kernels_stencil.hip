@@ -85,6 +85,48 @@ k_stencil_generic(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
   }
 }
 
+
+// Stencil fields with a fixed entry count, fully unrolled: all NENT coefficient loads and all NENT u loads of a point are
+// in flight together -- the run-time loop of the generic kernel keeps two loads in flight per thread, too few to cover the
+// HBM latency at 8 + 8*NENT bytes per point.  Same products in the same order as the generic kernel.  Measured at 512^3,
+// 27 entries (tools/varcoeff_times.py): 8.6 -> 7.3 ms per Jacobi step; non-temporal coefficient loads 7.5 ms (not used).
+struct UOffsets {
+  long long o[EXAMG_MAX_ENTRIES];
+};
+
+template <int MODE, int NENT>
+__global__ void __launch_bounds__(256)
+k_stencilfield_unrolled(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev ld,
+                        double *__restrict__ dst, LayoutDev lc, const double *__restrict__ cf, long long cplane, UOffsets uo, int diag,
+                        double w, Box box) {
+  const int n0 = box.n0();
+  const long long rows = (long long)box.n1() * box.n2();
+  const long long total = rows * n0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long row = t / n0;
+    const int i0 = box.b0 + (int)(t - row * n0);
+    const int i1 = box.b1 + (int)(row % box.n1());
+    const int i2 = box.b2 + (int)(row / box.n1());
+    const long long iu = lidx(lu, i0, i1, i2), ic = lidx(lc, i0, i1, i2);
+    double c[NENT], v[NENT];
+#pragma unroll
+    for (int k = 0; k < NENT; ++k) c[k] = cf[ic + k * cplane];
+#pragma unroll
+    for (int k = 0; k < NENT; ++k) v[k] = u[iu + uo.o[k]];
+    double acc = c[0] * v[0];
+#pragma unroll
+    for (int k = 1; k < NENT; ++k) acc = acc + c[k] * v[k];
+    if (MODE == EXAMG_SMOOTH) {
+      // the centre entry comes first (dispatch condition): c[0] is the diagonal, v[0] the point's own value; a run-time
+      // index into c[] would push the whole array to scratch memory
+      const double ww = (1.0 / c[0]) * w;
+      acc = v[0] + ww * (rhs[lidx(lf, i0, i1, i2)] - acc);
+    }
+    if (MODE == EXAMG_RESIDUAL) acc = rhs[lidx(lf, i0, i1, i2)] - acc;
+    dst[lidx(ld, i0, i1, i2)] = acc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3-D 7-point constant-coefficient z-marching kernel
 // ---------------------------------------------------------------------------------------------
@@ -266,6 +308,7 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
 }
 
 static int g_force_generic = 0;  // test hook: examg_debug_force_generic
+static int g_sf27_unrolled = 1;  // examg_debug_sf27(0): 27-entry stencil fields on the generic kernel
 
 // kernels_stencilfield.hip
 bool stencilfield7_ok(const examg_layout_t *lu, const examg_stencil_t *st, const Box &box, int colour);
@@ -367,6 +410,11 @@ static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev 
 
 using namespace examg;
 
+extern "C" int examg_debug_sf27(int unrolled) {
+  g_sf27_unrolled = unrolled;
+  return 0;
+}
+
 extern "C" int examg_debug_force_generic(int on) {
   const int old = g_force_generic;
   g_force_generic = on;
@@ -434,6 +482,23 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   if (!g_force_generic && stencilfield7_ok(lu_, st, box, colour)) {
     const LayoutDev lcf = make_layout(&st->clayout);
     return launch_stencilfield7(mode, lu, u, lf, rhs, ld, dst, lcf, st->cfield, w, box, s);
+  }
+
+  if (!g_force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
+      st->off[0][1] == 0 && st->off[0][2] == 0) {
+    const LayoutDev lc27 = make_layout(&st->clayout);
+    UOffsets uo;
+    for (int k = 0; k < 27; ++k) uo.o[k] = st->off[k][0] + lu.s1 * st->off[k][1] + lu.s2 * st->off[k][2];
+    long long nb27 = (box.count() + 255) / 256;
+    if (nb27 > 16384) nb27 = 16384;
+    dim3 grid27((unsigned)nb27), block27(256);
+#define EXAMG_SF27(M) hipLaunchKernelGGL((k_stencilfield_unrolled<M, 27>), grid27, block27, 0, s, lu, u, lf, rhs, ld, dst, lc27, st->cfield, lc27.size, uo, 0, w, box)
+    if (mode == EXAMG_APPLY) EXAMG_SF27(EXAMG_APPLY);
+    else if (mode == EXAMG_RESIDUAL) EXAMG_SF27(EXAMG_RESIDUAL);
+    else EXAMG_SF27(EXAMG_SMOOTH);
+#undef EXAMG_SF27
+    EXAMG_CHECK_LAUNCH("k_stencilfield_unrolled");
+    return 0;
   }
 
   StencilDev sd;

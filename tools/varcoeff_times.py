@@ -43,11 +43,13 @@ for name, offs in (("7-entry", stencil_field_offsets(3)), ("27-entry", helmholtz
     ops.fill_random(cf, 3)
     cf += 3.0
     st = Stencil(offs, [], cf, lf)
-    variants = [(-1, 2048)] + ([(v, bl) for v in (0, 1, 2, 3) for bl in (1024, 2048, 4096)] if K == 7 else [])
+    variants = [(-1, 2048)] + ([(v, bl) for v in (0, 1, 2, 3) for bl in (1024, 2048, 4096)] if K == 7 else [(-2, 0)])
     for mode, mname in ((2, "jacobi"), (1, "residual")):
         for variant, blocks in variants:
             if K == 7:
                 ops.L.examg_debug_stencilfield(variant, blocks)
+            else:
+                ops.L.examg_debug_sf27(1 if variant == -2 else 0)      # -1: generic kernel, -2: unrolled kernel
             ms = timeit(lambda: ops.stencil_op(mode, lu.c_struct(), u, lf.c_struct(), f, lu.c_struct(), un, st, 0.8, -1, b, e))
             bpl = 24 + 8 * K
             print("%-9s %-9s variant %2d blocks %4d n=%d  %.4f ms  %.3e LU/s  %.0f GB/s algorithmic (%d B/LU)"
