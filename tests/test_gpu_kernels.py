@@ -603,3 +603,41 @@ def test_init_helmholtz27(hip, orc):
 
     g, c = both(hip, orc, f)
     assert np.allclose(g[0], c[0], rtol=1e-13, atol=0.0)      # exp() through device libm
+
+
+def test_fused_kernels_on_a_large_odd_block(hip):
+    """640^3 cells (2.1 GB per array, byte offsets beyond 2^31, a size that is no power of two): the fused two-step kernel,
+    the fused red-black sweep and the wide restriction equal their unfused forms bit for bit (GPU against GPU; the oracle
+    covers the unfused forms at sizes it finishes in seconds)."""
+    import torch
+
+    n = 640
+    lu, lf, lc = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0), FieldLayout.node(3, (n // 2,) * 3, 0)
+    u, a, b_, t = (hip.new_array(lu.size) for _ in range(4))
+    f, fc1, fc2 = hip.new_array(lf.size), hip.new_array(lc.size), hip.new_array(lc.size)
+    hip.fill_random(u, 1)
+    hip.fill_random(f, 2)
+    A = laplace_fd(3, (1.0 / n,) * 3)
+    w = 0.8 / A.diag
+    b, e = box(3, n)
+    L, F, Lc = lu.c_struct(), lf.c_struct(), lc.c_struct()
+    t.copy_(u)
+    a.copy_(u)
+    b_.copy_(u)
+    hip.stencil_op(SMOOTH, L, u, F, f, L, t, A, w, -1, b, e)
+    hip.stencil_op(SMOOTH, L, t, F, f, L, a, A, w, -1, b, e)
+    hip.jacobi2(L, u, b_, None, F, f, A, w, b, e)
+    assert torch.equal(a, b_)
+    a.copy_(u)
+    for c in (0, 1):
+        hip.stencil_op(SMOOTH, L, a, F, f, L, a, A, w, c, b, e)
+    hip.rbgs_sweep_fused(L, u, b_, F, f, A, w, 0, b, e)
+    assert torch.equal(a, b_)
+    bc, ec = box(3, n // 2)
+    hip.restrict(L, u, Lc, fc1, 1.0, bc, ec)
+    hip.L.examg_debug_restrict(0)
+    try:
+        hip.restrict(L, u, Lc, fc2, 1.0, bc, ec)
+    finally:
+        hip.L.examg_debug_restrict(1)
+    assert torch.equal(fc1, fc2)
