@@ -230,6 +230,10 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   // threadIdx.y is the same for all lanes of a wave: as a scalar it keeps row predicates and LDS row addresses on the SALU
   const int lane = threadIdx.x, wv = TS_SCALAR_WV ? __builtin_amdgcn_readfirstlane(threadIdx.y) : threadIdx.y;
   int t = blockIdx.x;
+  if (g.remap) {  // XCD-contiguous tile order (workgroups are dealt round-robin to the 8 XCDs): neighbouring tiles share an L2
+    const int per = g.nblocks >> 3;
+    if (t < (per << 3)) t = (t & 7) * per + (t >> 3);
+  }
   const int tx = t % g.ntx;
   t /= g.ntx;
   const int ty = t % g.nty;
@@ -514,7 +518,7 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   g.zc = zc;
   g.ntz = (box.n2() + zc - 1) / zc;
   g.nblocks = xy * g.ntz;
-  g.remap = 0;
+  g.remap = g_ts_remap;
   g.first = first;
   g.box1 = box1;
   g.ax0 = -lu.ref0; g.ax1 = lu.tot0 - lu.ref0;

@@ -25,7 +25,7 @@ res = []
 for kind in ("jacobi2", "rbgs"):
     ref = None
     configs = [(0, 8, 0, 4096)]
-    configs += [(nw, 0, 0, blocks) for nw in (4, 5, 6, 7, 8, 16) for blocks in (512, 1024, 2048, 3072, 4096, 6144)]
+    configs += [(nw, 0, remap, blocks) for nw in (5, 8) for remap in (0, 1) for blocks in (2048, 3072, 4096)]
     for lds, wy, remap, blocks in configs:
         L.examg_debug_two_stage_lds(lds)
         L.examg_debug_two_stage(0, blocks, remap, wy if wy else 8)
