@@ -317,7 +317,7 @@ def vcycle(ops, dom, comm, L, world):
 
     # more than one block: the three coarsest levels are gathered and solved redundantly on every rank (solver.py: _agg_cycle)
     agg = L - 3 if world > 1 else None
-    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, agglomerate_level=agg)
+    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True, agglomerate_level=agg)
     P = SolverFromL4(cfg, ops, dom, comm)
     P.setup()
     P._update_residual(L)

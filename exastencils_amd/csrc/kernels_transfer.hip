@@ -119,6 +119,93 @@ k_restrict3_wide(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, d
   }
 }
 
+// RHS@coarser = scale * R * (rhs - A u) in ONE pass: residual (3-D 7-point constant coefficients) and full-weighting
+// restriction fused, the fine residual is never written or re-read (48 + 8 B per fine point -> 16 B).  Lane l of a tile
+// computes the residuals of the fine pair (2I, 2I+1), I = first + l - 1, on the three fine rows 2J-1..2J+1 of its coarse row J,
+// marching in fine z with u[p-1], u[p], u[p+1] in registers; fine plane 2K+1 serves coarse planes K and K+1.  Lanes 1..63
+// produce a coarse value (lane 0 only supplies r(2I-1) to lane 1 through the DPP shift), tiles advance by 63 points.
+// Every residual is the expression of the residual kernel, the 27 products are added in k_restrict's order: bit-identical
+// to examg_residual followed by examg_restrict.
+template <int ORDER>
+__global__ void __launch_bounds__(256)
+k_residual_restrict3(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ f, LayoutDev lc,
+                     double *__restrict__ fc, Coef7 k, double scale, Box box, int ntx, int zc, int nwaves) {
+  const int lane = threadIdx.x;
+  long long t = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+  if (t >= nwaves) return;
+  const int n1 = box.n1();
+  const int J = box.b1 + (int)(t % n1);        // consecutive waves of a workgroup: consecutive coarse rows (shared fine rows)
+  t /= n1;
+  const int tx = (int)(t % ntx);
+  const int kb = box.b2 + (int)(t / ntx) * zc;
+  const int ke = min(kb + zc, box.e2);
+  int I = box.b0 + tx * 63 + lane - 1;
+  const bool valid = lane >= 1 && I < box.e0;
+  if (I >= box.e0) I = box.e0 - 1;
+  const bool edge = lane == 63 || I == box.e0 - 1;   // the x+1 neighbour of the pair's second point is in no lane
+  const double *ur[5], *fr[3];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) ur[r] = u + lu.origin + 2 * I + lu.s1 * (2 * J - 2 + r);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) fr[r] = f + lf.origin + 2 * I + lf.s1 * (2 * J - 1 + r);
+  double *out = fc + lc.origin + I + lc.s1 * J;
+  const double w1[3] = {0.25, 0.5, 0.25};
+
+  d2 U[3][5];   // fine planes p-1, p, p+1; rows 2J-2 .. 2J+2
+  d2 R[3][3];   // residual planes 2K-1, 2K, 2K+1; rows 2J-1 .. 2J+1
+  auto load_plane = [&](d2 (&P)[5], int p) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r) P[r] = load2(ur[r] + lu.s2 * p);
+  };
+  auto residual_plane = [&](d2 (&out_r)[3], int p) {      // needs U = planes p-1, p, p+1
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const d2 c = U[1][b + 1], ym = U[1][b], yp = U[1][b + 2], zm = U[0][b + 1], zp = U[2][b + 1];
+      const d2 fv = load2(fr[b] + lf.s2 * p);
+      const double xl = lane_below(c.y);
+      double xr = lane_above(c.x);
+      if (edge) xr = ur[b + 1][lu.s2 * p + 2];
+      const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, ym.x, yp.x, zm.x, zp.x);
+      const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, ym.y, yp.y, zm.y, zp.y);
+      out_r[b].x = fv.x - acc_a;      // lane 0's first point has no valid x-1 neighbour: its value is never used
+      out_r[b].y = fv.y - acc_b;
+    }
+  };
+  // residual plane 2kb-1
+  load_plane(U[0], 2 * kb - 2);
+  load_plane(U[1], 2 * kb - 1);
+  load_plane(U[2], 2 * kb);
+  residual_plane(R[0], 2 * kb - 1);
+  for (int K = kb; K < ke; ++K) {
+#pragma unroll
+    for (int c = 1; c < 3; ++c) {
+      const int p = 2 * K + c - 1;                        // fine plane of this residual plane
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        U[0][r] = U[1][r];
+        U[1][r] = U[2][r];
+      }
+      load_plane(U[2], p + 1);
+      residual_plane(R[c], p);
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double v = a == 0 ? lane_below(R[c][b].y) : (a == 1 ? R[c][b].x : R[c][b].y);
+          const double wgt = scale * ((w1[a] * w1[b]) * w1[c]);
+          const double tv = wgt * v;
+          acc = (a == 0 && b == 0 && c == 0) ? tv : acc + tv;
+        }
+    if (valid) out[lc.s2 * K] = acc;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) R[0][b] = R[2][b];
+  }
+}
+
 // One thread per fine point.
 template <int ND>
 __global__ void __launch_bounds__(256)
@@ -282,6 +369,50 @@ extern "C" int examg_restrict(const examg_layout_t *lfine_, const double *rf, co
   else { set_error("examg_restrict: nd must be 2 or 3"); return 1; }
   EXAMG_CHECK_LAUNCH("k_restrict");
   return 0;
+}
+
+// RHS@coarser = scale * R * (rhs - A * u): `Residual = RHS - A * Solution` followed by the restriction loop, with the fine
+// residual field left out when nothing else reads it (mgCycle, Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:215-223, on a
+// block without neighbours).  [fbegin,fend): the residual loop's box, [cbegin,cend): the restriction loop's box.
+// 3-D 7-point constant stencils on long rows take the fused kernel and never touch `res`; everything else runs the two
+// kernels through `res` (then required).  Bit-identical to examg_residual + examg_restrict either way.
+extern "C" int examg_residual_restrict(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
+                                       const examg_layout_t *lr_, double *res, const examg_stencil_t *st,
+                                       const examg_layout_t *lc_, double *fc, double scale, const int32_t *fbegin,
+                                       const int32_t *fend, const int32_t *cbegin, const int32_t *cend, examg_stream_t stream) {
+  if (!lu_ || !u || !lf_ || !rhs || !st || !lc_ || !fc || !fbegin || !fend || !cbegin || !cend) { set_error("examg_residual_restrict: null argument"); return 1; }
+  const Box cb = make_box(cbegin, cend), fb = make_box(fbegin, fend);
+  if (cb.count() == 0) return 0;
+  const int ord = canonical_order7(st);
+  // fine footprint of the restriction: [2*cb - 1, 2*(ce-1) + 1] must lie inside the residual loop's box
+  const bool inside = 2 * cb.b0 - 1 >= fb.b0 && 2 * (cb.e0 - 1) + 1 < fb.e0 && 2 * cb.b1 - 1 >= fb.b1 && 2 * (cb.e1 - 1) + 1 < fb.e1 &&
+                      2 * cb.b2 - 1 >= fb.b2 && 2 * (cb.e2 - 1) + 1 < fb.e2;
+  const bool left_ok = 2 * (cb.b0 - 1) >= -(lu_->pad_l[0] + lu_->ghost_l[0]) && 2 * (cb.b0 - 1) >= -(lf_->pad_l[0] + lf_->ghost_l[0]);
+  if (g_restrict_wide && lu_->nd == 3 && ord >= 0 && cb.n0() >= 32 && inside && left_ok && box_inside(lu_, fb, 1) && box_inside(lf_, fb, 0) &&
+      box_inside(lc_, cb, 0)) {
+    const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_), lc = make_layout(lc_);
+    Coef7 k;
+    for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
+    const int ntx = (cb.n0() + 62) / 63;
+    const long long cols = (long long)ntx * cb.n1();
+    int ntz = (int)((4096 + cols - 1) / cols);
+    if (ntz < 1) ntz = 1;
+    int zc = (cb.n2() + ntz - 1) / ntz;
+    if (zc < 8) zc = 8;
+    if (zc > cb.n2()) zc = cb.n2();
+    ntz = (cb.n2() + zc - 1) / zc;
+    const long long nwaves = cols * ntz;
+    dim3 grid((unsigned)((nwaves + 3) / 4)), block(64, 4, 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (ord == 0) hipLaunchKernelGGL((k_residual_restrict3<0>), grid, block, 0, s, lu, u, lf, rhs, lc, fc, k, scale, cb, ntx, zc, (int)nwaves);
+    else hipLaunchKernelGGL((k_residual_restrict3<1>), grid, block, 0, s, lu, u, lf, rhs, lc, fc, k, scale, cb, ntx, zc, (int)nwaves);
+    EXAMG_CHECK_LAUNCH("k_residual_restrict3");
+    return 0;
+  }
+  if (!lr_ || !res) { set_error("examg_residual_restrict: this stencil / box needs the residual array"); return 1; }
+  int rc = examg_residual(lu_, u, lf_, rhs, lr_, res, st, fbegin, fend, stream);
+  if (rc) return rc;
+  return examg_restrict(lr_, res, lc_, fc, scale, cbegin, cend, stream);
 }
 
 extern "C" int examg_prolong_add(const examg_layout_t *lc_, const double *uc, const examg_layout_t *lfine_, double *uf,

@@ -96,6 +96,12 @@ class HipOps:
         check(self.L.examg_restrict(C.byref(lfine), self.ptr(rf), C.byref(lc), self.ptr(fc), float(scale), ivec(begin),
                                     ivec(end), self._stream()), "examg_restrict")
 
+    def residual_restrict(self, lu, u, lf, rhs, lr, res, st: Stencil, lc, fc, scale: float, fbegin, fend, cbegin, cend):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_residual_restrict(C.byref(lu), self.ptr(u), C.byref(lf), self.ptr(rhs), C.byref(lr) if lr is not None else None,
+                                             self.ptr(res) if res is not None else None, C.byref(sc), C.byref(lc), self.ptr(fc), float(scale),
+                                             ivec(fbegin), ivec(fend), ivec(cbegin), ivec(cend), self._stream()), "examg_residual_restrict")
+
     def prolong_add(self, lc, uc, lfine, uf, begin, end):
         check(self.L.examg_prolong_add(C.byref(lc), self.ptr(uc), C.byref(lfine), self.ptr(uf), ivec(begin), ivec(end),
                                        self._stream()), "examg_prolong_add")

@@ -116,6 +116,7 @@ class ConfigL4:
     align: int = 0
     fused_coarse: bool = True     # single block: mgCycle@coarsest as one persistent kernel
     fused_rbgs: bool = False      # one-pass red-black sweep (out of place, pointer swap)
+    fused_residual_restrict: bool = False   # single block: `Residual = ...` + restriction as one pass, fine residual not stored
     agglomerate_level: Optional[int] = None   # blocks > 1: levels <= this are solved redundantly on every rank (see _agg_cycle)
 
 
@@ -307,11 +308,20 @@ class SolverFromL4(_Program):
             return self.mgCycle_coarsest(l)
         ops = self.ops
         self._smooth(l)
-        self._update_residual(l)
         R, Fc = self.Residual[l], self.RHS[l - 1]
-        self.communicate(R)
-        b, e = self.bounds(Fc)
-        ops.restrict(R.lc, R.data(), Fc.lc, Fc.data(), 1.0, b, e)
+        if self.cfg.fused_residual_restrict and self._single_block():
+            # nothing reads Residual@l between here and its next update: residual and restriction in one pass, bit-identical
+            S = self.Solution[l]
+            self.communicate(S)
+            fb, fe = self.bounds(R)
+            b, e = self.bounds(Fc)
+            ops.residual_restrict(S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), R.lc, R.data(), self.Laplace[l], Fc.lc,
+                                  Fc.data(), 1.0, fb, fe, b, e)
+        else:
+            self._update_residual(l)
+            self.communicate(R)
+            b, e = self.bounds(Fc)
+            ops.restrict(R.lc, R.data(), Fc.lc, Fc.data(), 1.0, b, e)
         Sc, S = self.Solution[l - 1], self.Solution[l]
         b, e = self.bounds(Sc)
         ops.set(Sc.lc, Sc.data(), 0.0, b, e)

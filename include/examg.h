@@ -161,6 +161,18 @@ int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in, double *u_
                         const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin1, const int32_t *end1,
                         const int32_t *begin2, const int32_t *end2, examg_stream_t stream);
 
+/* `Residual = RHS - A * Solution` followed by `RHS@coarser = scale * R * Residual` (mgCycle,
+ * Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:215-223) as ONE pass when nothing else reads the fine residual: it is never
+ * written (48 + 8 B per fine point -> 16 B).  [fbegin,fend): the residual loop's box; [cbegin,cend): the restriction loop's
+ * box, whose fine footprint must lie inside it (a block without neighbours; with neighbours the restriction reads residuals
+ * on ghost points, which only an exchange of the stored field provides -- use the two calls).  3-D 7-point constant
+ * stencils on long rows take the fused kernel and never touch `res`/`lr` (may be NULL); everything else runs
+ * examg_residual + examg_restrict through `res`.  Bit-identical to the two calls either way. */
+int examg_residual_restrict(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs,
+                            const examg_layout_t *lr, double *res, const examg_stencil_t *st, const examg_layout_t *lc,
+                            double *fc, double scale, const int32_t *fbegin, const int32_t *fend, const int32_t *cbegin,
+                            const int32_t *cend, examg_stream_t stream);
+
 /* ---- K4: RHS@coarser = scale * R * Residual, R = kron [1/4 1/2 1/4]
  * (operator/l4/L4_DefaultRestriction.scala:29-36,63-88; solver/ir/IR_ResolveIntergridIndices.scala);
  * begin/end: coarse iterator box. */

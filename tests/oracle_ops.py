@@ -101,6 +101,10 @@ class OracleOps:
     def restrict(self, lfine, rf, lc, fc, scale, begin, end):
         self.L.orc_restrict(_lp(lfine), self.ptr(rf), _lp(lc), self.ptr(fc), float(scale), _iv(begin), _iv(end))
 
+    def residual_restrict(self, lu, u, lf, rhs, lr, res, st, lc, fc, scale, fbegin, fend, cbegin, cend):
+        self.stencil_op(1, lu, u, lf, rhs, lr, res, st, 0.0, -1, fbegin, fend)
+        self.restrict(lr, res, lc, fc, scale, cbegin, cend)
+
     def prolong_add(self, lc, uc, lfine, uf, begin, end):
         self.L.orc_prolong_add(_lp(lc), self.ptr(uc), _lp(lfine), self.ptr(uf), _iv(begin), _iv(end))
 

@@ -383,6 +383,27 @@ def test_restrict_and_prolong_bit_exact(hip, orc, nd, n, scale):
     assert_same(g, c, "transfer")
 
 
+@pytest.mark.parametrize("order", ["mp", "pm"])
+@pytest.mark.parametrize("n", [64, 130, 200])
+def test_residual_restrict_fused_bit_exact(hip, orc, n, order):
+    """`Residual = RHS - A * Solution` + restriction in one pass (fine residual never stored) against the oracle's two loops;
+    n = 64: short coarse rows, the two-kernel path through the residual array."""
+    st = laplace_fd(3, (1.0 / n,) * 3, order)
+
+    def f(ops):
+        lu, lf, lc = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0), FieldLayout.node(3, (n // 2,) * 3, 0)
+        u, fr, r, fc = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lc.size)
+        ops.fill_random(u, 21)
+        ops.fill_random(fr, 22)
+        fb, fe = box(3, n)
+        cb, ce = box(3, n // 2)
+        ops.residual_restrict(lu.c_struct(), u, lf.c_struct(), fr, lu.c_struct(), r, st, lc.c_struct(), fc, 1.0, fb, fe, cb, ce)
+        return [fc]
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "residual_restrict")
+
+
 def test_restrict_on_a_block_with_interior_faces(hip, orc):
     """Coarse loop bounds of a block with neighbours (iteration offsets 0): the fine footprint reaches the ghost layers;
     long rows take the wide kernel, a partial last tile included."""

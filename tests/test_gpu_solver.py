@@ -249,6 +249,20 @@ def test_rbgs_sweep_overlap_equals_sequential(hip, rank):
     assert np.array_equal(outs[0], outs[2])
 
 
+def test_fused_residual_restrict_changes_no_bit(hip):
+    """V-cycles with residual + restriction as one pass (fine residual never stored) print the same history, bit for bit."""
+    from exastencils_amd.solver import ConfigL4, SolverFromL4
+
+    hist = []
+    for fused in (False, True):
+        P = SolverFromL4(ConfigL4(nd=3, min_level=2, max_level=7, tol=1e-6, fused_rbgs=True, fused_residual_restrict=fused), hip)
+        P.setup()
+        P.Solve()
+        hist.append(P.res_history)
+    assert hist[0] == hist[1]
+    assert len(hist[0]) > 4
+
+
 def test_config4_helmholtz27_on_gpu(hip):
     """27-entry variable-coefficient Helmholtz V-cycles (config 4's operator) against the oracle program."""
     from test_host_logic import HELMHOLTZ27

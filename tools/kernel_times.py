@@ -46,6 +46,7 @@ def main():
         ("rbgs colour 1 (in place)", lambda: ops.stencil_op(2, L, u, F, f, L, u, A, w, 1, b, e), pts, 24),
         ("rbgs fused sweep", lambda: ops.rbgs_sweep_fused(L, u, un, F, f, A, w, 0, b, e), pts, 24),
         ("jacobi2 (two steps)", lambda: ops.jacobi2(L, u, un, None, F, f, A, w, b, e), 2 * pts, 24),
+        ("residual_restrict", lambda: ops.residual_restrict(L, u, F, f, L, r, A, Fc, fc, 1.0, b, e, bc, ec), pts, 16 + 1),
         ("restrict", lambda: ops.restrict(L, r, Fc, fc, 1.0, bc, ec), cpts, 72),
         ("prolong_add", lambda: ops.prolong_add(Lc, uc, L, u, b, e), pts, 17),
         ("dot", lambda: ops.dot(L, r, L, r, b, e, out), pts, 8),
