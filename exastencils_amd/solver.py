@@ -430,6 +430,7 @@ class ConfigL3:
     fmg: bool = False
     align: int = 0
     temporal_blocking: bool = False   # pairs of Jacobi steps in one pass (exastencils_amd/smoothers.py)
+    fused_residual_restrict: bool = False   # single block: UpResidual + Restriction as one pass (fine residual not stored)
     ksq: float = 0.0                  # stencil 'helmholtz27': shift k^2 of  -div(a grad u) - k^2 u  (config 4)
     rhs_from_solution: bool = False   # RHS = A * sol_fn (discrete manufactured solution)
 
@@ -557,8 +558,17 @@ class SolverFromL3(_Program):
         if l == self.cfg.min_level:
             return self.VCycle_0(l)
         self.Smoothers(l, self.cfg.n_smooth)
-        self.UpResidual(l)
-        self.Restriction(l)
+        if self.cfg.fused_residual_restrict and self._single_block():
+            # UpResidual@current + Restriction@current: nothing reads Residual@current before UpResidual writes it again
+            S, R, F, Fc = self.Solution[l], self.Residual[l], self.RHS[l], self.RHS[l - 1]
+            self.communicate(S, S.active)
+            fb, fe = self.bounds(R)
+            b, e = self.bounds(Fc)
+            self.ops.residual_restrict(S.lc, S.data(), F.lc, F.data(), R.lc, R.data(), self.Laplace[l], Fc.lc, Fc.data(),
+                                       self.cfg.restrict_scale, fb, fe, b, e)
+        else:
+            self.UpResidual(l)
+            self.Restriction(l)
         self.SetSolution(l - 1, 0.0)
         self.VCycle(l - 1)
         self.Correction(l)

@@ -261,6 +261,15 @@ def test_fused_residual_restrict_changes_no_bit(hip):
         hist.append(P.res_history)
     assert hist[0] == hist[1]
     assert len(hist[0]) > 4
+    from exastencils_amd.solver import ConfigL3, SolverFromL3
+
+    hist = []
+    for fused in (False, True):      # slotted Jacobi program, restriction scaled by 4, two-step passes
+        P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=7, temporal_blocking=True, fused_residual_restrict=fused), hip)
+        P.setup()
+        P.Solve()
+        hist.append(P.res_history)
+    assert hist[0] == hist[1]
 
 
 def test_config4_helmholtz27_on_gpu(hip):
