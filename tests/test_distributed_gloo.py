@@ -134,7 +134,8 @@ def _reference_single(case):
 @pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"),
                                          ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
                                          ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 2, 1), "rbgs_l4_cg"), ((2, 2, 1), "rbgs_l4_nodup_cg"), ((2, 1, 1), "rbgs_l4_fused"),
-                                         ((2, 2, 1), "rbgs_l4_fused_nodup_cg"), ((2, 1, 1), "rbgs_l4_agg"),
+                                         ((2, 2, 1), "rbgs_l4_fused_nodup_cg"), ((2, 1, 1), "rbgs_l4_agg"), ((1, 1, 2), "jacobi_l3_tb_cg"),
+                                         ((1, 2, 2), "rbgs_l4_fused_nodup_cg"),
                                          ((2, 2, 1), "rbgs_l4_fused_agg_nodup_cg"), ((2, 1, 1), "fmg_varcoeff"), ((2, 2, 1), "helmholtz27")])
 def test_decomposed_solve_matches_single_block(tmp_path, blocks, case):
     world = blocks[0] * blocks[1] * blocks[2]
@@ -243,8 +244,8 @@ def test_bench_vcycle_leg_on_two_blocks(tmp_path):
 
     port = _free_port()
     mp.spawn(_worker_bench_vcycle, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    # the same global problem on one block: 2 x 1 x 1 blocks of 64^3 cells = one fragment of 128 x 64 x 64 cells
-    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=1, max_level=6, tol=1e-6, nfrag=(1, 1, 1), frag_len=(2, 1, 1)))
+    # the same global problem on one block: 1 x 1 x 2 blocks of 64^3 cells = one fragment of 64 x 64 x 128 cells
+    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=1, max_level=6, tol=1e-6, nfrag=(1, 1, 1), frag_len=(1, 1, 2)))
     O.setup()
     O.Solve()
     for r in range(2):

@@ -55,9 +55,10 @@ def test_layout_matches_reference_sizes():
 
 
 def test_domain_rank_mapping_and_offsets():
-    assert RectDomain.blocks_for(8, 3) == (2, 2, 2)
-    assert RectDomain.blocks_for(4, 3) == (2, 2, 1)
-    assert RectDomain.blocks_for(2, 3) == (2, 1, 1)
+    assert RectDomain.blocks_for(8, 3) == (1, 2, 4)      # the unit-stride dimension stays undivided
+    assert RectDomain.blocks_for(4, 3) == (1, 2, 2)
+    assert RectDomain.blocks_for(2, 3) == (1, 1, 2)
+    assert RectDomain.blocks_for(4, 2) == (1, 4, 1)
     d = RectDomain(3, (2, 2, 2), rank=5)            # x-fastest: 5 = 1 + 2*(0 + 2*1)
     assert d.pos == (1, 0, 1)
     assert d.neighbor(0, -1) == 4 and d.neighbor(0, +1) is None

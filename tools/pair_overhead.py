@@ -34,7 +34,7 @@ class _LoopbackComm:
 
 ops = HipOps(0)
 L = 9
-for blocks, rank in (((1, 1, 1), 0), ((2, 1, 1), 0), ((2, 2, 2), 0), ((2, 2, 2), 7)):
+for blocks, rank in (((1, 1, 1), 0), ((2, 1, 1), 0), ((1, 1, 2), 0), ((2, 2, 1), 0), ((1, 2, 2), 0), ((2, 2, 2), 0), ((1, 2, 4), 2)):
     dom = RectDomain(3, blocks, rank)
     lay, layf = FieldLayout.node(3, dom.ncells(L), 1), FieldLayout.node(3, dom.ncells(L), 0, False, False)
     S, F, T = Field("S", L, lay, ops, 2, None), Field("F", L, layf, ops, 1, None), Field("T", L, lay, ops, 1, None)
