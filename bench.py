@@ -49,26 +49,6 @@ def parse():
     return ap.parse_args()
 
 
-def _cpu_budget():
-    """Hardware threads this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box gives one GPU's
-    share of the host, e.g. 16 of 256 threads; 128 OpenMP threads under that quota run 20x slower than 16)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as fh:          # cgroup v2: "<quota> <period>" or "max <period>"
-            q, p = fh.read().split()
-            if q != "max":
-                n = min(n, max(1, int(int(q) / int(p))))
-    except (OSError, ValueError):
-        try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
-                q, p = int(fq.read()), int(fp.read())
-                if q > 0:
-                    n = min(n, max(1, q // p))
-        except (OSError, ValueError):
-            pass
-    return n
-
-
 def cpu_baseline(seconds: float):
     """Restated reference CPU path on a bounded sample of the same workload: 512^3 Jacobi sweeps for ~`seconds` s on the
     hardware threads this process is allowed to use."""
@@ -77,7 +57,7 @@ def cpu_baseline(seconds: float):
     from oracle import mg
 
     L = mg.lib()
-    L.orc_set_num_threads(min(int(L.orc_num_threads()), _cpu_budget()))
+    L.orc_set_num_threads(min(int(L.orc_num_threads()), mg.cpu_budget()))   # affinity mask capped by the cgroup CPU quota
     n = 512
     lu, lf = mg.Layout.node(3, (n, n, n), 1), mg.Layout.node(3, (n, n, n), 0)
     u, un, f = lu.alloc(), lu.alloc(), lf.alloc()

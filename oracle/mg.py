@@ -106,8 +106,31 @@ def lib():
         L.orc_fill_random.restype = None
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads(min(int(L.orc_num_threads()), cpu_budget()))
         _lib = L
     return _lib
+
+
+def cpu_budget() -> int:
+    """Hardware threads this process may really use: the affinity mask capped by the cgroup CPU quota.  OpenMP's default
+    (all host threads) under a quota of a few CPUs oversubscribes them and runs an order of magnitude slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for quota_file, period_file in (("/sys/fs/cgroup/cpu.max", None),
+                                    ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            with open(quota_file) as fh:
+                txt = fh.read().split()
+            if period_file is None:
+                q, p = txt[0], txt[1]
+            else:
+                with open(period_file) as fh:
+                    q, p = txt[0], fh.read().split()[0]
+            if q != "max" and int(q) > 0:
+                n = min(n, max(1, int(q) // int(p)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 # function ids (must match examg_oracle.c and include/examg.h)
