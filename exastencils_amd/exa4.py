@@ -534,6 +534,11 @@ class Parser:
     def _loop(self):
         self.expect("loop")
         self.expect("over")
+        if self.at("fragments"):          # `loop over fragments { ... }`: one fragment per process here
+            self.next()
+            if self.at("with"):
+                raise Exa4Unsupported("line %d: loop over fragments with reduction" % self.peek().line)
+            return ("if", ("num", True), self.block(), [])
         target = self.postfix()
         only = None
         if self.accept("only"):

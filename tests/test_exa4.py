@@ -230,6 +230,15 @@ def test_constructs_outside_the_subset_are_refused(bc, body, what):
         exa4.Exa4Program(text, dict(dimensionality=3, minLevel=0, maxLevel=2), ops=OracleOps()).run()
 
 
+def test_loop_over_fragments_runs_its_body_once():
+    text = HEADER % "0.0" + "Function Application { loop over fragments { loop over u@finest { u@finest = 2.5 } } }"
+    P = exa4.Exa4Program(text, dict(dimensionality=3, minLevel=0, maxLevel=2), ops=OracleOps())
+    P.run()
+    f = P.fields[("u", 2)]
+    v = f.data().numpy().reshape(f.layout.shape_zyx)
+    assert v[2, 2, 2] == 2.5 and v[1, 2, 2] == 0.0 and P.launches == 1
+
+
 def test_syntax_errors_carry_the_line():
     with pytest.raises(exa4.Exa4SyntaxError, match="line 2"):
         exa4.Parser("Function F {\n loop under u { } }").parse()
