@@ -100,6 +100,8 @@ __device__ static inline double eval_fn(int fn, const double *p, double x, doubl
     case EXAMG_FN_KAPPA_RHS2D: return (2.0 * p[0]) * ((x - (x * x)) + (y - (y * y)));
     case EXAMG_FN_KAPPA_EXPSOL2D: return 1.0 - exp((-1.0 * p[0]) * ((x - (x * x)) * (y - (y * y))));
     case EXAMG_FN_KAPPA_COEF2D: return exp(p[0] * ((x - (x * x)) * (y - (y * y))));
+    case EXAMG_FN_POLY2D: return (x * x) - (y * y);
+    case EXAMG_FN_SINSINH2D: return sin(PI * x) * sinh(PI * y);
     default: return __builtin_nan("");
   }
 }

@@ -778,12 +778,16 @@ def fn_eval(fn: int, p: Sequence[float], x: float, y: float, z: float) -> float:
         return 1.0 - math.exp((-1.0 * k) * ((x - (x * x)) * (y - (y * y))))
     if fn == 13:
         return math.exp(k * ((x - (x * x)) * (y - (y * y))))
+    if fn == 14:
+        return (x * x) - (y * y)
+    if fn == 15:
+        return math.sin(PI * x) * math.sinh(PI * y)
     raise ValueError("function id %d" % fn)
 
 
 _FN_WITH_PARAM = {4, 5, 6, 7, 10, 11, 12, 13}
-_FN_2D_ONLY = {2, 3, 10, 11, 12, 13}     # ignore z
-_N_FN = 14
+_FN_2D_ONLY = {2, 3, 10, 11, 12, 13, 14, 15}     # ignore z
+_N_FN = 16
 
 
 # =====================================================================================================================

@@ -312,7 +312,9 @@ enum {
   ORC_FN_KAPPA_POLY2D = 10,/* kappa (x-x^2)(y-y^2) */
   ORC_FN_KAPPA_RHS2D = 11, /* 2 kappa ((x-x^2) + (y-y^2)) */
   ORC_FN_KAPPA_EXPSOL2D = 12,
-  ORC_FN_KAPPA_COEF2D = 13
+  ORC_FN_KAPPA_COEF2D = 13,
+  ORC_FN_POLY2D = 14,
+  ORC_FN_SINSINH2D = 15
 };
 
 double orc_eval_fn(int fn, const double *p, double x, double y, double z) {
@@ -333,6 +335,8 @@ double orc_eval_fn(int fn, const double *p, double x, double y, double z) {
     case ORC_FN_KAPPA_RHS2D: return (2.0 * p[0]) * ((x - (x * x)) + (y - (y * y)));
     case ORC_FN_KAPPA_EXPSOL2D: return 1.0 - exp((-1.0 * p[0]) * ((x - (x * x)) * (y - (y * y))));
     case ORC_FN_KAPPA_COEF2D: return exp(p[0] * ((x - (x * x)) * (y - (y * y))));
+    case ORC_FN_POLY2D: return (x * x) - (y * y);              /* Testing/BC/2D_Polynomial.exa4:43 */
+    case ORC_FN_SINSINH2D: return sin(PI * x) * sinh(PI * y);  /* Testing/BC/2D_Trigonometric.exa4:43 */
     default: return NAN;
   }
 }

@@ -38,6 +38,31 @@ REFERENCE_PROGRAMS = {
 }
 SLOW = {"Smoothers_RBGS", "Smoothers_Jac"}      # 576^3 on the CPU
 
+# Further tests of the reference's suite inside the subset: program, knowledge and expected output are all read from the
+# reference checkout (Testing/<name>.{exa4,knowledge,results}); compared under the harness' own rule.
+MORE_REFERENCE_TESTS = ["BC/2D_Polynomial", "BC/2D_Trigonometric", "BC/3D_Polynomial", "BC/3D_Trigonometric", "CommBasic/2D",
+                        "CommBasic/PureOMP", "FMG/2D_ConstCoeff", "FMG/2D_Polynomial", "SISC/2D_ConstCoeff", "SISC/2D_VarCoeff",
+                        "CUDA/2D_VarCoeff", "CommBasic/Hybrid", "CommBasic/Strategy26", "CommBasic/Summarize"]
+MORE_SLOW = {"CommBasic/Hybrid", "CommBasic/Strategy26", "CommBasic/Summarize"}      # 10-20 s each on the CPU
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("name", MORE_REFERENCE_TESTS)
+def test_more_reference_tests_reproduce_their_results_files(name):
+    from oracle import mg
+
+    if name in MORE_SLOW and not os.environ.get("EXAMG_SLOW"):
+        pytest.skip("set EXAMG_SLOW=1")
+    base = os.path.join(REF, "Testing", name)
+    k = knowledge.parse_file(base + ".knowledge")
+    k["testing_enabled"] = True
+    with open(base + ".exa4") as f:
+        P = exa4.Exa4Program(f.read(), k, ops=OracleOps())
+    out = P.run()
+    with open(base + ".results") as f:
+        want = f.read()
+    assert mg.compare_with_golden(out, want) == []      # Testing/run_test.py:12-42
+
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
 @pytest.mark.parametrize("name", sorted(REFERENCE_PROGRAMS))

@@ -493,7 +493,7 @@ def _ulp_close(a, b, ulps=4):
 
 
 @pytest.mark.parametrize("fn,nd,exact", [(FN_POLY3D, 3, True), (FN_TRIG2D_SOL, 2, False), (FN_KAPPA_RHS, 3, True),
-                                         (FN_KAPPA_EXPSOL, 3, False), (FN_TRIG3D_SOL, 3, False)])
+                                         (FN_KAPPA_EXPSOL, 3, False), (FN_TRIG3D_SOL, 3, False), (14, 2, True), (15, 2, False)])
 def test_fill_fn_and_dirichlet(hip, orc, fn, nd, exact):
     n = 24
     shape = tuple(n if d < nd else 0 for d in range(3))
