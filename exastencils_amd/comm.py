@@ -101,7 +101,7 @@ class Communicator:
 
     # -- exch<Field>_<level>(slot) ----------------------------------------------------------------
     def exchange(self, f: Field, slot: Optional[int] = None, what: str = "all", axis_only: bool = False):
-        if self.dist is None:
+        if self.dist is None and not any(self.domain.periodic):
             return   # single block, non-periodic: no neighbours, the generated exch function is empty
         lay, dom, nd = f.layout, self.domain, self.domain.nd
         x = f.data(slot)
@@ -139,8 +139,25 @@ class Communicator:
         if not sends and not recvs:
             return
         dist, ops = self.dist, self.ops
+        me = self.domain.rank
+        # a periodic dimension with one block: this block is its own neighbour -- what goes out on one side comes in on the
+        # other (send towards `side` pairs with the receive from `-side`), copied through the pack buffer
+        for peer, sbox, skey in [x_ for x_ in sends if x_[0] == me]:
+            sside = skey[4] if skey[0] == "ghost" else +1
+            for rpeer, rbox, rkey in recvs:
+                rside = rkey[4] if rkey[0] == "ghost" else -1
+                if rpeer == me and rkey[:4] == skey[:4] and rside == -sside:
+                    buf = self._buf(skey, self._count(sbox))
+                    ops.pack(f.lc, x, buf, sbox[0], sbox[1])
+                    ops.unpack(f.lc, x, buf, rbox[0], rbox[1])
+        sends = [x_ for x_ in sends if x_[0] != me]
+        recvs = [x_ for x_ in recvs if x_[0] != me]
+        if not sends and not recvs:
+            return
         p2p, rbufs = [], []
-        for peer, box, key in recvs:
+        # receives are posted in the opposite side order of the sends: when both neighbours of an axis are the same rank
+        # (two blocks, periodic) the first message sent (towards -) is the first one the peer expects (from +)
+        for peer, box, key in reversed(recvs):
             buf = self._buf(key, self._count(box))
             rbufs.append((buf, box))
             p2p.append(dist.P2POp(dist.irecv, buf, peer, self.group))

@@ -102,6 +102,7 @@ __device__ static inline double eval_fn(int fn, const double *p, double x, doubl
     case EXAMG_FN_KAPPA_COEF2D: return exp(p[0] * ((x - (x * x)) * (y - (y * y))));
     case EXAMG_FN_POLY2D: return (x * x) - (y * y);
     case EXAMG_FN_SINSINH2D: return sin(PI * x) * sinh(PI * y);
+    case EXAMG_FN_XSQ: return x * x;
     default: return __builtin_nan("");
   }
 }

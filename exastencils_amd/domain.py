@@ -22,8 +22,10 @@ class RectDomain:
     frag_len: Tuple[int, int, int] = (1, 1, 1)
     lo: Tuple[float, float, float] = (0.0, 0.0, 0.0)
     hi: Tuple[float, float, float] = (1.0, 1.0, 1.0)
+    periodic: Tuple[bool, bool, bool] = (False, False, False)    # domain_rect_periodic_{x,y,z}
 
     def __post_init__(self):
+        self.periodic = tuple(bool(self.periodic[d]) if d < self.nd and d < len(self.periodic) else False for d in range(3))
         self.num_blocks = tuple(int(self.num_blocks[d]) if d < self.nd else 1 for d in range(3))
         self.frag_len = tuple(int(self.frag_len[d]) if d < self.nd else 1 for d in range(3))
         n = self.world_size
@@ -62,8 +64,12 @@ class RectDomain:
         """Rank of the axis neighbour, None on a physical boundary (neighbor_isValid false)."""
         q = list(self.pos)
         q[d] += side
-        if d >= self.nd or not (0 <= q[d] < self.num_blocks[d]):
+        if d >= self.nd:
             return None
+        if not (0 <= q[d] < self.num_blocks[d]):
+            if not self.periodic[d]:
+                return None
+            q[d] %= self.num_blocks[d]          # periodic: the block at the other end (this block itself when there is one)
         return self.rank_of(q)
 
     def ncells(self, level: int) -> Tuple[int, int, int]:

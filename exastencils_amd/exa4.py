@@ -782,12 +782,15 @@ def fn_eval(fn: int, p: Sequence[float], x: float, y: float, z: float) -> float:
         return (x * x) - (y * y)
     if fn == 15:
         return math.sin(PI * x) * math.sinh(PI * y)
+    if fn == 16:
+        return x * x
     raise ValueError("function id %d" % fn)
 
 
 _FN_WITH_PARAM = {4, 5, 6, 7, 10, 11, 12, 13}
 _FN_2D_ONLY = {2, 3, 10, 11, 12, 13, 14, 15}     # ignore z
-_N_FN = 16
+_FN_ANY_DIM = {0, 16}
+_N_FN = 17
 
 
 # =====================================================================================================================
@@ -830,7 +833,7 @@ class Exa4Program:
         if domain is None:
             # one process: the reference's blocks x fragments become one fragment of the same global grid
             flen = tuple(d["frags_total"][i] * d["frag_len"][i] for i in range(3))
-            domain = RectDomain(self.nd, (1, 1, 1), 0, flen, lo[:3], hi[:3])
+            domain = RectDomain(self.nd, (1, 1, 1), 0, flen, lo[:3], hi[:3], d["periodic"])
         self.domain = domain
         self.comm = comm or Communicator(domain, ops)
         self.echo = echo
@@ -974,7 +977,7 @@ class Exa4Program:
         vals = [self._point_eval(e, lvl, *p) for p in pts]
         cands = [float(v) for v in self.globals.values() if isinstance(v, (int, float)) and not isinstance(v, bool)]
         for fn in range(_N_FN):
-            if (fn in _FN_2D_ONLY) != (self.nd == 2) and fn != 0:
+            if (fn in _FN_2D_ONLY) != (self.nd == 2) and fn not in _FN_ANY_DIM:
                 continue
             for par in (cands if fn in _FN_WITH_PARAM else [None]):
                 p = (par,) if par is not None else ()

@@ -18,7 +18,7 @@ from .lib import StencilC
 FN_ZERO, FN_POLY3D, FN_TRIG2D_SOL, FN_TRIG2D_RHS, FN_KAPPA_POLY, FN_KAPPA_RHS = 0, 1, 2, 3, 4, 5
 FN_KAPPA_EXPSOL, FN_KAPPA_COEF, FN_TRIG3D_SOL, FN_SIN3 = 6, 7, 8, 9
 FN_KAPPA_POLY2D, FN_KAPPA_RHS2D, FN_KAPPA_EXPSOL2D, FN_KAPPA_COEF2D = 10, 11, 12, 13
-FN_POLY2D, FN_SINSINH2D = 14, 15
+FN_POLY2D, FN_SINSINH2D, FN_XSQ = 14, 15, 16
 
 
 class Field:

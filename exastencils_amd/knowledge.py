@@ -76,6 +76,7 @@ def derive(k: Dict) -> Dict:
         "omp_threads": int(k.get("omp_numThreads", 1)),
         "cuda_block": tuple(int(k.get("cuda_blockSize_" + ax[d], (32, 4, 4)[d])) for d in range(3)),
         "comm_axis_neighbors_only": bool(k.get("comm_onlyAxisNeighbors", True)),
+        "periodic": tuple(bool(k.get("domain_rect_periodic_" + ax[d], False)) if d < nd else False for d in range(3)),
     }
 
 

@@ -94,7 +94,8 @@ enum {
   EXAMG_FN_KAPPA_EXPSOL2D = 12,
   EXAMG_FN_KAPPA_COEF2D = 13,
   EXAMG_FN_POLY2D = 14,      /* x*x - y*y                 (Testing/BC/2D_Polynomial.exa4:43) */
-  EXAMG_FN_SINSINH2D = 15    /* sin(PI x) * sinh(PI y)    (Testing/BC/2D_Trigonometric.exa4:43) */
+  EXAMG_FN_SINSINH2D = 15,   /* sin(PI x) * sinh(PI y)    (Testing/BC/2D_Trigonometric.exa4:43) */
+  EXAMG_FN_XSQ = 16          /* x*x                       (Testing/BC/2D_Periodic.exa4:43) */
 };
 
 int examg_version(void);

@@ -314,7 +314,8 @@ enum {
   ORC_FN_KAPPA_EXPSOL2D = 12,
   ORC_FN_KAPPA_COEF2D = 13,
   ORC_FN_POLY2D = 14,
-  ORC_FN_SINSINH2D = 15
+  ORC_FN_SINSINH2D = 15,
+  ORC_FN_XSQ = 16
 };
 
 double orc_eval_fn(int fn, const double *p, double x, double y, double z) {
@@ -337,6 +338,7 @@ double orc_eval_fn(int fn, const double *p, double x, double y, double z) {
     case ORC_FN_KAPPA_COEF2D: return exp(p[0] * ((x - (x * x)) * (y - (y * y))));
     case ORC_FN_POLY2D: return (x * x) - (y * y);              /* Testing/BC/2D_Polynomial.exa4:43 */
     case ORC_FN_SINSINH2D: return sin(PI * x) * sinh(PI * y);  /* Testing/BC/2D_Trigonometric.exa4:43 */
+    case ORC_FN_XSQ: return x * x;                             /* Testing/BC/2D_Periodic.exa4:43 */
     default: return NAN;
   }
 }

@@ -42,7 +42,8 @@ SLOW = {"Smoothers_RBGS", "Smoothers_Jac"}      # 576^3 on the CPU
 # reference checkout (Testing/<name>.{exa4,knowledge,results}); compared under the harness' own rule.
 MORE_REFERENCE_TESTS = ["BC/2D_Polynomial", "BC/2D_Trigonometric", "BC/3D_Polynomial", "BC/3D_Trigonometric", "CommBasic/2D",
                         "CommBasic/PureOMP", "FMG/2D_ConstCoeff", "FMG/2D_Polynomial", "SISC/2D_ConstCoeff", "SISC/2D_VarCoeff",
-                        "CUDA/2D_VarCoeff", "CommBasic/Hybrid", "CommBasic/Strategy26", "CommBasic/Summarize"]
+                        "CUDA/2D_VarCoeff", "BC/2D_Periodic", "BC/3D_Periodic", "CommBasic/Hybrid", "CommBasic/Strategy26",
+                        "CommBasic/Summarize"]
 MORE_SLOW = {"CommBasic/Hybrid", "CommBasic/Strategy26", "CommBasic/Summarize"}      # 10-20 s each on the CPU
 
 
@@ -311,6 +312,56 @@ def test_interpreter_on_two_blocks_matches_single_block(tmp_path):
     single.run()
     for r in range(2):
         meta = json.load(open(tmp_path / ("r%d.json" % r)))
+        assert meta["messages"] > 0
+        assert len(meta["values"]) == len(single.printed_values)
+        for x, y in zip(meta["values"], single.printed_values):
+            assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * single.printed_values[0]
+
+
+# -- periodic domain on two blocks: both neighbours along z are the other rank ---------------------------------------------
+def _worker_periodic(rank, world, port, out_dir):
+    import json
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import mg
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+
+    mg.lib().orc_set_num_threads(2)
+    ops = OracleOps()
+    dom = RectDomain(3, (1, 1, 2), rank, (2, 2, 1), periodic=(False, False, True))
+    P = example("jacobi3d_slots.exa4", 1, 4, ops=ops, domain=dom, comm=Communicator(dom, ops))
+    P.run()
+    json.dump({"values": P.printed_values, "messages": P.comm.stats["messages"]}, open(os.path.join(out_dir, "p%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_periodic_direction_on_two_blocks_matches_single_block(tmp_path):
+    import json
+
+    import torch.multiprocessing as mp
+
+    from exastencils_amd.domain import RectDomain
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_periodic, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    single = example("jacobi3d_slots.exa4", 1, 4, domain=RectDomain(3, (1, 1, 1), 0, (2, 2, 2), periodic=(False, False, True)))
+    single.run()
+    plain = example("jacobi3d_slots.exa4", 1, 4, domain=RectDomain(3, (1, 1, 1), 0, (2, 2, 2)))
+    plain.run()
+    assert single.printed_values != plain.printed_values          # the periodic direction changes the problem
+    for r in range(2):
+        meta = json.load(open(tmp_path / ("p%d.json" % r)))
         assert meta["messages"] > 0
         assert len(meta["values"]) == len(single.printed_values)
         for x, y in zip(meta["values"], single.printed_values):
