@@ -514,6 +514,13 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   if (ntz < 1) ntz = 1;
   int zc = (box.n2() + ntz - 1) / ntz;
   if (zc < 16) zc = 16;
+  // the kernel addresses a workgroup's window with 32-bit element offsets: plane stride x (chunk + halo planes) must fit
+  {
+    const LayoutDev lbig = lu.s2 > lf.s2 ? lu : lf;
+    const long long zmax = (2147483000LL - lbig.s1 * (2 * NW + 6) - 512) / lbig.s2 - 8;
+    if (zmax < 16) { set_error("examg two-stage kernel: plane too large for 32-bit window offsets"); return 1; }
+    if (zc > zmax) zc = (int)zmax;
+  }
   if (zc > box.n2()) zc = box.n2();
   g.zc = zc;
   g.ntz = (box.n2() + zc - 1) / zc;

@@ -662,6 +662,15 @@ class SolverFromL3(_Program):
             for s_ in range(self.Solution[l].num_slots):
                 self.apply_bc(self.Solution[l], s_)
         self.apply_bc(self.VecP)
+        if cfg.temporal_blocking and cfg.smoother == "jacobi":
+            # the scratch fields of the two-step passes are part of the set-up (a 43 GB allocation inside Solve shows up there)
+            if not hasattr(self, "_pair_tmp"):
+                self._pair_tmp = {}
+            for l in self.levels[1:]:
+                if l not in self._pair_tmp:
+                    S = self.Solution[l]
+                    self._pair_tmp[l] = Field("SolutionTmp", l, S.layout, self.ops, 1, S.bc_fn, S.bc_params)
+                    self.apply_bc(self._pair_tmp[l])
 
     # Function Solve
     def Solve(self) -> int:
