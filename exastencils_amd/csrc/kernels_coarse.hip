@@ -150,6 +150,121 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
   }
 }
 
+
+// Small coarsest grids (<= 4096 points, constant coefficients, reach 1): the same solver with the vectors resident on the CU.
+// Every thread owns up to four fixed points and keeps their Residual, Solution and A*p values in registers; only the search
+// direction, which the mat-vec reads at neighbours, lives in LDS (with a zero halo = its homogeneous Dirichlet planes).  No
+// global memory traffic inside the iteration.  Per-thread partial sums run over the same points in the same order and the
+// block sums use the same tree as k_cg_coarse: bit-identical results.
+constexpr int CG_PPT = 4;
+
+struct StencilCGL {
+  int nent;
+  int lo[EXAMG_MAX_ENTRIES];   // offsets in the LDS array of p
+  double coef[EXAMG_MAX_ENTRIES];
+};
+
+__global__ void __launch_bounds__(CG_THREADS)
+k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDev lr, double *res, LayoutDev lp, double *p,
+                LayoutDev lq, double *ap, StencilCG st, StencilCGL sl, FaceBoxesCG fbr, FaceBoxesCG fbp, FaceBoxesCG fbs, int max_it,
+                double rel_tol, Box box, double *info, int ldx, int ldxy, int ldtot) {
+  extern __shared__ double P[];
+  __shared__ double sm[CG_THREADS / 64];
+  const int total = (int)box.count();
+  for (int t = threadIdx.x; t < ldtot; t += CG_THREADS) P[t] = 0.0;
+  double r[CG_PPT], x[CG_PPT], q[CG_PPT], pv[CG_PPT];
+  int li[CG_PPT];
+  long long ku[CG_PPT], kr[CG_PPT], kp[CG_PPT], kq[CG_PPT];
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < CG_PPT; ++j) {
+    const int t = threadIdx.x + j * CG_THREADS;
+    r[j] = x[j] = q[j] = pv[j] = 0.0;
+    li[j] = 0;
+    ku[j] = kr[j] = kp[j] = kq[j] = 0;
+    if (t < total) {
+      int i0, i1, i2;
+      cg_unflatten(box, t, i0, i1, i2);
+      ku[j] = lidx(lu, i0, i1, i2);
+      kr[j] = lidx(lr, i0, i1, i2);
+      kp[j] = lidx(lp, i0, i1, i2);
+      kq[j] = lidx(lq, i0, i1, i2);
+      li[j] = (i0 - box.b0 + 1) + (i1 - box.b1 + 1) * ldx + (i2 - box.b2 + 1) * ldxy;
+      r[j] = rhs[lidx(lf, i0, i1, i2)] - cg_apply(st, lu, sol, lu, i0, i1, i2);   // Residual = RHS - Laplace * Solution
+      x[j] = sol[ku[j]];
+      s = s + r[j] * r[j];
+    }
+  }
+  cg_zero_faces(fbr, lr, res);   // apply bc to Residual / cgTmp0: their boundary planes in memory, as the statements leave them
+  cg_zero_faces(fbp, lp, p);
+  double curRes = sqrt(cg_block_sum(s, sm));
+  const double initRes = curRes;
+#pragma unroll
+  for (int j = 0; j < CG_PPT; ++j) {
+    pv[j] = r[j];                 // cgTmp0 = Residual
+    if (threadIdx.x + j * CG_THREADS < total) P[li[j]] = pv[j];
+  }
+  __syncthreads();
+
+  int it = 0;
+  double nextRes = curRes;
+  for (; it < max_it;) {
+    double sn = 0.0, sd = 0.0;
+#pragma unroll
+    for (int j = 0; j < CG_PPT; ++j) {
+      if (threadIdx.x + j * CG_THREADS < total) {
+        double acc = sl.coef[0] * P[li[j] + sl.lo[0]];
+        for (int k = 1; k < sl.nent; ++k) acc = acc + sl.coef[k] * P[li[j] + sl.lo[k]];
+        q[j] = acc;
+        sn = sn + r[j] * r[j];
+        sd = sd + pv[j] * acc;
+      }
+    }
+    const double alphaNom = cg_block_sum(sn, sm);
+    const double alphaDenom = cg_block_sum(sd, sm);
+    const double alpha = alphaNom / alphaDenom;
+    double s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < CG_PPT; ++j) {
+      if (threadIdx.x + j * CG_THREADS < total) {
+        x[j] = x[j] + alpha * pv[j];
+        r[j] = r[j] - alpha * q[j];
+        s2 = s2 + r[j] * r[j];
+      }
+    }
+    nextRes = sqrt(cg_block_sum(s2, sm));
+    ++it;
+    if (nextRes <= rel_tol * initRes) break;
+    const double beta = (nextRes * nextRes) / (curRes * curRes);
+#pragma unroll
+    for (int j = 0; j < CG_PPT; ++j) {
+      if (threadIdx.x + j * CG_THREADS < total) {
+        pv[j] = r[j] + beta * pv[j];
+        P[li[j]] = pv[j];
+      }
+    }
+    curRes = nextRes;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < CG_PPT; ++j) {
+    if (threadIdx.x + j * CG_THREADS < total) {
+      sol[ku[j]] = x[j];
+      res[kr[j]] = r[j];
+      p[kp[j]] = pv[j];
+      ap[kq[j]] = q[j];
+    }
+  }
+  cg_zero_faces(fbs, lu, sol);
+  if (threadIdx.x == 0 && info) {
+    info[0] = (double)it;
+    info[1] = initRes;
+    info[2] = nextRes;
+  }
+}
+
+static int g_cg_lds = 1;   // examg_debug_cg(0): global-memory solver for every size
+
 static FaceBoxesCG face_boxes(const examg_layout_t *l, uint32_t face_mask) {
   FaceBoxesCG fb;
   fb.n = 0;
@@ -176,6 +291,11 @@ static FaceBoxesCG face_boxes(const examg_layout_t *l, uint32_t face_mask) {
 }  // namespace examg
 
 using namespace examg;
+
+extern "C" int examg_debug_cg(int lds) {
+  examg::g_cg_lds = lds;
+  return 0;
+}
 
 extern "C" int examg_cg_coarse(const examg_layout_t *lu_, double *sol, const examg_layout_t *lf_, const double *rhs,
                                const examg_layout_t *lr_, double *res, const examg_layout_t *lp_, double *p,
@@ -221,6 +341,27 @@ extern "C" int examg_cg_coarse(const examg_layout_t *lu_, double *sol, const exa
   if (st->cfield) {
     lc = make_layout(&st->clayout);
     sd.cplane = lc.size;
+  }
+  const long long ldx = box.n0() + 2, ldxy = ldx * (box.n1() + 2), ldtot = ldxy * (box.n2() + 2);
+  // the LDS copy of cgTmp0 has a zero halo: right when the box is the whole interior, so that its neighbours are exactly the
+  // boundary planes `apply bc` keeps at zero
+  bool whole = true;
+  {
+    const int bb[3] = {box.b0, box.b1, box.b2}, ee[3] = {box.e0, box.e1, box.e2};
+    for (int d = 0; d < lp_->nd; ++d) whole = whole && bb[d] == lp_->dup_l[d] && ee[d] == lp_->dup_l[d] + lp_->inner[d];
+  }
+  if (g_cg_lds && whole && !st->cfield && reach <= 1 && box.count() <= CG_PPT * CG_THREADS && ldtot * 8 <= 60 * 1024) {
+    StencilCGL sl;
+    sl.nent = st->nent;
+    for (int k = 0; k < st->nent; ++k) {
+      sl.lo[k] = (int)(st->off[k][0] + ldx * st->off[k][1] + ldxy * st->off[k][2]);
+      sl.coef[k] = st->coef[k];
+    }
+    hipLaunchKernelGGL(k_cg_coarse_lds, dim3(1), dim3(CG_THREADS), (size_t)ldtot * 8, s, lu, sol, make_layout(lf_), rhs, make_layout(lr_), res,
+                       lp, p, make_layout(lq_), ap, sd, sl, face_boxes(lr_, face_mask), face_boxes(lp_, face_mask),
+                       face_boxes(lu_, face_mask), max_it, rel_tol, box, info, (int)ldx, (int)ldxy, (int)ldtot);
+    EXAMG_CHECK_LAUNCH("k_cg_coarse_lds");
+    return 0;
   }
   hipLaunchKernelGGL(k_cg_coarse, dim3(1), dim3(CG_THREADS), 0, s, lu, sol, make_layout(lf_), rhs, make_layout(lr_), res, lp, p,
                      make_layout(lq_), ap, lc, sd, face_boxes(lr_, face_mask), face_boxes(lp_, face_mask),

@@ -249,6 +249,27 @@ def test_rbgs_sweep_overlap_equals_sequential(hip, rank):
     assert np.array_equal(outs[0], outs[2])
 
 
+def test_lds_resident_coarse_cg_equals_global_memory_solver(hip):
+    """Coarsest grids of up to 4096 points run the CG with its vectors in registers / LDS: same iterates, bit for bit, as
+    the global-memory form of the kernel (3-D 16^3 and 8^3 coarsest grids, 2-D 16^2)."""
+    from exastencils_amd.solver import ConfigL4, SolverFromL4
+
+    for kw in (dict(nd=3, min_level=4, max_level=6), dict(nd=3, min_level=3, max_level=5),
+               dict(nd=2, min_level=4, max_level=7, bc_fn=2, rhs_fn=3)):
+        hist = []
+        for lds in (0, 1):
+            hip.L.examg_debug_cg(lds)
+            try:
+                P = SolverFromL4(ConfigL4(tol=1e-8, **kw), hip)
+                P.setup()
+                P.Solve()
+            finally:
+                hip.L.examg_debug_cg(1)
+            hist.append((P.res_history, hip.to_host(P.Solution[kw["max_level"]].data()).copy()))
+        assert hist[0][0] == hist[1][0]
+        assert np.array_equal(hist[0][1], hist[1][1])
+
+
 def test_fused_residual_restrict_changes_no_bit(hip):
     """V-cycles with residual + restriction as one pass (fine residual never stored) print the same history, bit for bit."""
     from exastencils_amd.solver import ConfigL4, SolverFromL4
