@@ -102,3 +102,22 @@ def test_captured_cycle_replays_like_direct_calls(hip):
     a, b = residuals(False), residuals(True)
     assert a == b
     assert a[2] < 2e-2 * a[0]
+
+
+def test_periodic_direction_on_gpu(hip):
+    """`domain_rect_periodic_z`: the block is its own neighbour along z (self-exchange through pack/unpack); the GPU run
+    follows the CPU-ops run of the same interpreted program."""
+    from oracle_ops import OracleOps
+    from test_exa4 import example
+
+    from exastencils_amd.domain import RectDomain
+
+    def run(ops):
+        P = example("jacobi3d_slots.exa4", 1, 6, ops=ops, domain=RectDomain(3, (1, 1, 1), 0, (1, 1, 1), periodic=(False, False, True)))
+        P.run()
+        return P
+
+    G, C_ = run(hip), run(OracleOps())
+    _close(G.printed_values, C_.printed_values, C_.printed_values[0])
+    assert G.out[-1] == C_.out[-1]
+    assert G.comm.stats["messages"] == 0          # no other block: local copies only
