@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import os
 import re
-from typing import Dict, Optional, Tuple
+from typing import Dict, Optional
 
 _LINE = re.compile(r"^\s*([A-Za-z_][A-Za-z0-9_]*)\s*=\s*(.+?)\s*$")
 _IMPORT = re.compile(r"^\s*import\s+['\"](.+?)['\"]\s*$")
