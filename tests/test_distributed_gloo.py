@@ -254,3 +254,58 @@ def test_bench_vcycle_leg_on_two_blocks(tmp_path):
         assert v["solve_iterations"] == O.iterations
         want = O.res_history[-1] / O.res_history[0]
         assert abs(v["solve_residual_reduction"] - want) <= 1e-8 * want
+
+
+# -------------------------------------------------------------------------------------------------
+def _worker_eight(rank, world, port, out_dir):
+    """The decomposition bench.py uses on a full node, 1 x 2 x 4 blocks: fused red-black sweeps with shells, single-batch
+    ghosts, left-out duplicate exchange, agglomerated coarse levels."""
+    _init(rank, world, port)
+    from oracle import mg
+    from oracle_ops import OracleOps
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.solver import ConfigL4, SolverFromL4
+
+    mg.lib().orc_set_num_threads(1)
+    ops = OracleOps()
+    blocks = RectDomain.blocks_for(world, 3)
+    flen = tuple(4 // blocks[d] for d in range(3))
+    dom = RectDomain(3, blocks, rank, flen)
+    comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
+    P = SolverFromL4(ConfigL4(nd=3, min_level=0, max_level=3, frag_len=flen, tol=1e-6, fused_coarse=False, fused_rbgs=True,
+                              agglomerate_level=1), ops, dom, comm)
+    P.setup()
+    P.Solve()
+    from exastencils_amd.solver import ConfigL3, SolverFromL3
+
+    # the smoother path of bench.py's headline: slotted Jacobi in two-step passes (interior + shell), single-batch ghosts
+    Q = SolverFromL3(ConfigL3(nd=3, min_level=0, max_level=3, frag_len=flen, temporal_blocking=True), ops, dom, comm)
+    Q.setup()
+    Q.Solve()
+    json.dump({"res": P.res_history, "it": P.iterations, "blocks": list(blocks), "res_jac": Q.res_history, "it_jac": Q.iterations},
+              open(os.path.join(out_dir, "e_%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_blocks_as_on_a_full_node(tmp_path):
+    from oracle import mg
+
+    port = _free_port()
+    mp.spawn(_worker_eight, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=0, max_level=3, tol=1e-6, nfrag=(1, 1, 1), frag_len=(4, 4, 4)))
+    O.setup()
+    O.Solve()
+    J = mg.ProgramB(mg.ConfigB(nd=3, min_level=0, max_level=3, nfrag=(1, 1, 1), frag_len=(4, 4, 4)))
+    J.setup()
+    J.Solve()
+    for r in range(8):
+        v = json.load(open(tmp_path / ("e_%d.json" % r)))
+        assert v["blocks"] == [1, 2, 4]
+        assert v["it"] == O.iterations and v["it_jac"] == J.iterations
+        for x, y in zip(v["res"], O.res_history):
+            assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * O.res_history[0], (v["res"], O.res_history)
+        for x, y in zip(v["res_jac"], J.res_history):
+            assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * J.res_history[0], (v["res_jac"], J.res_history)
