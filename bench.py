@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-temporal-blocking", action="store_true", help="one kernel launch per smoother step")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--extras-timeout", type=float, default=240.0, help="seconds the extra measurements may take")
+    ap.add_argument("--backend", default="nccl", help="'gloo': rehearsal with several ranks on ONE GPU (messages staged through the host)")
     return ap.parse_args()
 
 
@@ -106,10 +107,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    local_rank %= max(1, torch.cuda.device_count())      # rehearsal: more ranks than GPUs share the cards
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from exastencils_amd.comm import Communicator
     from exastencils_amd.domain import RectDomain
@@ -119,7 +124,10 @@ def main():
 
     ops = HipOps(local_rank)
     nd, L = 3, args.level
-    dom = RectDomain(nd, RectDomain.blocks_for(world, nd), rank)
+    # weak scaling keeps the mesh width: the physical domain grows with the blocks, [0,1]^3 per block (a unit cube cut into
+    # 1 x 2 x 4 blocks of 512^3 cells would be an anisotropic mesh, on which point smoothers with full coarsening degrade)
+    blocks = RectDomain.blocks_for(world, nd)
+    dom = RectDomain(nd, blocks, rank, hi=tuple(float(b) for b in blocks))
     # 7-point loops read face ghosts only (one batch per exchange); duplicate planes are computed to the same bits on
     # both sides by every loop of these programs, so their upstream exchange is left out (exastencils_amd/comm.py)
     comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
@@ -172,7 +180,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=ops.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=ops.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -48,6 +48,10 @@ class Communicator:
             if dist.get_rank(group) != domain.rank:
                 raise RuntimeError("rank mismatch between torch.distributed and the domain")
             self.dist = dist
+        # rehearsal mode: backend "gloo" with device arrays (several ranks sharing one GPU) -- messages are staged through
+        # the host.  Product runs use "nccl" (RCCL), where device buffers go on the wire directly.
+        self._stage = bool(self.dist is not None and self.dist.get_backend(group) == "gloo" and getattr(ops, "device", None) is not None
+                           and getattr(ops.device, "type", "cpu") != "cpu")
         self._bufs: Dict[Tuple, object] = {}
         self.stats = {"messages": 0, "bytes": 0}
 
@@ -159,17 +163,20 @@ class Communicator:
         # (two blocks, periodic) the first message sent (towards -) is the first one the peer expects (from +)
         for peer, box, key in reversed(recvs):
             buf = self._buf(key, self._count(box))
-            rbufs.append((buf, box))
-            p2p.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+            wire = buf.cpu() if self._stage else buf
+            rbufs.append((buf, wire, box))
+            p2p.append(dist.P2POp(dist.irecv, wire, peer, self.group))
         for peer, box, key in sends:
             buf = self._buf(key, self._count(box))
             ops.pack(f.lc, x, buf, box[0], box[1])
-            p2p.append(dist.P2POp(dist.isend, buf, peer, self.group))
+            p2p.append(dist.P2POp(dist.isend, buf.cpu() if self._stage else buf, peer, self.group))
             self.stats["messages"] += 1
             self.stats["bytes"] += 8 * buf.numel()
         for w in dist.batch_isend_irecv(p2p):
             w.wait()
-        for buf, box in rbufs:
+        for buf, wire, box in rbufs:
+            if self._stage:
+                buf.copy_(wire)
             ops.unpack(f.lc, x, buf, box[0], box[1])
 
     # -- reductions across blocks -------------------------------------------------------------------
@@ -178,5 +185,20 @@ class Communicator:
         if self.dist is None:
             return t
         rop = self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX
+        if self._stage:
+            c = t.cpu()
+            self.dist.all_reduce(c, op=rop, group=self.group)
+            t.copy_(c)
+            return t
         self.dist.all_reduce(t, op=rop, group=self.group)
         return t
+
+    def all_gather(self, outs: List, t):
+        """Every rank's `t` into `outs[rank]` (coarse-level agglomeration, exastencils_amd/solver.py)."""
+        if self._stage:
+            couts = [o.cpu() for o in outs]
+            self.dist.all_gather(couts, t.cpu(), group=self.group)
+            for o, c in zip(outs, couts):
+                o.copy_(c)
+            return
+        self.dist.all_gather(outs, t, group=self.group)

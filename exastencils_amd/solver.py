@@ -177,7 +177,7 @@ class SolverFromL4(_Program):
         own_b = [0, 0, 0]
         own_e = [nc[d] + 1 if d < nd else 1 for d in range(3)]
         ops.pack(F.lc, F.data(), self._agg_send, own_b, own_e)
-        self.comm.dist.all_gather(self._agg_recv, self._agg_send, group=self.comm.group)
+        self.comm.all_gather(self._agg_recv, self._agg_send)
         AF, AS = A.RHS[k], A.Solution[k]
         for r in range(dom.world_size):
             pos = RectDomain(nd, dom.num_blocks, r, dom.frag_len).pos
