@@ -183,6 +183,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=ops.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the job's lattice updates per step: every grid point once (duplicate planes at interior faces are computed by both
+        # neighbours; the reduction box of a block leaves its lower duplicate planes to the neighbour)
+        ub, ue = dom.loop_bounds(Solution.layout, reduction=True)
+        unique = (ue[0] - ub[0]) * (ue[1] - ub[1]) * (ue[2] - ub[2])
+        t = torch.tensor([float(unique)], dtype=torch.float64, device=t.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_updates = int(t.item())
+    else:
+        total_updates = updates
 
     # the two hot kernels alone, events on the launch stream
     stream = torch.cuda.current_stream()
@@ -231,7 +240,7 @@ def main():
                 traffic = None
         out = {
             "metric": "LU/s",
-            "value": world * updates * args.steps / dt,
+            "value": total_updates * args.steps / dt,
             "unit": "LU/s",
             "n_gpus": world,
             "steps": args.steps,
