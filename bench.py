@@ -271,6 +271,11 @@ def main():
                 "kernel_ms": kernel_ms,
                 "bytes_per_lu": BYTES_PER_LU,
                 "lu_per_launch": units,
+                # two updates share one pass in the dominant kernel, so `achieved` (algorithmic bytes / time) can exceed the
+                # peak; the bytes that really moved at the L2's fabric side (`traffic`, PMC) per second, and the one-step-
+                # per-launch kernel against the same peak, for orientation
+                "traffic_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+                "frac_one_step_per_launch": single_gbs / HBM_PEAK_GBS,
             },
         }
         out.update(extra)
