@@ -150,15 +150,58 @@ k_dot_rows(LayoutDev lx, const double *__restrict__ x, LayoutDev ly, const doubl
   if (threadIdx.x == 0) part[blockIdx.x] = r;
 }
 
+// A point function: one of the built-in expressions (fn id + parameters) or a postfix program (include/examg.h).
+struct FnEval {
+  int fn;
+  Params4 p;
+  __device__ __forceinline__ double operator()(double x, double y, double z) const { return eval_fn(fn, p.v, x, y, z); }
+};
+struct ExprEval {
+  examg_expr_t e;
+  __device__ double operator()(double x, double y, double z) const {
+    double st[24];
+    int sp = 0;
+    for (int i = 0; i < e.n; ++i) {
+      switch (e.op[i]) {
+        case EXAMG_OP_CONST: st[sp++] = e.c[i]; break;
+        case EXAMG_OP_X: st[sp++] = x; break;
+        case EXAMG_OP_Y: st[sp++] = y; break;
+        case EXAMG_OP_Z: st[sp++] = z; break;
+        case EXAMG_OP_ADD: --sp; st[sp - 1] = st[sp - 1] + st[sp]; break;
+        case EXAMG_OP_SUB: --sp; st[sp - 1] = st[sp - 1] - st[sp]; break;
+        case EXAMG_OP_MUL: --sp; st[sp - 1] = st[sp - 1] * st[sp]; break;
+        case EXAMG_OP_DIV: --sp; st[sp - 1] = st[sp - 1] / st[sp]; break;
+        case EXAMG_OP_NEG: st[sp - 1] = -st[sp - 1]; break;
+        case EXAMG_OP_SIN: st[sp - 1] = sin(st[sp - 1]); break;
+        case EXAMG_OP_COS: st[sp - 1] = cos(st[sp - 1]); break;
+        case EXAMG_OP_EXP: st[sp - 1] = exp(st[sp - 1]); break;
+        case EXAMG_OP_SINH: st[sp - 1] = sinh(st[sp - 1]); break;
+        case EXAMG_OP_COSH: st[sp - 1] = cosh(st[sp - 1]); break;
+        case EXAMG_OP_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
+        case EXAMG_OP_POW: --sp; st[sp - 1] = pow(st[sp - 1], st[sp]); break;
+        case EXAMG_OP_TAN: st[sp - 1] = tan(st[sp - 1]); break;
+        case EXAMG_OP_LOG: st[sp - 1] = log(st[sp - 1]); break;
+        case EXAMG_OP_FABS: st[sp - 1] = fabs(st[sp - 1]); break;
+        case EXAMG_OP_MAX: --sp; st[sp - 1] = fmax(st[sp - 1], st[sp]); break;
+        case EXAMG_OP_MIN: --sp; st[sp - 1] = fmin(st[sp - 1], st[sp]); break;
+        case EXAMG_OP_TANH: st[sp - 1] = tanh(st[sp - 1]); break;
+        default: st[sp++] = __builtin_nan(""); break;
+      }
+    }
+    return st[0];
+  }
+};
+
+template <class F>
 __global__ void __launch_bounds__(RED_BLOCK)
-k_maxerr_partial(LayoutDev l, const double *__restrict__ x, Geom g, int fn, Params4 p, Box box, double *part) {
+k_maxerr_partial(LayoutDev l, const double *__restrict__ x, Geom g, F fn, Box box, double *part) {
   const long long total = box.count();
   double m = 0.0;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     int i0, i1, i2;
     unflatten(box, t, i0, i1, i2);
     const double px = i0 * g.h0 + g.pb0, py = i1 * g.h1 + g.pb1, pz = i2 * g.h2 + g.pb2;
-    m = fmax(m, fabs(x[lidx(l, i0, i1, i2)] - eval_fn(fn, p.v, px, py, pz)));
+    m = fmax(m, fabs(x[lidx(l, i0, i1, i2)] - fn(px, py, pz)));
   }
   const double r = block_reduce<true>(m);
   if (threadIdx.x == 0) part[blockIdx.x] = r;
@@ -173,13 +216,14 @@ __global__ void __launch_bounds__(RED_BLOCK) k_reduce_final(const double *part, 
 }
 
 // ---- analytic fills ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_fill_fn(LayoutDev l, double *x, Geom g, int fn, Params4 p, Box box) {
+template <class F>
+__global__ void __launch_bounds__(256) k_fill_fn(LayoutDev l, double *x, Geom g, F fn, Box box) {
   const long long total = box.count();
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     int i0, i1, i2;
     unflatten(box, t, i0, i1, i2);
     const double px = i0 * g.h0 + g.pb0, py = i1 * g.h1 + g.pb1, pz = i2 * g.h2 + g.pb2;
-    x[lidx(l, i0, i1, i2)] = eval_fn(fn, p.v, px, py, pz);
+    x[lidx(l, i0, i1, i2)] = fn(px, py, pz);
   }
 }
 
@@ -189,7 +233,8 @@ struct FaceBoxes {
   int n;
 };
 
-__global__ void __launch_bounds__(256) k_apply_dirichlet(LayoutDev l, double *x, Geom g, int fn, Params4 p, FaceBoxes fb) {
+template <class F>
+__global__ void __launch_bounds__(256) k_apply_dirichlet(LayoutDev l, double *x, Geom g, F fn, FaceBoxes fb) {
   const long long total = fb.start[fb.n];
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     int f = 0;
@@ -197,7 +242,7 @@ __global__ void __launch_bounds__(256) k_apply_dirichlet(LayoutDev l, double *x,
     int i0, i1, i2;
     unflatten(fb.box[f], t - fb.start[f], i0, i1, i2);
     const double px = i0 * g.h0 + g.pb0, py = i1 * g.h1 + g.pb1, pz = i2 * g.h2 + g.pb2;
-    x[lidx(l, i0, i1, i2)] = eval_fn(fn, p.v, px, py, pz);
+    x[lidx(l, i0, i1, i2)] = fn(px, py, pz);
   }
 }
 
@@ -339,34 +384,36 @@ extern "C" int examg_dot(const examg_layout_t *lx_, const double *x, const examg
   return 0;
 }
 
-extern "C" int examg_max_err_fn(const examg_layout_t *l_, const double *x, const examg_geom_t *g, int fn,
-                                const double *params, const int32_t *begin, const int32_t *end, double *result,
-                                void *work, examg_stream_t stream) {
-  if (!l_ || !x || !g || !begin || !end || !result || !work) { set_error("examg_max_err_fn: null argument"); return 1; }
+template <class F>
+static int max_err_impl(const char *who, const examg_layout_t *l_, const double *x, const examg_geom_t *g, const F &fn,
+                        const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream) {
+  if (!l_ || !x || !g || !begin || !end || !result || !work) { set_error("examg_max_err: null argument"); return 1; }
   const Box box = make_box(begin, end);
   hipStream_t s = (hipStream_t)stream;
-  if (box.count() == 0) return check_hip(hipMemsetAsync(result, 0, sizeof(double), s), "examg_max_err_fn memset");
-  if (!box_inside(l_, box, 0)) { set_error("examg_max_err_fn: box leaves the allocation"); return 1; }
+  if (box.count() == 0) return check_hip(hipMemsetAsync(result, 0, sizeof(double), s), "examg_max_err memset");
+  if (!box_inside(l_, box, 0)) { set_error("examg_max_err: box leaves the allocation"); return 1; }
   const int nb = red_blocks(box.count());
-  hipLaunchKernelGGL(k_maxerr_partial, dim3(nb), dim3(RED_BLOCK), 0, s, make_layout(l_), x, make_geom(g), fn, make_params(params), box, (double *)work);
+  hipLaunchKernelGGL((k_maxerr_partial<F>), dim3(nb), dim3(RED_BLOCK), 0, s, make_layout(l_), x, make_geom(g), fn, box, (double *)work);
   hipLaunchKernelGGL((k_reduce_final<true>), dim3(1), dim3(RED_BLOCK), 0, s, (const double *)work, nb, result);
-  EXAMG_CHECK_LAUNCH("k_maxerr");
+  EXAMG_CHECK_LAUNCH(who);
   return 0;
 }
 
-extern "C" int examg_fill_fn(const examg_layout_t *l_, double *x, const examg_geom_t *g, int fn, const double *params,
-                             const int32_t *begin, const int32_t *end, examg_stream_t stream) {
-  if (!l_ || !x || !g || !begin || !end) { set_error("examg_fill_fn: null argument"); return 1; }
+template <class F>
+static int fill_impl(const char *who, const examg_layout_t *l_, double *x, const examg_geom_t *g, const F &fn, const int32_t *begin,
+                     const int32_t *end, examg_stream_t stream) {
+  if (!l_ || !x || !g || !begin || !end) { set_error("examg_fill: null argument"); return 1; }
   const Box box = make_box(begin, end);
   if (box.count() == 0) return 0;
-  if (!box_inside(l_, box, 0)) { set_error("examg_fill_fn: box leaves the allocation"); return 1; }
-  hipLaunchKernelGGL(k_fill_fn, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(l_), x, make_geom(g), fn, make_params(params), box);
-  EXAMG_CHECK_LAUNCH("k_fill_fn");
+  if (!box_inside(l_, box, 0)) { set_error("examg_fill: box leaves the allocation"); return 1; }
+  hipLaunchKernelGGL((k_fill_fn<F>), grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(l_), x, make_geom(g), fn, box);
+  EXAMG_CHECK_LAUNCH(who);
   return 0;
 }
 
-extern "C" int examg_apply_dirichlet(const examg_layout_t *l, double *x, const examg_geom_t *g, int fn,
-                                     const double *params, uint32_t face_mask, examg_stream_t stream) {
+template <class F>
+static int dirichlet_impl(const char *who, const examg_layout_t *l, double *x, const examg_geom_t *g, const F &fn, uint32_t face_mask,
+                          examg_stream_t stream) {
   if (!l || !x || !g) { set_error("examg_apply_dirichlet: null argument"); return 1; }
   FaceBoxes fb;
   fb.n = 0;
@@ -391,9 +438,65 @@ extern "C" int examg_apply_dirichlet(const examg_layout_t *l, double *x, const e
       ++fb.n;
     }
   if (fb.n == 0) return 0;
-  hipLaunchKernelGGL(k_apply_dirichlet, grid_for(fb.start[fb.n], 2048), dim3(256), 0, (hipStream_t)stream, make_layout(l), x, make_geom(g), fn, make_params(params), fb);
-  EXAMG_CHECK_LAUNCH("k_apply_dirichlet");
+  hipLaunchKernelGGL((k_apply_dirichlet<F>), grid_for(fb.start[fb.n], 2048), dim3(256), 0, (hipStream_t)stream, make_layout(l), x, make_geom(g), fn, fb);
+  EXAMG_CHECK_LAUNCH(who);
   return 0;
+}
+
+static bool expr_ok(const examg_expr_t *e) {
+  if (!e || e->n < 1 || e->n > EXAMG_MAX_EXPR) { set_error("examg expression: null or too long"); return false; }
+  int sp = 0;      // the stack discipline is checked on the host, the kernel trusts it
+  for (int i = 0; i < e->n; ++i) {
+    switch (e->op[i]) {
+      case EXAMG_OP_CONST: case EXAMG_OP_X: case EXAMG_OP_Y: case EXAMG_OP_Z: ++sp; break;
+      case EXAMG_OP_ADD: case EXAMG_OP_SUB: case EXAMG_OP_MUL: case EXAMG_OP_DIV: case EXAMG_OP_POW: case EXAMG_OP_MAX: case EXAMG_OP_MIN:
+        if (sp < 2) { set_error("examg expression: stack underflow"); return false; }
+        --sp;
+        break;
+      case EXAMG_OP_NEG: case EXAMG_OP_SIN: case EXAMG_OP_COS: case EXAMG_OP_EXP: case EXAMG_OP_SINH: case EXAMG_OP_COSH: case EXAMG_OP_SQRT:
+      case EXAMG_OP_TAN: case EXAMG_OP_LOG: case EXAMG_OP_FABS: case EXAMG_OP_TANH:
+        if (sp < 1) { set_error("examg expression: stack underflow"); return false; }
+        break;
+      default: set_error("examg expression: unknown opcode"); return false;
+    }
+    if (sp > 24) { set_error("examg expression: stack deeper than 24"); return false; }
+  }
+  if (sp != 1) { set_error("examg expression: must leave exactly one value"); return false; }
+  return true;
+}
+
+extern "C" int examg_max_err_fn(const examg_layout_t *l_, const double *x, const examg_geom_t *g, int fn,
+                                const double *params, const int32_t *begin, const int32_t *end, double *result,
+                                void *work, examg_stream_t stream) {
+  return max_err_impl("k_maxerr", l_, x, g, FnEval{fn, make_params(params)}, begin, end, result, work, stream);
+}
+
+extern "C" int examg_max_err_expr(const examg_layout_t *l_, const double *x, const examg_geom_t *g, const examg_expr_t *e,
+                                  const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream) {
+  if (!expr_ok(e)) return 1;
+  return max_err_impl("k_maxerr_expr", l_, x, g, ExprEval{*e}, begin, end, result, work, stream);
+}
+
+extern "C" int examg_fill_fn(const examg_layout_t *l_, double *x, const examg_geom_t *g, int fn, const double *params,
+                             const int32_t *begin, const int32_t *end, examg_stream_t stream) {
+  return fill_impl("k_fill_fn", l_, x, g, FnEval{fn, make_params(params)}, begin, end, stream);
+}
+
+extern "C" int examg_fill_expr(const examg_layout_t *l_, double *x, const examg_geom_t *g, const examg_expr_t *e,
+                               const int32_t *begin, const int32_t *end, examg_stream_t stream) {
+  if (!expr_ok(e)) return 1;
+  return fill_impl("k_fill_expr", l_, x, g, ExprEval{*e}, begin, end, stream);
+}
+
+extern "C" int examg_apply_dirichlet(const examg_layout_t *l, double *x, const examg_geom_t *g, int fn,
+                                     const double *params, uint32_t face_mask, examg_stream_t stream) {
+  return dirichlet_impl("k_apply_dirichlet", l, x, g, FnEval{fn, make_params(params)}, face_mask, stream);
+}
+
+extern "C" int examg_apply_dirichlet_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, const examg_expr_t *e,
+                                          uint32_t face_mask, examg_stream_t stream) {
+  if (!expr_ok(e)) return 1;
+  return dirichlet_impl("k_apply_dirichlet_expr", l, x, g, ExprEval{*e}, face_mask, stream);
 }
 
 extern "C" int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,

@@ -24,8 +24,10 @@ Loop bodies recognised (anything else raises Exa4Unsupported -- nothing is silen
   RHS@coarser = [s *] Restriction * Residual | U += Prolongation@coarser * U@coarser  examg_restrict / examg_prolong_add
   s += F*G (reduction +) | s = max(s, fabs(F - analytic)) (reduction max)             examg_dot / examg_max_err_fn
   A:[o] = -a(x +- h/2)/h^2 ... (7 entries of a stencil field)                         examg_init_varcoeff7
-Analytic point functions (boundary values, right-hand sides, exact solutions, coefficient functions) are matched
-numerically against the built-in function ids of include/examg.h; an expression outside that set is unsupported.
+Analytic point functions (boundary values, right-hand sides, exact solutions) are matched numerically against the
+built-in function ids of include/examg.h; any other expression over the node position -- user functions included -- is
+compiled to a postfix program (examg_expr_t) that the device evaluates per point in the order of the expression tree
+(examg_fill_expr / examg_apply_dirichlet_expr / examg_max_err_expr).  Coefficient functions of stencil fields must be built-ins.
 
 Fewer passes than statements, where the statements allow it (`fuse=True`, bit-identical): a `color with` red-black
 sweep is one out-of-place pass (examg_rbgs_sweep_fused), `repeat n times { Smoother ( ) }` with a slotted Jacobi body runs
@@ -849,7 +851,7 @@ class Exa4Program:
         self.fields: Dict[Tuple[str, int], Field] = {}
         self.stencils: Dict[Tuple[str, int], Stencil] = {}
         self.transfer: Dict[str, str] = {}
-        self._fn_cache: Dict[Tuple[str, Optional[int]], Tuple[int, Tuple[float, ...]]] = {}
+        self._fn_cache: Dict[Tuple, Tuple] = {}
         self._rng = random.Random(20240229)
         self.fuse = fuse
         # a coarsest-level function that is exactly the generated conjugate-gradient solver runs as ONE persistent kernel
@@ -925,7 +927,7 @@ class Exa4Program:
                 lay = FieldLayout(nd, inner, ghost, dup, (0, 0, 0), (0, 0, 0), ld.dup_comm, ld.ghost_comm)
                 bc_fn, bc_par = None, ()
                 if fd.bc is not None:
-                    bc_fn, bc_par = self._recognise(fd.bc, lvl)
+                    bc_fn, bc_par = self._analytic(fd.bc, lvl)
                 if ld.vec_len != 1:
                     f = Field.__new__(Field)     # coefficient planes: allocated by the stencil field below
                     f.name, f.level, f.layout, f.num_slots, f.bc_fn, f.bc_params = fd.name, lvl, lay, 1, None, ()
@@ -985,6 +987,63 @@ class Exa4Program:
                     self._fn_cache[key] = (fn, p)
                     return fn, p
         raise Exa4Unsupported("analytic expression is none of the built-in point functions (include/examg.h EXAMG_FN_*)")
+
+    def _compile_point_expr(self, e, lvl: Optional[int], subst: Optional[Dict[str, list]] = None) -> list:
+        """Postfix program (include/examg.h EXAMG_OP_*) of an expression over the node position: operands in the order of
+        the expression tree, user functions inlined, everything that does not depend on the position folded to constants
+        exactly where the tree has it."""
+        k = e[0]
+        fr = _Frame(lvl, {})
+        if k == "num":
+            return [("const", float(e[1]))]
+        if k == "neg":
+            return self._compile_point_expr(e[1], lvl, subst) + [("neg", None)]
+        if k == "id":
+            name = e[1]
+            if subst is not None and name in subst:
+                return list(subst[name])
+            m = _COORD.match(name)
+            if m:
+                return [(m.group(2), None)]
+            return [("const", float(self._eval(e, fr)))]        # globals, PI, vf_gridWidth_*
+        if k == "bin" and e[1] in ("+", "-", "*", "/"):
+            return self._compile_point_expr(e[2], lvl, subst) + self._compile_point_expr(e[3], lvl, subst) + [(e[1], None)]
+        if k == "bin" and e[1] == "**":
+            base = self._compile_point_expr(e[2], lvl, subst)
+            if e[3][0] == "num" and float(e[3][1]) == 2.0:
+                return base + base + [("*", None)]                # the generator expands integer powers into products
+            return base + self._compile_point_expr(e[3], lvl, subst) + [("pow", None)]
+        if k == "call":
+            name, args = e[1], e[3]
+            if name in self.functions:
+                fn = self._resolve(name, self._level_of(e[2], fr) if e[2] is not None else lvl)
+                if len(fn.body) != 1 or fn.body[0][0] != "return" or fn.body[0][1] is None or len(fn.params) != len(args):
+                    raise Exa4Unsupported("function %s inside a point expression must be a single return statement" % name)
+                inner = {p: self._compile_point_expr(a, lvl, subst) for p, a in zip(fn.params, args)}
+                return self._compile_point_expr(fn.body[0][1], lvl, inner)
+            un = {"sin": "sin", "cos": "cos", "exp": "exp", "sinh": "sinh", "cosh": "cosh", "sqrt": "sqrt", "tan": "tan", "log": "log",
+                  "fabs": "fabs", "abs": "fabs", "tanh": "tanh"}
+            if name in un and len(args) == 1:
+                return self._compile_point_expr(args[0], lvl, subst) + [(un[name], None)]
+            if name in ("pow", "max", "min") and len(args) == 2:
+                return self._compile_point_expr(args[0], lvl, subst) + self._compile_point_expr(args[1], lvl, subst) + [(name, None)]
+        raise Exa4Unsupported("point expression with %s %r" % (k, e[1] if len(e) > 1 else ""))
+
+    def _analytic(self, e, lvl: Optional[int]):
+        """(fn id, params) of a built-in point function when the expression is one, else an expression program (ExprC)."""
+        try:
+            return self._recognise(e, lvl)
+        except Exa4Unsupported:
+            pass
+        key = ("expr", repr(e), lvl)
+        if key not in self._fn_cache:
+            from .lib import ExprC
+
+            try:
+                self._fn_cache[key] = (ExprC.from_program(self._compile_point_expr(e, lvl)), ())
+            except ValueError as ex:
+                raise Exa4Unsupported(str(ex))
+        return self._fn_cache[key]
 
     # -- expression evaluation (host scalars) ---------------------------------------------------------------------------
     def _level_of(self, spec, fr: _Frame) -> int:
@@ -1578,7 +1637,10 @@ class Exa4Program:
         mask = self.domain.face_mask()
         if mask:
             self.launches += 1
-            self.ops.apply_dirichlet(f.lc, f.data(slot), self.domain.geom(f.level), f.bc_fn, f.bc_params, mask)
+            if isinstance(f.bc_fn, int):
+                self.ops.apply_dirichlet(f.lc, f.data(slot), self.domain.geom(f.level), f.bc_fn, f.bc_params, mask)
+            else:
+                self.ops.apply_dirichlet_expr(f.lc, f.data(slot), self.domain.geom(f.level), f.bc_fn, mask)
 
     # -- loops ----------------------------------------------------------------------------------------------------------
     def _loop_boxes(self, f: Field, only, where, reduction, fr: _Frame):
@@ -1690,8 +1752,10 @@ class Exa4Program:
             if self._is_scalar(rhs):
                 return ops.set(D.lc, D.data(ds), float(self._eval(rhs, fr)), b, e)
             if not _contains(rhs, ("fld", "sten", "sentry")):
-                fn, par = self._recognise(rhs, D.level)
-                return ops.fill_fn(D.lc, D.data(ds), self.domain.geom(D.level), fn, par, b, e)
+                fn, par = self._analytic(rhs, D.level)
+                if isinstance(fn, int):
+                    return ops.fill_fn(D.lc, D.data(ds), self.domain.geom(D.level), fn, par, b, e)
+                return ops.fill_expr(D.lc, D.data(ds), self.domain.geom(D.level), fn, b, e)
             if rhs[0] == "fld":
                 X, xs = self._field(rhs, fr)
                 return ops.axpby(X.lc, X.data(xs), D.lc, D.data(ds), 1.0, 0.0, b, e)
@@ -1778,11 +1842,14 @@ class Exa4Program:
                         t = locals_[t[1]]
                     if t[0] == "call" and t[1] in ("fabs", "abs") and t[3][0][0] == "bin" and t[3][0][1] == "-" and t[3][0][2][0] == "fld":
                         X, xs = self._field(t[3][0][2], fr)
-                        fn, par = self._recognise(t[3][0][3], X.level)
+                        fn, par = self._analytic(t[3][0][3], X.level)
                         acc = fr.vars[var]
                         for b, e in boxes:
                             self.launches += 1
-                            r = self.ops.max_err_fn(X.lc, X.data(xs), self.domain.geom(X.level), fn, par, b, e)
+                            if isinstance(fn, int):
+                                r = self.ops.max_err_fn(X.lc, X.data(xs), self.domain.geom(X.level), fn, par, b, e)
+                            else:
+                                r = self.ops.max_err_expr(X.lc, X.data(xs), self.domain.geom(X.level), fn, b, e)
                             acc = max(acc, self.ops.scalar_value(self.comm.allreduce(r, "max")))
                         fr.vars[var] = acc
                         continue

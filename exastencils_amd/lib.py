@@ -34,6 +34,29 @@ class GeomC(C.Structure):
     _fields_ = [("pos_begin", C.c_double * 3), ("h", C.c_double * 3)]
 
 
+MAX_EXPR = 128
+OPS = {"const": 0, "x": 1, "y": 2, "z": 3, "+": 4, "-": 5, "*": 6, "/": 7, "neg": 8, "sin": 9, "cos": 10, "exp": 11, "sinh": 12,
+       "cosh": 13, "sqrt": 14, "pow": 15, "tan": 16, "log": 17, "fabs": 18, "max": 19, "min": 20, "tanh": 21}
+
+
+class ExprC(C.Structure):
+    """examg_expr_t: a postfix program over the node position (include/examg.h)."""
+    _fields_ = [("n", C.c_int32), ("op", C.c_int32 * MAX_EXPR), ("c", C.c_double * MAX_EXPR)]
+
+    @staticmethod
+    def from_program(prog):
+        """prog: list of (opcode name, constant or None)."""
+        if not 1 <= len(prog) <= MAX_EXPR:
+            raise ValueError("expression program with %d instructions (limit %d)" % (len(prog), MAX_EXPR))
+        e = ExprC()
+        e.n = len(prog)
+        for i, (name, c) in enumerate(prog):
+            e.op[i] = OPS[name]
+            e.c[i] = float(c) if c is not None else 0.0
+        e.program = list(prog)
+        return e
+
+
 class ExamgError(RuntimeError):
     pass
 
@@ -45,7 +68,7 @@ SYMBOLS = [
     "examg_version", "examg_last_error", "examg_device_count", "examg_stencil_op", "examg_jacobi",
     "examg_rbgs_colour", "examg_residual", "examg_rbgs_sweep_fused", "examg_rbgs_sweep_fused_boxes", "examg_jacobi2", "examg_jacobi2_boxes", "examg_restrict", "examg_residual_restrict", "examg_prolong_add",
     "examg_set", "examg_axpby", "examg_axpby_dev", "examg_reduce_work_bytes", "examg_dot", "examg_max_err_fn",
-    "examg_fill_fn", "examg_apply_dirichlet", "examg_init_varcoeff7", "examg_init_helmholtz27", "examg_pack", "examg_unpack",
+    "examg_fill_fn", "examg_apply_dirichlet", "examg_fill_expr", "examg_apply_dirichlet_expr", "examg_max_err_expr", "examg_init_varcoeff7", "examg_init_helmholtz27", "examg_pack", "examg_unpack",
     "examg_cg_coarse", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
 ]
 
@@ -88,6 +111,10 @@ def load():
     L.examg_max_err_fn.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp, vp, vp]
     L.examg_fill_fn.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp]
     L.examg_apply_dirichlet.argtypes = [lp, vp, gp, C.c_int, dp, C.c_uint32, vp]
+    ep = C.POINTER(ExprC)
+    L.examg_fill_expr.argtypes = [lp, vp, gp, ep, ip, ip, vp]
+    L.examg_apply_dirichlet_expr.argtypes = [lp, vp, gp, ep, C.c_uint32, vp]
+    L.examg_max_err_expr.argtypes = [lp, vp, gp, ep, ip, ip, vp, vp, vp]
     L.examg_init_varcoeff7.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp]
     L.examg_init_helmholtz27.argtypes = [lp, vp, gp, C.c_int, dp, ip, ip, vp]
     L.examg_pack.argtypes = [lp, vp, vp, ip, ip, vp]

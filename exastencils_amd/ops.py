@@ -132,6 +132,20 @@ class HipOps:
                                       ivec(end), self.ptr(out), self.ptr(self._work), self._stream()), "examg_max_err_fn")
         return out
 
+    def max_err_expr(self, l, x, geom, expr, begin, end, out=None):
+        out = self.new_scalar() if out is None else out
+        check(self.L.examg_max_err_expr(C.byref(l), self.ptr(x), C.byref(geom), C.byref(expr), ivec(begin), ivec(end), self.ptr(out),
+                                        self.ptr(self._work), self._stream()), "examg_max_err_expr")
+        return out
+
+    def fill_expr(self, l, x, geom, expr, begin, end):
+        check(self.L.examg_fill_expr(C.byref(l), self.ptr(x), C.byref(geom), C.byref(expr), ivec(begin), ivec(end), self._stream()),
+              "examg_fill_expr")
+
+    def apply_dirichlet_expr(self, l, x, geom, expr, face_mask: int):
+        check(self.L.examg_apply_dirichlet_expr(C.byref(l), self.ptr(x), C.byref(geom), C.byref(expr), int(face_mask), self._stream()),
+              "examg_apply_dirichlet_expr")
+
     def scalar_value(self, t) -> float:
         """Host value of a device scalar (the reference's 8-byte D2H copy after a reduction)."""
         return float(t.item())

@@ -212,6 +212,33 @@ int examg_dot(const examg_layout_t *lx, const double *x, const examg_layout_t *l
 int examg_max_err_fn(const examg_layout_t *l, const double *x, const examg_geom_t *g, int fn, const double *params,
                      const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream);
 
+/* ---- analytic expressions as stack programs ------------------------------------------------------------------------
+ * The generator inlines whatever expression a program gives for boundary values, right-hand sides and exact solutions
+ * into the loop body (boundary/ir/IR_DirichletBC.scala:37-40; `loop over RHS { RHS = <expr> }`).  A library cannot be
+ * recompiled per program, so an expression over the node position travels as a postfix program that a generic kernel
+ * evaluates per point, in the order the expression tree prescribes (same operations in the same order as the printed
+ * code).  op[i]: EXAMG_OP_*; c[i]: the literal of a CONST instruction. */
+#define EXAMG_MAX_EXPR 128
+enum {
+  EXAMG_OP_CONST = 0, EXAMG_OP_X = 1, EXAMG_OP_Y = 2, EXAMG_OP_Z = 3, EXAMG_OP_ADD = 4, EXAMG_OP_SUB = 5, EXAMG_OP_MUL = 6,
+  EXAMG_OP_DIV = 7, EXAMG_OP_NEG = 8, EXAMG_OP_SIN = 9, EXAMG_OP_COS = 10, EXAMG_OP_EXP = 11, EXAMG_OP_SINH = 12,
+  EXAMG_OP_COSH = 13, EXAMG_OP_SQRT = 14, EXAMG_OP_POW = 15, EXAMG_OP_TAN = 16, EXAMG_OP_LOG = 17, EXAMG_OP_FABS = 18,
+  EXAMG_OP_MAX = 19, EXAMG_OP_MIN = 20, EXAMG_OP_TANH = 21
+};
+typedef struct {
+  int32_t n;
+  int32_t op[EXAMG_MAX_EXPR];
+  double c[EXAMG_MAX_EXPR];
+} examg_expr_t;
+
+/* As examg_fill_fn / examg_apply_dirichlet / examg_max_err_fn with the function given as an expression program. */
+int examg_fill_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, const examg_expr_t *e, const int32_t *begin,
+                    const int32_t *end, examg_stream_t stream);
+int examg_apply_dirichlet_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, const examg_expr_t *e,
+                               uint32_t face_mask, examg_stream_t stream);
+int examg_max_err_expr(const examg_layout_t *l, const double *x, const examg_geom_t *g, const examg_expr_t *e,
+                       const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream);
+
 /* ---- K8: x[box] = fn(node position): Dirichlet faces (boundary/ir/IR_DirichletBC.scala:37-40 over
  * the ranges of boundary/ir/IR_ApplyBCFunction.scala:53-83), InitRHS, SetFuncDir. */
 int examg_fill_fn(const examg_layout_t *l, double *x, const examg_geom_t *g, int fn, const double *params,

@@ -160,6 +160,69 @@ class OracleOps:
         out[0] = self.L.orc_max_err_fn(_lp(l), self.ptr(x), _gp(geom), int(fn), _p4(params), _iv(begin), _iv(end))
         return out
 
+    # -- expression programs (include/examg.h EXAMG_OP_*): evaluated with numpy, test-only -----------------------------
+    @staticmethod
+    def _eval_program(prog, x, y, z):
+        import numpy as np
+
+        un = {"neg": np.negative, "sin": np.sin, "cos": np.cos, "exp": np.exp, "sinh": np.sinh, "cosh": np.cosh, "sqrt": np.sqrt,
+              "tan": np.tan, "log": np.log, "fabs": np.abs, "tanh": np.tanh}
+        bi = {"+": np.add, "-": np.subtract, "*": np.multiply, "/": np.divide, "pow": np.power, "max": np.maximum, "min": np.minimum}
+        st = []
+        for name, c in prog:
+            if name == "const":
+                st.append(np.full_like(x, c, dtype=np.float64) + 0.0 * x)
+            elif name in ("x", "y", "z"):
+                st.append({"x": x, "y": y, "z": z}[name] + 0.0 * x)
+            elif name in un:
+                st[-1] = un[name](st[-1])
+            else:
+                b = st.pop()
+                st[-1] = bi[name](st[-1], b)
+        return st[0]
+
+    def _box_points(self, l, geom, begin, end):
+        import numpy as np
+
+        i2, i1, i0 = np.meshgrid(np.arange(begin[2], end[2]), np.arange(begin[1], end[1]), np.arange(begin[0], end[0]), indexing="ij")
+        x = i0 * geom.h[0] + geom.pos_begin[0]
+        y = i1 * geom.h[1] + geom.pos_begin[1]
+        z = i2 * geom.h[2] + geom.pos_begin[2]
+        ref = [l.pad_l[d] + l.ghost_l[d] for d in range(3)]
+        tot = [l.pad_l[d] + l.ghost_l[d] + l.dup_l[d] + l.inner[d] + l.dup_r[d] + l.ghost_r[d] + l.pad_r[d] for d in range(3)]
+        sl = tuple(slice(begin[d] + ref[d], end[d] + ref[d]) for d in (2, 1, 0))
+        return x, y, z, sl, (tot[2], tot[1], tot[0])
+
+    def fill_expr(self, l, x, geom, expr, begin, end):
+        if any(end[d] <= begin[d] for d in range(3)):
+            return
+        px, py, pz, sl, shape = self._box_points(l, geom, begin, end)
+        x.numpy().reshape(shape)[sl] = self._eval_program(expr.program, px, py, pz)
+
+    def max_err_expr(self, l, x, geom, expr, begin, end, out=None):
+        import numpy as np
+
+        out = self.new_scalar() if out is None else out
+        out[0] = 0.0
+        if all(end[d] > begin[d] for d in range(3)):
+            px, py, pz, sl, shape = self._box_points(l, geom, begin, end)
+            out[0] = float(np.max(np.abs(x.numpy().reshape(shape)[sl] - self._eval_program(expr.program, px, py, pz))))
+        return out
+
+    def apply_dirichlet_expr(self, l, x, geom, expr, face_mask):
+        nd = l.nd
+        for d in range(nd):
+            for side in (0, 1):
+                if not face_mask & (1 << (2 * d + side)):
+                    continue
+                b, e = [0, 0, 0], [1, 1, 1]
+                for t in range(nd):
+                    if t == d:
+                        b[t], e[t] = (0, l.dup_l[t]) if side == 0 else (l.dup_l[t] + l.inner[t], l.dup_l[t] + l.inner[t] + l.dup_r[t])
+                    else:
+                        b[t], e[t] = -l.ghost_l[t], l.dup_l[t] + l.inner[t] + l.dup_r[t] + l.ghost_r[t]
+                self.fill_expr(l, x, geom, expr, b, e)
+
     def scalar_value(self, t):
         return float(t.item())
 

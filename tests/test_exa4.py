@@ -246,14 +246,54 @@ Stencil A@all { [0, 0, 0] => 6.0
 @pytest.mark.parametrize("bc,body,what", [
     ("0.0", "loop over u@finest { u@finest += 0.8 / diag ( A@finest ) * ( f@finest - A@finest * u@finest ) }", "without colouring"),
     ("0.0", "loop over u@finest { u@finest = u@finest * f@finest }", "none of the recognised kernels"),
-    ("0.0", "loop over u@finest { u@finest = sin ( vf_nodePosition_x ) * 3.0 }", "built-in point functions"),
-    ("tan ( vf_boundaryCoord_x )", "", "built-in point functions"),
+    ("0.0", "loop over u@finest { u@finest = atan2 ( vf_nodePosition_x, 2.0 ) }", "point expression"),
     ("0.0", "repeat 2 times with contraction [1, 1, 1] { }", "contraction"),
 ])
 def test_constructs_outside_the_subset_are_refused(bc, body, what):
     text = HEADER % bc + "Function Application { %s }" % body
     with pytest.raises(exa4.Exa4Unsupported, match=what):
         exa4.Exa4Program(text, dict(dimensionality=3, minLevel=0, maxLevel=2), ops=OracleOps()).run()
+
+
+def test_arbitrary_point_expressions_become_device_programs():
+    """Boundary values and fills that are none of the built-in functions are compiled to postfix programs (examg_expr_t)
+    in tree order, user functions inlined."""
+    import numpy as np
+
+    text = (HEADER % "tan ( vf_boundaryCoord_x ) + vf_boundaryCoord_y * vf_boundaryCoord_z"
+            + "Globals { Val c : Real = 3.0 }\n"
+            + "Function g ( a : Real, b : Real ) : Real { return exp ( a ) - b ** 2 }\n"
+            + "Function Application { loop over f@finest { f@finest = c * g ( vf_nodePosition_x, vf_nodePosition_z ) }\n"
+            + " apply bc to u@finest }")
+    P = exa4.Exa4Program(text, dict(dimensionality=3, minLevel=0, maxLevel=3), ops=OracleOps())
+    P.run()
+    u, f = P.fields[("u", 3)], P.fields[("f", 3)]
+    assert not isinstance(u.bc_fn, int) and [o for o, _ in u.bc_fn.program] == ["x", "tan", "y", "z", "*", "+"]
+    h = 1.0 / 8
+    fv = f.data().numpy().reshape(f.layout.shape_zyx)
+    x, z = 3 * h, 5 * h
+    assert fv[5 + 1, 2 + 1, 3 + 1] == 3.0 * (np.exp(x) - z * z)          # array index = iterator + ghost
+    uv = u.data().numpy().reshape(u.layout.shape_zyx)
+    assert uv[4 + 1, 2 + 1, 0 + 1] == np.tan(0.0) + (2 * h) * (4 * h)    # x = 0 face
+    assert uv[4 + 1, 2 + 1, 8 + 1] == np.tan(1.0) + (2 * h) * (4 * h)    # x = 1 face
+    assert uv[4 + 1, 2 + 1, 4 + 1] == 0.0                                # interior untouched
+
+
+def test_expression_programs_agree_with_the_built_in_functions(monkeypatch):
+    """The red-black example with its boundary polynomial forced through the program path prints the same bits."""
+    ref = example("poisson3d_rbgs.exa4", 2, 4)
+    ref.run()
+
+    def refuse(self, e, lvl):
+        if e == ("num", 0.0):
+            return 0, ()
+        raise exa4.Exa4Unsupported("forced")
+
+    monkeypatch.setattr(exa4.Exa4Program, "_recognise", refuse)
+    P = example("poisson3d_rbgs.exa4", 2, 4)
+    assert not isinstance(P.fields[("u", 4)].bc_fn, int)
+    P.run()
+    assert P.printed_values == ref.printed_values
 
 
 def test_loop_over_fragments_runs_its_body_once():

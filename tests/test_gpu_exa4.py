@@ -121,3 +121,24 @@ def test_periodic_direction_on_gpu(hip):
     _close(G.printed_values, C_.printed_values, C_.printed_values[0])
     assert G.out[-1] == C_.out[-1]
     assert G.comm.stats["messages"] == 0          # no other block: local copies only
+
+
+def test_program_path_of_boundary_values_equals_built_in_path(hip, monkeypatch):
+    """The red-black example with its boundary polynomial forced through the expression-program kernels: same bits."""
+    from test_exa4 import example
+
+    from exastencils_amd import exa4
+
+    ref = example("poisson3d_rbgs.exa4", 2, 6, ops=hip)
+    ref.run()
+
+    def refuse(self, e, lvl):
+        if e == ("num", 0.0):
+            return 0, ()
+        raise exa4.Exa4Unsupported("forced")
+
+    monkeypatch.setattr(exa4.Exa4Program, "_recognise", refuse)
+    P = example("poisson3d_rbgs.exa4", 2, 6, ops=hip)
+    assert not isinstance(P.fields[("u", 6)].bc_fn, int)
+    P.run()
+    assert P.printed_values == ref.printed_values

@@ -662,3 +662,40 @@ def test_fused_kernels_on_a_large_odd_block(hip):
     finally:
         hip.L.examg_debug_restrict(1)
     assert torch.equal(fc1, fc2)
+
+
+def test_expression_programs_on_device(hip, orc):
+    """examg_fill_expr / examg_apply_dirichlet_expr / examg_max_err_expr: a polynomial program gives the bits of the built-in
+    function with the same expression tree; a transcendental one follows numpy to a few ulp; malformed programs are refused."""
+    from exastencils_amd.lib import ExamgError, ExprC
+
+    n = 24
+    l = FieldLayout.node(3, (n, n, n), 1)
+    g = geom(3, n, 0.25)
+    b, e = box(3, n)
+    poly = ExprC.from_program([("x", None), ("x", None), ("*", None), ("const", 0.5), ("y", None), ("*", None), ("y", None), ("*", None),
+                               ("-", None), ("const", 0.5), ("z", None), ("*", None), ("z", None), ("*", None), ("-", None)])
+    trig = ExprC.from_program([("x", None), ("tan", None), ("y", None), ("z", None), ("*", None), ("exp", None), ("+", None),
+                               ("const", 2.0), ("x", None), ("pow", None), ("-", None)])
+
+    def run(ops, expr):
+        x, y = ops.new_array(l.size), ops.new_array(l.size)
+        ops.fill_expr(l.c_struct(), x, g, expr, b, e)
+        ops.apply_dirichlet_expr(l.c_struct(), y, g, expr, 63)
+        err = ops.scalar_value(ops.max_err_expr(l.c_struct(), y, g, expr, b, e))
+        return ops.to_host(x).copy(), ops.to_host(y).copy(), err
+
+    gx, gy, gerr = run(hip, poly)
+    x2, y2 = hip.new_array(l.size), hip.new_array(l.size)
+    hip.fill_fn(l.c_struct(), x2, g, FN_POLY3D, (), b, e)
+    hip.apply_dirichlet(l.c_struct(), y2, g, FN_POLY3D, (), 63)
+    assert np.array_equal(gx, hip.to_host(x2)) and np.array_equal(gy, hip.to_host(y2))
+    assert gerr == hip.scalar_value(hip.max_err_fn(l.c_struct(), y2, g, FN_POLY3D, (), b, e))
+    cx, cy, cerr = run(orc, poly)
+    assert np.array_equal(gx, cx) and np.array_equal(gy, cy) and gerr == cerr
+    gx, gy, gerr = run(hip, trig)
+    cx, cy, cerr = run(orc, trig)
+    assert _ulp_close(gx, cx, 8) and _ulp_close(gy, cy, 8) and abs(gerr - cerr) <= 1e-12 * max(1.0, cerr)
+    bad = ExprC.from_program([("x", None), ("+", None)])
+    with pytest.raises(ExamgError, match="underflow"):
+        hip.fill_expr(l.c_struct(), hip.new_array(l.size), g, bad, b, e)
