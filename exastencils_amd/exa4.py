@@ -1870,8 +1870,36 @@ class Exa4Program:
                 o[d] = sgn
                 want.append(tuple(o))
         got = {tuple(st[2][3]) + (0,) * (3 - len(st[2][3])): st[3] for st in body}
-        if [tuple(o) for o in A.offsets] != want or set(got) != set(want) or any(st[1] != "=" for st in body):
-            raise Exa4Unsupported("stencil field initialisation: entries must be c,+x,-x,+y,-y[,+z,-z]")
+        offs = [tuple(o) for o in A.offsets]
+        if set(got) != set(offs) or len(got) != len(body) or any(st[1] != "=" for st in body):
+            raise Exa4Unsupported("stencil field initialisation: one assignment per declared entry")
+        try:
+            if offs != want:
+                raise Exa4Unsupported("not the 5/7-entry form of examg_init_varcoeff7")
+            fn, par = self._varcoeff_function(got, want, lvl)
+        except Exa4Unsupported:
+            want = offs
+            # any other discretisation / coefficient function: every entry is a point expression of its own, filled into
+            # its coefficient plane by the expression kernel (one launch per entry)
+            size = A.clayout.size
+            for k, o in enumerate(want):
+                prog, _ = self._analytic(got[o], lvl)
+                plane = A.cfield[k * size:(k + 1) * size]
+                for b, e in boxes:
+                    self.launches += 1
+                    if isinstance(prog, int):
+                        self.ops.fill_fn(A.clayout.c_struct(), plane, self.domain.geom(lvl), prog, _, b, e)
+                    else:
+                        self.ops.fill_expr(A.clayout.c_struct(), plane, self.domain.geom(lvl), prog, b, e)
+            return
+        for b, e in boxes:
+            self.launches += 1
+            self.ops.init_varcoeff7(A.clayout.c_struct(), A.cfield, self.domain.geom(lvl), fn, par, b, e)
+
+    def _varcoeff_function(self, got, want, lvl: int):
+        """Coefficient function id if the entries are -div(a grad) with a built-in `a` at the half points, in the exact
+        form of examg_init_varcoeff7."""
+        nd = self.nd
         calls = [c for c in _find_calls(got[want[1]]) if c[1] in self.functions]
         if not calls:
             raise Exa4Unsupported("stencil field initialisation without a coefficient function")
@@ -1897,9 +1925,7 @@ class Exa4Program:
                 v = self._point_eval(got[o], lvl, x, y, z)
                 if abs(v - ref[o]) > 1e-11 * max(1.0, abs(ref[o])):
                     raise Exa4Unsupported("stencil field entry %r is not -a(x +- h/2)/h^2" % (o,))
-        for b, e in boxes:
-            self.launches += 1
-            self.ops.init_varcoeff7(A.clayout.c_struct(), A.cfield, self.domain.geom(lvl), fn, par, b, e)
+        return fn, par
 
 
 # -- AST helpers ----------------------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ class GeomC(C.Structure):
     _fields_ = [("pos_begin", C.c_double * 3), ("h", C.c_double * 3)]
 
 
-MAX_EXPR = 128
+MAX_EXPR = 256
 OPS = {"const": 0, "x": 1, "y": 2, "z": 3, "+": 4, "-": 5, "*": 6, "/": 7, "neg": 8, "sin": 9, "cos": 10, "exp": 11, "sinh": 12,
        "cosh": 13, "sqrt": 14, "pow": 15, "tan": 16, "log": 17, "fabs": 18, "max": 19, "min": 20, "tanh": 21}
 

@@ -218,7 +218,7 @@ int examg_max_err_fn(const examg_layout_t *l, const double *x, const examg_geom_
  * recompiled per program, so an expression over the node position travels as a postfix program that a generic kernel
  * evaluates per point, in the order the expression tree prescribes (same operations in the same order as the printed
  * code).  op[i]: EXAMG_OP_*; c[i]: the literal of a CONST instruction. */
-#define EXAMG_MAX_EXPR 128
+#define EXAMG_MAX_EXPR 256
 enum {
   EXAMG_OP_CONST = 0, EXAMG_OP_X = 1, EXAMG_OP_Y = 2, EXAMG_OP_Z = 3, EXAMG_OP_ADD = 4, EXAMG_OP_SUB = 5, EXAMG_OP_MUL = 6,
   EXAMG_OP_DIV = 7, EXAMG_OP_NEG = 8, EXAMG_OP_SIN = 9, EXAMG_OP_COS = 10, EXAMG_OP_EXP = 11, EXAMG_OP_SINH = 12,

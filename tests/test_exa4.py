@@ -296,6 +296,25 @@ def test_expression_programs_agree_with_the_built_in_functions(monkeypatch):
     assert P.printed_values == ref.printed_values
 
 
+def test_stencil_field_entries_as_expression_programs(monkeypatch):
+    """The variable-coefficient example with its seven coefficient expressions filled plane by plane through the program
+    path instead of examg_init_varcoeff7: same expression tree (bit-identical on the device, tests/test_gpu_exa4.py; the CPU
+    stand-ins evaluate exp() with numpy in one path and glibc in the other, an ulp apart)."""
+    ref = example("varcoeff3d.exa4", 0, 3)
+    ref.run()
+
+    def refuse(self, got, want, lvl):
+        raise exa4.Exa4Unsupported("forced")
+
+    monkeypatch.setattr(exa4.Exa4Program, "_varcoeff_function", refuse)
+    P = example("varcoeff3d.exa4", 0, 3)
+    P.run()
+    assert len(P.printed_values) == len(ref.printed_values)
+    for x, y in zip(P.printed_values, ref.printed_values):
+        assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * ref.printed_values[0]
+    assert P.launches > ref.launches
+
+
 def test_loop_over_fragments_runs_its_body_once():
     text = HEADER % "0.0" + "Function Application { loop over fragments { loop over u@finest { u@finest = 2.5 } } }"
     P = exa4.Exa4Program(text, dict(dimensionality=3, minLevel=0, maxLevel=2), ops=OracleOps())

@@ -142,3 +142,21 @@ def test_program_path_of_boundary_values_equals_built_in_path(hip, monkeypatch):
     assert not isinstance(P.fields[("u", 6)].bc_fn, int)
     P.run()
     assert P.printed_values == ref.printed_values
+
+
+def test_stencil_field_entries_as_programs_equal_the_dedicated_kernel(hip, monkeypatch):
+    """Seven coefficient expressions filled plane by plane by the expression kernel == examg_init_varcoeff7, bit for bit."""
+    from test_exa4 import example
+
+    from exastencils_amd import exa4
+
+    ref = example("varcoeff3d.exa4", 1, 5, ops=hip)
+    ref.run()
+
+    def refuse(self, got, want, lvl):
+        raise exa4.Exa4Unsupported("forced")
+
+    monkeypatch.setattr(exa4.Exa4Program, "_varcoeff_function", refuse)
+    P = example("varcoeff3d.exa4", 1, 5, ops=hip)
+    P.run()
+    assert P.printed_values == ref.printed_values
