@@ -23,11 +23,12 @@ Loop bodies recognised (anything else raises Exa4Unsupported -- nothing is silen
                                                                                       examg_rbgs_colour
   RHS@coarser = [s *] Restriction * Residual | U += Prolongation@coarser * U@coarser  examg_restrict / examg_prolong_add
   s += F*G (reduction +) | s = max(s, fabs(F - analytic)) (reduction max)             examg_dot / examg_max_err_fn
-  A:[o] = -a(x +- h/2)/h^2 ... (7 entries of a stencil field)                         examg_init_varcoeff7
+  A:[o] = expr (every entry of a stencil field)                                      examg_init_varcoeff7 / examg_fill_expr
 Analytic point functions (boundary values, right-hand sides, exact solutions) are matched numerically against the
 built-in function ids of include/examg.h; any other expression over the node position -- user functions included -- is
 compiled to a postfix program (examg_expr_t) that the device evaluates per point in the order of the expression tree
-(examg_fill_expr / examg_apply_dirichlet_expr / examg_max_err_expr).  Coefficient functions of stencil fields must be built-ins.
+(examg_fill_expr / examg_apply_dirichlet_expr / examg_max_err_expr).  Stencil-field entries `A:[o] = expr` take
+examg_init_varcoeff7 when they are -div(a grad) with a built-in `a`, else one expression program per coefficient plane.
 
 Fewer passes than statements, where the statements allow it (`fuse=True`, bit-identical): a `color with` red-black
 sweep is one out-of-place pass (examg_rbgs_sweep_fused), `repeat n times { Smoother ( ) }` with a slotted Jacobi body runs
