@@ -118,6 +118,7 @@ class ConfigL4:
     fused_rbgs: bool = False      # one-pass red-black sweep (out of place, pointer swap)
     fused_residual_restrict: bool = False   # single block: `Residual = ...` + restriction as one pass, fine residual not stored
     agglomerate_level: Optional[int] = None   # blocks > 1: levels <= this are solved redundantly on every rank (see _agg_cycle)
+    agglomerate_extra_levels: int = 0         # the gathered hierarchy coarsens this many levels below min_level
 
 
 class SolverFromL4(_Program):
@@ -155,7 +156,10 @@ class SolverFromL4(_Program):
             # kernel, no further communication -- then keeps its own part of the correction.  Same statements as the
             # distributed cycle; only the order in which the coarse-grid CG's reductions add differs.
             whole = RectDomain(nd, (1, 1, 1), 0, tuple(dom.num_blocks[d] * dom.frag_len[d] for d in range(3)), dom.lo, dom.hi)
-            acfg = ConfigL4(nd=nd, min_level=lo, max_level=k, frag_len=whole.frag_len, omega=cfg.omega, n_smooth=cfg.n_smooth,
+            # The whole coarsest level is `blocks` times larger than one block's (16 x 32 x 64 points on 8 GPUs): the gathered
+            # hierarchy may go on coarsening (agglomerate_extra_levels) so that the CG again sees a grid of a few hundred
+            # points -- the cycle then has more levels than on one GPU, as a larger problem should.
+            acfg = ConfigL4(nd=nd, min_level=max(0, lo - cfg.agglomerate_extra_levels), max_level=k, frag_len=whole.frag_len, omega=cfg.omega, n_smooth=cfg.n_smooth,
                             cg_max=cfg.cg_max, cg_tol=cfg.cg_tol, bc_fn=FN_ZERO, align=cfg.align, fused_coarse=True,
                             fused_rbgs=cfg.fused_rbgs)
             self._agg = SolverFromL4(acfg, ops, whole, Communicator(whole, ops))

@@ -88,7 +88,8 @@ def _worker_solver(rank, world, port, blocks, case, out_dir):
         P = SolverFromL3(ConfigL3(**HELMHOLTZ27, frag_len=flen), ops, dom, comm)
     else:
         P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, frag_len=flen, tol=1e-6, fused_coarse=False,
-                                  fused_rbgs="_fused" in case, agglomerate_level=2 if "_agg" in case else None), ops, dom, comm)
+                                  fused_rbgs="_fused" in case, agglomerate_level=2 if "_agg" in case else None,
+                                  agglomerate_extra_levels=1 if "_aggx" in case else 0), ops, dom, comm)
     P.setup()
     P.Solve()
     S = P.Solution[4]
@@ -121,7 +122,8 @@ def _reference_single(case):
 
         P = SolverFromL3(ConfigL3(**HELMHOLTZ27, frag_len=flen), ops)
     else:
-        P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, frag_len=flen, tol=1e-6, fused_coarse=False), ops)
+        # "_aggx": the gathered hierarchy of the decomposed run coarsens one level below min_level = the single block with min_level 0
+        P = SolverFromL4(ConfigL4(nd=3, min_level=0 if "_aggx" in case else 1, max_level=4, frag_len=flen, tol=1e-6, fused_coarse=False), ops)
     P.setup()
     P.Solve()
     S = P.Solution[4]
@@ -134,7 +136,7 @@ def _reference_single(case):
 @pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"),
                                          ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
                                          ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 2, 1), "rbgs_l4_cg"), ((2, 2, 1), "rbgs_l4_nodup_cg"), ((2, 1, 1), "rbgs_l4_fused"),
-                                         ((2, 2, 1), "rbgs_l4_fused_nodup_cg"), ((2, 1, 1), "rbgs_l4_agg"), ((1, 1, 2), "jacobi_l3_tb_cg"),
+                                         ((2, 2, 1), "rbgs_l4_fused_nodup_cg"), ((2, 1, 1), "rbgs_l4_agg"), ((1, 1, 2), "rbgs_l4_fused_aggx_nodup_cg"), ((1, 1, 2), "jacobi_l3_tb_cg"),
                                          ((1, 2, 2), "rbgs_l4_fused_nodup_cg"),
                                          ((2, 2, 1), "rbgs_l4_fused_agg_nodup_cg"), ((2, 1, 1), "fmg_varcoeff"), ((2, 2, 1), "helmholtz27")])
 def test_decomposed_solve_matches_single_block(tmp_path, blocks, case):
