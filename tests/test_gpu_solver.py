@@ -372,3 +372,26 @@ def test_reference_large_hybrid_on_one_gpu():
                            timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         assert json.loads(r.stdout.strip().splitlines()[-1])["matches_reference_results"]
+
+
+def test_config4_algorithm_fmg_with_red_black_cycles(hip):
+    """BASELINE configs[4] names FMG on the Poisson3D problem: nested iteration from the coarsest level (boundary values of
+    every level from the function, zero right-hand side, cycle, prolongation to the next level) followed by red-black
+    V(3,3) cycles -- the FMG driver of Testing/FMG/3D_Trigonometric.exa4:189-242 with the smoother of
+    Testing/Smoothers/RBGS.exa4:125-133 on the h-scaled Laplacian, against the oracle program at 64^3."""
+    from exastencils_amd.solver import ConfigL3, SolverFromL3
+
+    kw = dict(nd=3, min_level=2, max_level=6, smoother="rbgs", omega=1.0, stencil="scaled", restrict_scale=1.0, tol=1e-8, cg_max=512,
+              bc_fn=1, fmg=True)
+    O = mg.ProgramB(mg.ConfigB(**kw))
+    O.setup()
+    O.Solve()
+    P = SolverFromL3(ConfigL3(**kw), hip)
+    P.setup()
+    P.Solve()
+    assert P.iterations == O.iterations
+    _close(P.res_history, O.res_history)
+    plain = mg.ProgramB(mg.ConfigB(**dict(kw, fmg=False)))
+    plain.setup()
+    plain.Solve()
+    assert O.res_history[1] < 0.2 * plain.res_history[1]          # the nested start pays off: first V-cycle starts far closer
