@@ -435,6 +435,7 @@ class ConfigL3:
     align: int = 0
     temporal_blocking: bool = False   # pairs of Jacobi steps in one pass (exastencils_amd/smoothers.py)
     fused_residual_restrict: bool = False   # single block: UpResidual + Restriction as one pass (fine residual not stored)
+    fused_rbgs: bool = False          # red-black sweeps as one out-of-place pass (with neighbours: fused interior + shell)
     ksq: float = 0.0                  # stencil 'helmholtz27': shift k^2 of  -div(a grad u) - k^2 u  (config 4)
     rhs_from_solution: bool = False   # RHS = A * sol_fn (discrete manufactured solution)
 
@@ -475,6 +476,7 @@ class SolverFromL3(_Program):
                 ops.init_varcoeff7(nocomm.c_struct(), cf, dom.geom(l), cfg.coef_fn, prm, b, e)
                 self.Laplace[l] = Stencil(stencil_field_offsets(nd), [], cf, nocomm)
         nc = dom.ncells(lo)
+        self._shell_epoch: Dict[int, int] = {}
         self.VecP = Field("VecP", lo, FieldLayout.node(nd, nc, 1, True, True, cfg.align), ops, 1, FN_ZERO)
         self.VecGradP = Field("VecGradP", lo, FieldLayout.node(nd, nc, 0, False, False, cfg.align), ops, 1, None)
 
@@ -510,6 +512,25 @@ class SolverFromL3(_Program):
             self.communicate(S, S.active, "ghost")
             self.ops.stencil_op(SMOOTH, S.lc, S.data(S.active), F.lc, F.data(), S.lc, S.data(S.next), A, self._w(l), -1, b, e)
             S.advance()
+        elif self.cfg.fused_rbgs and A.cfield is None:
+            # both colour loops in one out-of-place pass; the second array carries the field's boundary planes, refreshed
+            # whenever they were rewritten (SetFuncDir / ResetBC of the FMG start)
+            from .smoothers import rbgs_sweep
+
+            if not hasattr(self, "_rb_alt"):
+                self._rb_alt, self._rb_tmp, self._rb_epoch = {}, {}, {}
+            alt = self._rb_alt.get(l)
+            if alt is None:
+                alt = self._rb_alt[l] = self.ops.new_array(S.layout.size)
+                self._rb_tmp[l] = Field("SolutionSweepTmp", l, S.layout, self.ops, 1, None)
+            if self._rb_epoch.get(l) != self._shell_epoch.get(l, 0):
+                lay = S.layout
+                gb = [lay.idx("GLB", d) if d < self.nd else 0 for d in range(3)]
+                ge = [lay.idx("GRE", d) if d < self.nd else 1 for d in range(3)]
+                self.ops.axpby(S.lc, S.data(), S.lc, alt, 1.0, 0.0, gb, ge)
+                self._rb_epoch[l] = self._shell_epoch.get(l, 0)
+            self.communicate(S, S.active, "dup")       # the ghost part of `communicate Solution` is inside rbgs_sweep
+            self._rb_alt[l] = rbgs_sweep(self.ops, self.comm, self.domain, S, F, A, self._w(l), alt, self._rb_tmp[l], 0)
         else:                                   # Testing/Smoothers/RBGS.exa4:125-133
             for colour in (0, 1):
                 self.communicate(S, S.active)
@@ -625,6 +646,7 @@ class SolverFromL3(_Program):
                         b[t], e[t] = lay.idx("DLB", t), lay.idx("DRE", t)
                 for s_ in range(S.num_slots):
                     self.ops.fill_fn(S.lc, S.data(s_), dom.geom(l), self.cfg.bc_fn, (self.cfg.kappa,), b, e)
+        self._shell_epoch[l] = self._shell_epoch.get(l, 0) + 1
 
     def InitRHS(self, l: int):
         F = self.RHS[l]
@@ -637,6 +659,7 @@ class SolverFromL3(_Program):
     def ResetBC(self, l: int):
         for s_ in range(self.Solution[l].num_slots):
             self.apply_bc(self.Solution[l], s_)
+        self._shell_epoch[l] = self._shell_epoch.get(l, 0) + 1
 
     def FMG(self, l: int):
         self.SetFuncDir(l)

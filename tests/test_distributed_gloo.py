@@ -80,6 +80,9 @@ def _worker_solver(rank, world, port, blocks, case, out_dir):
     elif case == "rbgs_l3":
         P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="rbgs", omega=1.0, stencil="unit",
                                   restrict_scale=4.0, tol=1e-5, cg_max=512), ops, dom, comm)
+    elif case == "rbgs_l3_fused":
+        P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="rbgs", omega=1.0, stencil="unit",
+                                  restrict_scale=4.0, tol=1e-5, cg_max=512, fused_rbgs=True), ops, dom, comm)
     elif case == "fmg_varcoeff":
         P = SolverFromL3(ConfigL3(**_FMG_VAR, frag_len=flen), ops, dom, comm)
     elif case == "helmholtz27":
@@ -112,7 +115,7 @@ def _reference_single(case):
     if case in ("jacobi_l3", "jacobi_l3_tb", "jacobi_l3_tb_cg"):
         P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="jacobi", omega=0.8, stencil="unit",
                                   restrict_scale=4.0, tol=1e-5, cg_max=512), ops)
-    elif case == "rbgs_l3":
+    elif case in ("rbgs_l3", "rbgs_l3_fused"):
         P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, frag_len=flen, smoother="rbgs", omega=1.0, stencil="unit",
                                   restrict_scale=4.0, tol=1e-5, cg_max=512), ops)
     elif case == "fmg_varcoeff":
@@ -133,7 +136,7 @@ def _reference_single(case):
     return P, own
 
 
-@pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"),
+@pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"), ((1, 2, 2), "rbgs_l3_fused"),
                                          ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
                                          ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 2, 1), "rbgs_l4_cg"), ((2, 2, 1), "rbgs_l4_nodup_cg"), ((2, 1, 1), "rbgs_l4_fused"),
                                          ((2, 2, 1), "rbgs_l4_fused_nodup_cg"), ((2, 1, 1), "rbgs_l4_agg"), ((1, 1, 2), "rbgs_l4_fused_aggx_nodup_cg"), ((1, 1, 2), "jacobi_l3_tb_cg"),

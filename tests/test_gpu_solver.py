@@ -395,3 +395,11 @@ def test_config4_algorithm_fmg_with_red_black_cycles(hip):
     plain.setup()
     plain.Solve()
     assert O.res_history[1] < 0.2 * plain.res_history[1]          # the nested start pays off: first V-cycle starts far closer
+    # red-black sweeps as single out-of-place passes (second array's boundary planes follow SetFuncDir / ResetBC): same bits
+    Q = SolverFromL3(ConfigL3(**dict(kw, max_level=7), fused_rbgs=True, fused_residual_restrict=True), hip)
+    Q.setup()
+    Q.Solve()
+    R = SolverFromL3(ConfigL3(**dict(kw, max_level=7)), hip)
+    R.setup()
+    R.Solve()
+    assert Q.res_history == R.res_history
