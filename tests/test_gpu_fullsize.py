@@ -1,0 +1,124 @@
+"""Parity at BASELINE.json's full per-GPU size (512^3 cells): the HIP path against residual histories and solution digests that
+this repository's CPU oracle produced at that size (tests/golden/own/*.json -- "own oracle" fixtures written by
+tools/make_own_goldens.py in the build container; NOT reference data: the reference has no golden at these sizes).
+
+Tolerance: 1e-10 relative per iterate (BASELINE.json north_star); iteration counts equal; digests of the final solution
+(l2 norm, sums of three z planes) within 1e-10 of their magnitude.  Every case runs the plain statement-by-statement driver
+and the fused drivers (one-pass red-black sweeps, residual + restriction in one pass, two-step Jacobi passes) -- the
+configuration bench.py times."""
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from exastencils_amd.solver import ConfigL3, ConfigL4, SolverFromL3, SolverFromL4
+
+RTOL = 1e-10
+OWN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "own")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from exastencils_amd.ops import HipOps
+
+    return HipOps(0)
+
+
+def _fixture(name):
+    with open(os.path.join(OWN, name + ".json")) as f:
+        rec = json.load(f)
+    rec["res"] = [float.fromhex(h) for h in rec["res_history"]]
+    rec["err"] = [float.fromhex(h) for h in rec["err_history"]]
+    return rec
+
+
+def _check_history(got, want, rtol=RTOL):
+    assert len(got) == len(want), (got, want)
+    for x, y in zip(got, want):
+        assert abs(x - y) <= rtol * abs(y), ("iterate differs by %.3e relative" % (abs(x - y) / abs(y)), got, want)
+
+
+def _check_solution(hip, S, rec):
+    """l2 norm and plane sums of the duplicate + inner nodes of the final solution (the fixture's digests)."""
+    import torch
+
+    lay = S.layout
+    v = S.data().view(*lay.shape_zyx)
+    sl = tuple(slice(lay.pad_l[d] + lay.ghost[d], lay.tot(d) - lay.ghost[d] - lay.pad_r[d]) for d in (2, 1, 0))
+    v = v[sl]
+    sol = rec["solution"]
+    l2 = float(torch.sqrt(torch.sum(v * v)).item())
+    want = float.fromhex(sol["l2"])
+    assert abs(l2 - want) <= RTOL * want, (l2, want)
+    for p, s_hex, a_hex in zip(sol["planes"], sol["plane_sums"], sol["plane_abs_sums"]):
+        s = float(torch.sum(v[p]).item())
+        assert abs(s - float.fromhex(s_hex)) <= RTOL * float.fromhex(a_hex), (p, s, float.fromhex(s_hex))
+    del v
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_config3_512_history_vs_own_oracle(hip, fused):
+    """BASELINE configs[2]: Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:121-249 at 512^3, levels 4..9, RBGS V(3,3),
+    CG coarse solve, stop at 1e-6: every residual of the Solve loop within 1e-10 of the oracle's."""
+    rec = _fixture("config3_512")
+    cfg = ConfigL4(**rec["config"], fused_rbgs=fused, fused_residual_restrict=fused)
+    P = SolverFromL4(cfg, hip)
+    P.setup()
+    P.Solve()
+    assert P.iterations == rec["iterations"]
+    _check_history(P.res_history, rec["res"])
+    _check_solution(hip, P.Solution[cfg.max_level], rec)
+
+
+def test_config3_512_graph_replay_history(hip):
+    """The same solve with the V-cycle replayed from a hipGraph (what bench.py times)."""
+    rec = _fixture("config3_512")
+    cfg = ConfigL4(**rec["config"], fused_rbgs=True, fused_residual_restrict=True)
+    P = SolverFromL4(cfg, hip)
+    P.setup()
+    P.capture_cycle()
+    P.reset()
+    P.Solve(use_graph=True)
+    assert P.iterations == rec["iterations"]
+    _check_history(P.res_history, rec["res"])
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_config5_512_fmg_history_vs_own_oracle(hip, fused):
+    """BASELINE configs[4]'s algorithm on one block of 512^3: FMG start (Testing/FMG/3D_Trigonometric.exa4:189-242) then
+    red-black V(3,3) cycles (Testing/Smoothers/RBGS.exa4:125-133), levels 2..9."""
+    rec = _fixture("config5_512")
+    kw = dict(rec["config"])
+    P = SolverFromL3(ConfigL3(**kw, fused_rbgs=fused, fused_residual_restrict=fused), hip)
+    P.setup()
+    P.Solve()
+    assert P.iterations == rec["iterations"]
+    _check_history(P.res_history, rec["res"])
+    _check_solution(hip, P.Solution[kw["max_level"]], rec)
+
+
+@pytest.mark.parametrize("name", ["config4_256", "config4_512"])
+def test_config4_helmholtz27_history_vs_own_oracle(hip, name):
+    """BASELINE configs[3]'s operator at full per-GPU size: 27-entry variable-coefficient Helmholtz stencil field, Jacobi
+    V(3,3) cycles to 1e-8 (parity unpinned by the reference; the oracle itself is pinned on the 7-entry stencil-field
+    program Testing/SISC/3D_VarCoeff).  The coefficient profile and the manufactured solution pass through exp / sin of the
+    device's libm on this side and of glibc on the oracle's (last-ulp differences of the problem DATA, ~1e-16 relative);
+    histories still agree within 1e-10 per iterate."""
+    import torch
+
+    rec = _fixture(name)
+    kw = dict(rec["config"])
+    kw["frag_len"] = tuple(kw["frag_len"])
+    P = SolverFromL3(ConfigL3(**kw), hip)
+    P.setup()
+    P.Solve()
+    assert P.iterations == rec["iterations"]
+    _check_history(P.res_history, rec["res"])
+    for x, y in zip(P.err_history, rec["err"]):
+        assert abs(x - y) <= 1e-10 * max(abs(y), abs(rec["err"][0])), (P.err_history, rec["err"])
+    _check_solution(hip, P.Solution[kw["max_level"]], rec)
+    del P
+    torch.cuda.empty_cache()

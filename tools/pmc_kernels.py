@@ -1,0 +1,107 @@
+#!/usr/bin/env python
+"""Launch every hot kernel of the V-cycle a few times at one level, in a fixed order, for rocprofv3 counter passes:
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmcK_FETCH -- python3 $R/tools/pmc_kernels.py
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmcK_WRITE -- python3 $R/tools/pmc_kernels.py
+    python3 $R/tools/pmc_kernels.py --time          # un-profiled timing pass (HIP events), gpurun_out/pmcK_times.json
+    python3 $R/tools/pmc_reduce.py                  # -> profiles/r02_pmc_kernels.json
+
+Each case is one kernel launch; `compulsory` = distinct field.slot reads/writes x 8 B x points of the launch (the reference's
+own rule, Compiler/src/exastencils/performance/ir/IR_EvaluatePerformanceEstimates.scala:206-215)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def cases(ops, level, with27=True, align=0):
+    from exastencils_amd.field import Stencil, helmholtz27_offsets, laplace_fd
+    from exastencils_amd.layout import FieldLayout
+    from exastencils_amd.lib import GeomC
+
+    n = 1 << level
+    nc, ncc = (n, n, n), (n // 2,) * 3
+    lu, lf = FieldLayout.node(3, nc, 1, True, True, align), FieldLayout.node(3, nc, 0, True, False, align)
+    luc, lfc = FieldLayout.node(3, ncc, 1, True, True, align), FieldLayout.node(3, ncc, 0, True, False, align)
+    u, un, r = (ops.new_array(lu.size) for _ in range(3))
+    f = ops.new_array(lf.size)
+    uc, fc = ops.new_array(luc.size), ops.new_array(lfc.size)
+    for i, t in enumerate((u, un, f, r, uc, fc)):
+        ops.fill_random(t, 100 + i)
+    A = laplace_fd(3, (1.0 / n,) * 3)
+    w = 0.8 / A.diag
+    b, e = [1, 1, 1], [n, n, n]
+    bc, ec = [1, 1, 1], [n // 2] * 3
+    L, F, Lc, Fc = lu.c_struct(), lf.c_struct(), luc.c_struct(), lfc.c_struct()
+    pts, cpts = (n - 1) ** 3, (n // 2 - 1) ** 3
+    out = ops.new_scalar()
+    # name, launch, kernel-name pattern, compulsory bytes per launch, lattice updates per launch
+    cs = [
+        ("jacobi_1step", lambda: ops.stencil_op(2, L, u, F, f, L, un, A, w, -1, b, e), "k_stencil7_zmarch<2", 24 * pts, pts),
+        ("residual", lambda: ops.stencil_op(1, L, u, F, f, L, r, A, 0.0, -1, b, e), "k_stencil7_zmarch<1", 24 * pts, pts),
+        ("rbgs_half_sweep", lambda: ops.stencil_op(2, L, u, F, f, L, u, A, w, 0, b, e), "k_stencil7_zmarch<2", 24 * pts, pts // 2),
+        ("jacobi_2step", lambda: ops.jacobi2(L, u, un, None, F, f, A, w, b, e), "k_two_stage7_lds<0, false", 24 * pts, 2 * pts),
+        ("rbgs_fused_sweep", lambda: ops.rbgs_sweep_fused(L, u, un, F, f, A, w, 0, b, e), "k_two_stage7_lds<0, true", 24 * pts, pts),
+        ("residual_restrict", lambda: ops.residual_restrict(L, u, F, f, L, r, A, Fc, fc, 1.0, b, e, bc, ec), "k_residual_restrict3",
+         16 * pts + 8 * cpts, pts),
+        ("restrict", lambda: ops.restrict(L, r, Fc, fc, 1.0, bc, ec), "k_restrict3_wide", 8 * pts + 8 * cpts, cpts),
+        ("prolong_add", lambda: ops.prolong_add(Lc, uc, L, u, b, e), "k_prolong_add3_pairs", 16 * pts + 8 * cpts, pts),
+        ("dot_norm", lambda: ops.dot(L, r, L, r, b, e, out), "k_dot_rows", 8 * pts, pts),
+    ]
+    if with27:
+        nocomm = FieldLayout.node(3, nc, 0, False, False, align)
+        cf = ops.new_array(27 * nocomm.size)
+        g = GeomC()
+        for d in range(3):
+            g.h[d] = 1.0 / n
+        ops.init_helmholtz27(nocomm.c_struct(), cf, g, 7, (10.0, 2.0), [0, 0, 0], [n + 1] * 3)
+        A27 = Stencil(helmholtz27_offsets(), [], cf, nocomm)
+        Fn = nocomm.c_struct()
+        f27 = ops.new_array(nocomm.size)
+        ops.fill_random(f27, 7)
+        cs.append(("jacobi_27entry_field", lambda: ops.stencil_op(2, L, u, Fn, f27, L, un, A27, 0.8, -1, b, e),
+                   "k_stencilfield_unrolled<2, 27>", (24 + 8 * 27) * pts, pts))
+    return cs, dict(u=u)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--level", type=int, default=9)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--time", action="store_true", help="timing pass: 20 launches per case between HIP events")
+    ap.add_argument("--no27", action="store_true")
+    ap.add_argument("--align", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+
+    from exastencils_amd.ops import HipOps
+
+    ops = HipOps(0)
+    cs, keep = cases(ops, args.level, not args.no27, args.align)
+    res = []
+    for name, fn, pattern, comp, lu in cs:
+        fn()
+        torch.cuda.synchronize()
+        reps = 20 if args.time else args.reps
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        res.append(dict(case=name, kernel=pattern, compulsory_bytes=comp, lattice_updates=lu, ms=ms, level=args.level, align=args.align))
+        if args.time:
+            print("%-22s %8.4f ms  %6.0f GB/s compulsory  frac %.3f" % (name, ms, comp / ms / 1e6, comp / ms / 1e6 / 8000.0), flush=True)
+        ops.fill_random(keep["u"], 100)
+    if args.time:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(res, open(os.path.join(ROOT, "gpurun_out", "pmcK_times_L%d%s.json" % (args.level, "_a%d" % args.align if args.align else "")), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
