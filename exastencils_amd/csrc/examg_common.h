@@ -139,6 +139,9 @@ __device__ __forceinline__ void store2(double *p, d2 v) {
   s.b = v.y;
   *reinterpret_cast<d2u *>(p) = s;
 }
+// non-temporal 16-byte store at 8-byte alignment (global_store_dwordx4 ... nt)
+typedef d2 d2_a8 __attribute__((aligned(8)));
+__device__ __forceinline__ void store2_nt(double *p, d2 v) { __builtin_nontemporal_store(v, (d2_a8 *)p); }
 // 16-byte load where both points may be read, scalar loads at the edges of an allocation / box, 0 outside
 __device__ __forceinline__ d2 load2g(const double *p, bool oka, bool okb) {
   d2 r = {0.0, 0.0};

@@ -541,43 +541,6 @@ extern "C" int examg_fill_random(double *x, int64_t n, uint64_t seed, examg_stre
   return 0;
 }
 
-// ---- bandwidth reference points for tools/tune_jacobi.py (not part of the ABI) -------------------
-namespace examg {
-typedef double dv2 __attribute__((ext_vector_type(2)));
-template <bool NT, int MODE>
-__global__ void __launch_bounds__(256) k_triad(double *__restrict__ o, const double *__restrict__ a, const double *__restrict__ b,
-                                               long long n2, double w) {
-  // MODE 0: o = a + w*b (2 reads, 1 write)   1: o = a (copy)   2: read only (a+b reduced, never stored unless NaN)
-  const dv2 *a2 = reinterpret_cast<const dv2 *>(a);
-  const dv2 *b2 = reinterpret_cast<const dv2 *>(b);
-  dv2 *o2 = reinterpret_cast<dv2 *>(o);
-  dv2 acc = {0.0, 0.0};
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-    dv2 r;
-    if (MODE == 0) r = a2[i] + w * b2[i];
-    else if (MODE == 1) r = a2[i];
-    else { acc += a2[i] + b2[i]; continue; }
-    if (NT) { __builtin_nontemporal_store(r.x, &o[2 * i]); __builtin_nontemporal_store(r.y, &o[2 * i + 1]); }
-    else o2[i] = r;
-  }
-  if (MODE == 2 && acc.x + acc.y == 123.456) o[0] = acc.x;
-}
-}  // namespace examg
-
-extern "C" int examg_debug_triad(double *o, const double *a, const double *b, int64_t n, double w, int nt, int mode,
-                                 int blocks, examg_stream_t stream) {
-  hipStream_t s = (hipStream_t)stream;
-  const long long n2 = n / 2;
-  dim3 g(blocks), bl(256);
-#define TR(NT_, M_) hipLaunchKernelGGL((examg::k_triad<NT_, M_>), g, bl, 0, s, o, a, b, n2, w)
-  if (mode == 0) { if (nt) TR(true, 0); else TR(false, 0); }
-  else if (mode == 1) { if (nt) TR(true, 1); else TR(false, 1); }
-  else TR(false, 2);
-#undef TR
-  EXAMG_CHECK_LAUNCH("k_triad");
-  return 0;
-}
-
 // ---- external fields (interfacing/ir/IR_CopyToExternalField.scala:31-90, IR_CopyFromExternalField.scala) ----------
 // get<Name>(dest, slot) / set<Name>(src, slot): copy between a caller-owned array in its own layout and the internal
 // field over [DLB - min(ghost_int, ghost_ext), DRE + min(ghost_int, ghost_ext)) per dimension; iterator coordinates

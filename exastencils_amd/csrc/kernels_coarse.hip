@@ -263,7 +263,7 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
   }
 }
 
-static int g_cg_lds = 1;   // examg_debug_cg(0): global-memory solver for every size
+static thread_local int g_cg_lds = 1;   // examg_debug_cg(0): global-memory solver for every size
 
 static FaceBoxesCG face_boxes(const examg_layout_t *l, uint32_t face_mask) {
   FaceBoxesCG fb;
@@ -292,10 +292,12 @@ static FaceBoxesCG face_boxes(const examg_layout_t *l, uint32_t face_mask) {
 
 using namespace examg;
 
+#ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_cg(int lds) {
   examg::g_cg_lds = lds;
   return 0;
 }
+#endif
 
 extern "C" int examg_cg_coarse(const examg_layout_t *lu_, double *sol, const examg_layout_t *lf_, const double *rhs,
                                const examg_layout_t *lr_, double *res, const examg_layout_t *lp_, double *p,

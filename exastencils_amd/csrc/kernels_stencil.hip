@@ -13,25 +13,6 @@
 // file is compiled with -ffp-contract=off, so results are bit-identical to the CPU path.
 #include "examg_common.h"
 
-// shipped configuration of the fast path, from the sweeps of tools/tune_jacobi.py on MI355X (gpurun_out/tune*.log,
-// summary in DESIGN.md): 2 rows per wave, 4 waves per workgroup, non-temporal stores (+12 %), loads of the next
-// plane in flight while this one is computed, ~1024 workgroups, z march, plain tile order.
-#ifndef EXAMG_ZM_RY
-#define EXAMG_ZM_RY 2
-#endif
-#ifndef EXAMG_ZM_WY
-#define EXAMG_ZM_WY 4
-#endif
-#ifndef EXAMG_ZM_NT
-#define EXAMG_ZM_NT true
-#endif
-#ifndef EXAMG_ZM_MY
-#define EXAMG_ZM_MY false
-#endif
-#ifndef EXAMG_ZM_PF
-#define EXAMG_ZM_PF 1
-#endif
-
 namespace examg {
 
 struct StencilDev {
@@ -139,148 +120,116 @@ __device__ __forceinline__ double finish(double u, double acc, double f, double 
 
 struct ZMarchGeom {
   int colour;         // COL kernels: the colour to update
-  int ntx, ntt, ntm;  // tiles per dim: x, tile-row dim T, march dim M
-  int mc;             // planes (or rows) per march chunk
-  int nblocks;        // ntx * ntt * ntm
-  int remap;          // XCD-aware tile order on/off
+  int xo;             // x of lane 0's first point in tile 0: box.b0, or box.b0 - 1 where that makes every 16-byte access aligned
+  int ntx, nty, ntz;  // tiles per dim
+  int zc;             // planes per march chunk
 };
 
-// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (blocks b and b+8 share one
-// L2), so give each XCD a contiguous run of tiles -- adjacent tiles then share halo rows in L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-  const int per = nblocks >> 3;
-  const int full = per << 3;
-  if (bid >= full) return bid;  // tail blocks keep their id
-  return (bid & 7) * per + (bid >> 3);
-}
-
-// Tile = 128 x-points (2 per lane) by RY rows per wave, WY waves per workgroup, marching along M.
-//   MY = false: rows are y, march is z (register pipeline holds u[z-1], u[z], u[z+1]);
-//   MY = true : rows are z, march is y (consecutive steps are 1 row = ~4 KB apart: TLB-friendly).
-// COL: red-black half sweep in place (dst == u): of the two points a lane holds per row exactly one has
-//   (i0+i1+i2) % 2 == g.colour; it is updated, the other is written back unchanged (whole 16-byte stores).
-//   Race-free: only values of the other colour (never written in this sweep) and the lane's own centre are used.
 template <bool ALIAS> struct Ptr { typedef double *__restrict__ out; typedef const double *__restrict__ in; };
 template <> struct Ptr<true> { typedef double *out; typedef const double *in; };
 
-template <int MODE, int ORDER, int RY, int WY, bool NT, bool MY, int PF, bool REV, bool COL>
+// Tile = 128 x-points (2 per lane) by RY rows per wave, WY waves per workgroup, marching in z with a register pipeline
+// (u[z-1], u[z], u[z+1]); the loads of step z+1 -- own rows of plane z+2, rhs of plane z+1, the two y-halo rows and the two
+// window-edge values of plane z+1 -- are in flight while step z is computed.
+// COL: red-black half sweep in place (dst == u): of the two points a lane holds per row exactly one has
+//   (i0+i1+i2) % 2 == g.colour; it is updated, the other is written back unchanged (whole 16-byte stores).
+//   Race-free: only values of the other colour (never written in this sweep) and the lane's own centre are used.
+// Configuration from tools/stencil_lab.hip on MI355X at 512^3: 2 rows per wave, 4 waves per workgroup,
+// ~512 workgroups (two per CU), prefetch depth 1, edge values prefetched with the stage (they were the one load whose
+// latency every step waited for: -4 % at 512^3, -10 % at 256^3), non-temporal 16-byte stores.
+template <int MODE, int ORDER, int RY, int WY, bool COL>
 __global__ void __launch_bounds__(64 * WY)
 k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev ld,
                   typename Ptr<COL>::out dst, Coef7 k, double w, Box box, ZMarchGeom g) {
   const int lane = threadIdx.x;   // 0..63
   const int wv = threadIdx.y;     // wave in block
-  int t = g.remap ? xcd_remap(blockIdx.x, g.nblocks) : (int)blockIdx.x;
-  if (REV) t = g.nblocks - 1 - t;  // backward sweep: last tiles first (see launch_zmarch: Infinity-Cache reuse)
+  int t = blockIdx.x;
   const int tx = t % g.ntx;
   t /= g.ntx;
-  const int tt = t % g.ntt;
-  const int tm = t / g.ntt;
+  const int ty = t % g.nty;
+  const int tz = t / g.nty;
 
-  const int bT = MY ? box.b2 : box.b1, eT = MY ? box.e2 : box.e1;
-  const int bM = MY ? box.b1 : box.b2, eM = MY ? box.e1 : box.e2;
-  const long long uT = MY ? lu.s2 : lu.s1, uM = MY ? lu.s1 : lu.s2;
-  const long long fT = MY ? lf.s2 : lf.s1, fM = MY ? lf.s1 : lf.s2;
-  const long long dT = MY ? ld.s2 : ld.s1, dM = MY ? ld.s1 : ld.s2;
-
-  const int x = box.b0 + tx * 128 + lane * 2;
-  const int rw = bT + (tt * WY + wv) * RY;  // first row of this wave
-  const int mb = bM + tm * g.mc;
-  const int me = min(mb + g.mc, eM);
-  if (rw >= eT) return;  // wave-uniform
-  const bool va = x < box.e0, vb = x + 1 < box.e0;
+  const int x = g.xo + tx * 128 + lane * 2;
+  const int rw = box.b1 + (ty * WY + wv) * RY;  // first row of this wave
+  const int mb = box.b2 + tz * g.zc;
+  const int me = min(mb + g.zc, box.e2);
+  if (rw >= box.e1) return;  // wave-uniform
+  const bool va = x >= box.b0 && x < box.e0, vb = x + 1 < box.e0;   // x + 1 >= b0 always
   // right neighbour of b comes from lane+1 unless that lane is past the box
   const bool rload = vb && (lane == 63 || x + 2 >= box.e0);
   const bool lload = va && lane == 0;
-  const int xs = va ? x : box.b0;  // safe column for idle lanes (never stored)
+  const int xs = (va || vb) ? x : g.xo;  // safe column for idle lanes (never stored)
 
   const double *ur[RY];
   const double *fr[RY];
   double *dr[RY];
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
-    const int row = min(rw + r, eT);  // clamped rows re-read the upper halo row
-    ur[r] = u + lu.origin + xs + uT * row;
-    fr[r] = rhs + lf.origin + xs + fT * row;
-    dr[r] = dst + ld.origin + xs + dT * row;
+    const int row = min(rw + r, box.e1);  // clamped rows re-read the upper halo row
+    ur[r] = u + lu.origin + xs + lu.s1 * row;
+    fr[r] = rhs + lf.origin + xs + lf.s1 * row;
+    dr[r] = dst + ld.origin + xs + ld.s1 * row;
   }
-  const double *uhm = u + lu.origin + xs + uT * (rw - 1);
-  const double *uhp = u + lu.origin + xs + uT * min(rw + RY, eT);
+  const double *uhm = u + lu.origin + xs + lu.s1 * (rw - 1);
+  const double *uhp = u + lu.origin + xs + lu.s1 * min(rw + RY, box.e1);
 
-  constexpr int sg = REV ? -1 : 1;         // march direction
-  const int m0 = REV ? me - 1 : mb;        // first plane; step q handles plane m0 + sg*q
-  const int cnt = me - mb;
-  d2 um[RY], uc[RY];                       // planes m - sg and m of the own rows
+  d2 um[RY], uc[RY];                       // planes m - 1 and m of the own rows
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
-    um[r] = load2(ur[r] + uM * (m0 - sg));
-    uc[r] = load2(ur[r] + uM * m0);
+    um[r] = load2(ur[r] + lu.s2 * (mb - 1));
+    uc[r] = load2(ur[r] + lu.s2 * mb);
   }
-  // one pipeline stage = everything step m needs from memory: u[m+1] and rhs[m] of the own rows, the two
-  // halo rows of plane m.  With PF the loads of step m+1 are issued before step m is computed.
+  // one pipeline stage = everything step m needs from memory
   struct Stage {
     d2 up[RY], f[RY], hm, hp;
+    double el[RY], er[RY];
   };
-  auto load_stage = [&](Stage &st, int q) {
-    const int m = m0 + sg * q;
+  auto load_stage = [&](Stage &st, int m) {
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-      st.up[r] = load2(ur[r] + uM * (m + sg));
-      if (MODE != EXAMG_APPLY) st.f[r] = load2(fr[r] + fM * m);
+      st.up[r] = load2(ur[r] + lu.s2 * (m + 1));
+      if (MODE != EXAMG_APPLY) st.f[r] = load2(fr[r] + lf.s2 * m);
+      st.el[r] = 0.0;
+      st.er[r] = 0.0;
+      if (lload) st.el[r] = ur[r][lu.s2 * m - 1];
+      if (rload) st.er[r] = ur[r][lu.s2 * m + 2];
     }
-    st.hm = load2(uhm + uM * m);
-    st.hp = load2(uhp + uM * m);
+    st.hm = load2(uhm + lu.s2 * m);
+    st.hp = load2(uhp + lu.s2 * m);
   };
-  auto compute = [&](const Stage &st, int q) {
-    const int m = m0 + sg * q;
+  auto compute = [&](const Stage &st, int m) {
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
       // wavefront-level x-halo exchange
       double xl = lane_below(uc[r].y);
       double xr = lane_above(uc[r].x);
-      if (lload) xl = ur[r][uM * m - 1];
-      if (rload) xr = ur[r][uM * m + 2];
+      if (lload) xl = st.el[r];
+      if (rload) xr = st.er[r];
       const d2 tm_ = (r == 0) ? st.hm : uc[r == 0 ? 0 : r - 1];
       const d2 tp_ = (r == RY - 1) ? st.hp : uc[r == RY - 1 ? r : r + 1];
-      const d2 mm_ = REV ? st.up[r] : um[r];   // plane m-1 and m+1 along the march dimension
-      const d2 mp_ = REV ? um[r] : st.up[r];
       d2 o;
       if (COL) {
-        // the point of this lane's pair that carries the colour: a if (x + row + m) has that parity, else b; x = b0 +
+        // the point of this lane's pair that carries the colour: a if (x + row + m) has that parity, else b; x = xo +
         // 128*tx + 2*lane, so the parity is the same in every lane: scalar branch, one convolution, one lane exchange
         o = uc[r];
-        if (((box.b0 + rw + r + m) & 1) == g.colour) {
-          const double acc = MY ? conv7<ORDER>(k, uc[r].x, xl, uc[r].y, mm_.x, mp_.x, tm_.x, tp_.x)
-                                : conv7<ORDER>(k, uc[r].x, xl, uc[r].y, tm_.x, tp_.x, mm_.x, mp_.x);
+        if (((g.xo + rw + r + m) & 1) == g.colour) {
+          const double acc = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, tm_.x, tp_.x, um[r].x, st.up[r].x);
           o.x = finish<MODE>(uc[r].x, acc, st.f[r].x, w);
         } else {
-          const double acc = MY ? conv7<ORDER>(k, uc[r].y, uc[r].x, xr, mm_.y, mp_.y, tm_.y, tp_.y)
-                                : conv7<ORDER>(k, uc[r].y, uc[r].x, xr, tm_.y, tp_.y, mm_.y, mp_.y);
+          const double acc = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, tm_.y, tp_.y, um[r].y, st.up[r].y);
           o.y = finish<MODE>(uc[r].y, acc, st.f[r].y, w);
         }
       } else {
-        double acc_a, acc_b;
-        if (MY) {
-          acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, mm_.x, mp_.x, tm_.x, tp_.x);
-          acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, mm_.y, mp_.y, tm_.y, tp_.y);
-        } else {
-          acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, tm_.x, tp_.x, mm_.x, mp_.x);
-          acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, tm_.y, tp_.y, mm_.y, mp_.y);
-        }
+        const double acc_a = conv7<ORDER>(k, uc[r].x, xl, uc[r].y, tm_.x, tp_.x, um[r].x, st.up[r].x);
+        const double acc_b = conv7<ORDER>(k, uc[r].y, uc[r].x, xr, tm_.y, tp_.y, um[r].y, st.up[r].y);
         o.x = finish<MODE>(uc[r].x, acc_a, st.f[r].x, w);
         o.y = finish<MODE>(uc[r].y, acc_b, st.f[r].y, w);
       }
-      if (rw + r < eT) {
-        double *q = dr[r] + dM * m;
-        if (vb) {
-          if (NT) {
-            __builtin_nontemporal_store(o.x, q);
-            __builtin_nontemporal_store(o.y, q + 1);
-          } else {
-            store2(q, o);
-          }
-        } else if (va) {
-          q[0] = o.x;
-        }
+      if (rw + r < box.e1) {
+        double *q = dr[r] + ld.s2 * m;
+        if (va && vb) store2_nt(q, o);
+        else if (va) q[0] = o.x;
+        else if (vb) q[1] = o.y;
       }
     }
 #pragma unroll
@@ -289,127 +238,71 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
       uc[r] = st.up[r];
     }
   };
-  // software pipeline of depth PF: the loads of step m+PF are in flight while step m is computed
-  Stage st[PF + 1];
+  // software pipeline of depth 1: the loads of step m+1 are in flight while step m is computed
+  Stage st[2];
+  load_stage(st[0], mb);
+  int m = mb;
+  while (m < me) {
 #pragma unroll
-  for (int j = 0; j < PF; ++j)
-    if (j < cnt) load_stage(st[j], j);
-  int q = 0;
-  while (q < cnt) {
-#pragma unroll
-    for (int j = 0; j <= PF; ++j) {
-      if (q < cnt) {
-        if (q + PF < cnt) load_stage(st[(j + PF) % (PF + 1)], q + PF);
-        compute(st[j], q);
-        ++q;
+    for (int j = 0; j < 2; ++j) {
+      if (m < me) {
+        if (m + 1 < me) load_stage(st[j ^ 1], m + 1);
+        compute(st[j], m);
+        ++m;
       }
     }
   }
 }
 
-static int g_force_generic = 0;  // test hook: examg_debug_force_generic
-static int g_sf27_unrolled = 1;  // examg_debug_sf27(0): 27-entry stencil fields on the generic kernel
+static thread_local int g_force_generic = 0;  // test hook (debug build only): examg_debug_force_generic
+static thread_local int g_sf27_unrolled = 1;  // examg_debug_sf27(0): 27-entry stencil fields on the generic kernel
 
 // kernels_stencilfield.hip
 bool stencilfield7_ok(const examg_layout_t *lu, const examg_stencil_t *st, const Box &box, int colour);
 int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
                          double *dst, const LayoutDev &lc, const double *cf, double w, const Box &box, hipStream_t s);
 
+constexpr int ZM_RY = 2, ZM_WY = 4, ZM_BLOCKS = 512, ZM_MINCHUNK = 16;
 
-// Tuning knobs (examg_debug_tune); the defaults are the measured best on MI355X at 512^3.
-struct Tune {
-  int ry = 2, wy = 4, nt = 1, my = 0, pf = 1, remap = 0, blocks = 1024, minchunk = 16, dir = 0;
-};
-static Tune g_tune;
-static bool g_dir_toggle = false;
-
-template <int MODE, int ORDER, int RY, int WY, bool NT, bool MY, int PF>
-static void launch_zmarch_t(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                            double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
-  const int nT = MY ? box.n2() : box.n1(), nM = MY ? box.n1() : box.n2();
+template <int MODE, int ORDER>
+static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
+                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
   ZMarchGeom g;
-  g.ntx = (box.n0() + 127) / 128;
-  g.ntt = (nT + RY * WY - 1) / (RY * WY);
-  const int xy = g.ntx * g.ntt;
-  int ntm = (g_tune.blocks + xy - 1) / xy;
-  if (ntm < 1) ntm = 1;
-  int mc = (nM + ntm - 1) / ntm;
-  if (mc < g_tune.minchunk) mc = g_tune.minchunk;
-  if (mc > nM) mc = nM;
-  g.mc = mc;
-  g.ntm = (nM + mc - 1) / mc;
-  g.nblocks = g.ntx * g.ntt * g.ntm;
-  g.remap = g_tune.remap;
+  // Padded layouts (`align`, field/ir/IR_AddPaddingToFieldLayouts.scala:36-41) have even row lengths and put the lower duplicate
+  // point on an even index: starting the windows one point to the left of an odd box makes every 16-byte load and store of
+  // the sweep 16-byte aligned (the extra point is loaded, never stored).  Not possible in the verbatim layout, whose odd
+  // strides flip the parity from row to row.  512^3, rows of 544 doubles: 0.62 -> 0.57 ms (tools/stencil_lab.hip).
+  const bool even = !(lu.s1 & 1) && !(lu.s2 & 1) && !(lf.s1 & 1) && !(lf.s2 & 1) && !(ld.s1 & 1) && !(ld.s2 & 1);
+  const int pu = (int)((lu.origin + box.b0) & 1), pf = (int)((lf.origin + box.b0) & 1), pd = (int)((ld.origin + box.b0) & 1);
+  const bool shift = even && pu == 1 && pd == 1 && (MODE == EXAMG_APPLY || pf == 1) && lu.ref0 + box.b0 >= 1 &&
+                     ld.ref0 + box.b0 >= 1 && (MODE == EXAMG_APPLY || lf.ref0 + box.b0 >= 1);
+  g.xo = box.b0 - (shift ? 1 : 0);
+  g.ntx = (box.e0 - g.xo + 127) / 128;
+  g.nty = (box.n1() + ZM_RY * ZM_WY - 1) / (ZM_RY * ZM_WY);
+  const int xy = g.ntx * g.nty;
+  int ntz = (ZM_BLOCKS + xy - 1) / xy;
+  if (ntz < 1) ntz = 1;
+  int zc = (box.n2() + ntz - 1) / ntz;
+  if (zc < ZM_MINCHUNK) zc = ZM_MINCHUNK;
+  if (zc > box.n2()) zc = box.n2();
+  g.zc = zc;
+  g.ntz = (box.n2() + zc - 1) / zc;
   g.colour = colour;
-  dim3 block(64, WY, 1), grid(g.nblocks, 1, 1);
+  dim3 block(64, ZM_WY, 1), grid(g.ntx * g.nty * g.ntz, 1, 1);
   if (colour >= 0) {
     if (MODE == EXAMG_SMOOTH)
-      hipLaunchKernelGGL((k_stencil7_zmarch<EXAMG_SMOOTH, ORDER, RY, WY, NT, MY, PF, false, true>), grid, block, 0, s, lu, u, lf,
-                         rhs, ld, dst, k, w, box, g);
+      hipLaunchKernelGGL((k_stencil7_zmarch<EXAMG_SMOOTH, ORDER, ZM_RY, ZM_WY, true>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
     return;
   }
-  // Sweep direction (tuning knob `dir`; -1 alternates from launch to launch so that a sweep starts where the
-  // previous one ended).  Measured on MI355X at 256^3 and 512^3: no gain -- the 256 MiB Infinity Cache does not
-  // hold streamed data long enough -- so the shipped default is always forward.  Results do not depend on it.
-  bool rev;
-  if (g_tune.dir < 0) { rev = g_dir_toggle; g_dir_toggle = !g_dir_toggle; }
-  else rev = g_tune.dir != 0;
-  if (rev) hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, RY, WY, NT, MY, PF, true, false>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
-  else hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, RY, WY, NT, MY, PF, false, false>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, ZM_RY, ZM_WY, false>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
 }
-
-#ifdef EXAMG_TUNE
-// every (RY, WY, NT, MY) combination, for tools/tune_jacobi.py
-template <int MODE, int ORDER, int RY, int WY>
-static void launch_zmarch_ntmy(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                               double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
-#define EXAMG_L(NT_, MY_, PF_) launch_zmarch_t<MODE, ORDER, RY, WY, NT_, MY_, PF_>(lu, u, lf, rhs, ld, dst, k, w, box, s)
-  switch (g_tune.pf) {
-    case 1: if (g_tune.nt) EXAMG_L(true, false, 1); else EXAMG_L(false, false, 1); break;
-    case 2: if (g_tune.nt) EXAMG_L(true, false, 2); else EXAMG_L(false, false, 2); break;
-    case 3: if (g_tune.nt) EXAMG_L(true, false, 3); else EXAMG_L(false, false, 3); break;
-    case 4: if (g_tune.nt) EXAMG_L(true, false, 4); else EXAMG_L(false, false, 4); break;
-    default:
-      if (g_tune.nt) { if (g_tune.my) EXAMG_L(true, true, 0); else EXAMG_L(true, false, 0); }
-      else { if (g_tune.my) EXAMG_L(false, true, 0); else EXAMG_L(false, false, 0); }
-  }
-#undef EXAMG_L
-}
-template <int MODE, int ORDER, int RY>
-static void launch_zmarch_wy(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                             double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s) {
-  switch (g_tune.wy) {
-    case 1: launch_zmarch_ntmy<MODE, ORDER, RY, 1>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
-    case 2: launch_zmarch_ntmy<MODE, ORDER, RY, 2>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
-    case 8: launch_zmarch_ntmy<MODE, ORDER, RY, 8>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
-    default: launch_zmarch_ntmy<MODE, ORDER, RY, 4>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
-  }
-}
-template <int MODE, int ORDER>
-static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
-  if (colour >= 0) {
-    launch_zmarch_t<MODE, ORDER, EXAMG_ZM_RY, EXAMG_ZM_WY, EXAMG_ZM_NT, EXAMG_ZM_MY, EXAMG_ZM_PF>(lu, u, lf, rhs, ld, dst, k, w, box, s, colour);
-    return;
-  }
-  switch (g_tune.ry) {
-    case 1: launch_zmarch_wy<MODE, ORDER, 1>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
-    case 4: launch_zmarch_wy<MODE, ORDER, 4>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
-    default: launch_zmarch_wy<MODE, ORDER, 2>(lu, u, lf, rhs, ld, dst, k, w, box, s); break;
-  }
-}
-#else
-template <int MODE, int ORDER>
-static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
-  launch_zmarch_t<MODE, ORDER, EXAMG_ZM_RY, EXAMG_ZM_WY, EXAMG_ZM_NT, EXAMG_ZM_MY, EXAMG_ZM_PF>(lu, u, lf, rhs, ld, dst, k, w, box, s, colour);
-}
-#endif
 
 }  // namespace examg
 
 using namespace examg;
 
+#ifdef EXAMG_DEBUG_HOOKS
+// Variant selection for the parity tests (debug build libexamg_dbg.so only; per host thread)
 extern "C" int examg_debug_sf27(int unrolled) {
   g_sf27_unrolled = unrolled;
   return 0;
@@ -420,23 +313,7 @@ extern "C" int examg_debug_force_generic(int on) {
   g_force_generic = on;
   return old;
 }
-
-// Tuning hook for tools/tune_jacobi.py: key in {ry, wy, nt, my, remap, blocks, minchunk}.  ry/wy/nt/my only
-// take effect in a build with -DEXAMG_TUNE (all template combinations instantiated).
-extern "C" int examg_debug_tune(const char *key, int value) {
-  if (!key) return 1;
-  if (!strcmp(key, "ry")) g_tune.ry = value;
-  else if (!strcmp(key, "wy")) g_tune.wy = value;
-  else if (!strcmp(key, "nt")) g_tune.nt = value;
-  else if (!strcmp(key, "my")) g_tune.my = value;
-  else if (!strcmp(key, "pf")) g_tune.pf = value;
-  else if (!strcmp(key, "dir")) g_tune.dir = value;
-  else if (!strcmp(key, "remap")) g_tune.remap = value;
-  else if (!strcmp(key, "blocks")) g_tune.blocks = value;
-  else if (!strcmp(key, "minchunk")) g_tune.minchunk = value;
-  else return 1;
-  return 0;
-}
+#endif
 
 extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_,
                                 const double *rhs, const examg_layout_t *ld_, double *dst, const examg_stencil_t *st,

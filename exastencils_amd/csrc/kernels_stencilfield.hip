@@ -151,8 +151,8 @@ k_stencilfield7_zmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf,
 
 // tuning hook (examg_debug_stencilfield): 0 = RY1/PF1, 1 = RY2/PF0, 2 = RY2/PF1, 3 = RY1/PF2; -1 = generic kernel.
 // tools/varcoeff_times.py at 512^3 (Jacobi, ms): generic 2.64, variant 0 2.31, 1 1.99, 2 2.74, 3 2.44 -> variant 1
-static int g_sf_variant = 1;
-static int g_sf_blocks = 2048;
+static thread_local int g_sf_variant = 1;
+static thread_local int g_sf_blocks = 2048;
 
 template <int MODE, int RY, int WY, int PF>
 static void launch_sf(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld, double *dst,
@@ -205,8 +205,10 @@ int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const L
 
 }  // namespace examg
 
+#ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_stencilfield(int variant, int blocks) {
   examg::g_sf_variant = variant;   // -1 disables the fast path
   if (blocks > 0) examg::g_sf_blocks = blocks;
   return 0;
 }
+#endif

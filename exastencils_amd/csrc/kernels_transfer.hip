@@ -320,7 +320,7 @@ k_prolong_add3_pairs(LayoutDev lc, const double *__restrict__ uc, LayoutDev lfin
   }
 }
 
-static int g_restrict_wide = 1;   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
+static thread_local int g_restrict_wide = 1;   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
 
 static inline dim3 grid_for(long long total) {
   long long nb = (total + 255) / 256;
@@ -333,10 +333,12 @@ static inline dim3 grid_for(long long total) {
 
 using namespace examg;
 
+#ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_restrict(int wide) {
   examg::g_restrict_wide = wide;
   return 0;
 }
+#endif
 
 extern "C" int examg_restrict(const examg_layout_t *lfine_, const double *rf, const examg_layout_t *lc_, double *fc,
                               double scale, const int32_t *begin, const int32_t *end, examg_stream_t stream) {

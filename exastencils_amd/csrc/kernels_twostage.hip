@@ -8,11 +8,12 @@
 //     CommFullTempBlockable layouts of the generated-from-L3 programs.
 // Both read u and rhs once and write the result once: 24 B per point per pass.
 //
-// Structure: out of place (u_out != u_in, the caller swaps pointers), so tiles are independent: every wave
+// Structure: out of place (u_out != u_in, the caller swaps pointers), so tiles are independent: every workgroup
 // recomputes the stage-1 values of its halo (2-point halo in x, y and z of the input, 1-point halo of the
-// stage-1 field).  A wave loads a 128-point x window (2 per lane) and produces the inner 124; it owns RY rows,
-// computes stage 1 on RY+2 rows from RY+4 loaded rows, and marches in z with 3-plane register rings for the
-// input and for the stage-1 field.  x-neighbours come from the adjacent lanes.
+// stage-1 field).  A workgroup loads a 128-point x window (2 per lane) and produces the inner 124; its waves own two rows
+// each, share their y-neighbour rows through LDS and march in z with register pipelines for the input and for the
+// stage-1 field.  x-neighbours come from the adjacent lanes.  (Round 1 also had a variant without LDS, every wave
+// recomputing its own y-halo: 0.97 ms against 0.72 ms at 512^3; removed.)
 // Arithmetic per point is the same expression, in the same order, as the one-stage kernels: results are
 // bit-identical to running the two loops one after the other.
 #include "examg_common.h"
@@ -21,6 +22,7 @@ namespace examg {
 
 struct TSGeom {
   int ntx, nty, ntz, zc, nblocks, remap;
+  int xs;                  // 1: windows start one point further left, which makes every 16-byte access aligned (padded layouts)
   int first;               // COL: colour updated in stage 1
   Box box1;                // stage-1 box (contains the output box); points outside keep the input value
   int ax0, ax1, ay0, ay1, az0, az1;  // allocation of u in iterator coordinates, half open
@@ -28,187 +30,8 @@ struct TSGeom {
 
 constexpr int TS_OUT = 124;  // outputs per 128-point window
 
-template <int ORDER, bool COL, int RY, int WY, bool NT>
-__global__ void __launch_bounds__(64 * WY)
-k_two_stage7(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs,
-             double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g) {
-  constexpr int RU = RY + 4;  // input rows per plane
-  constexpr int RV = RY + 2;  // stage-1 rows per plane
-  const int lane = threadIdx.x, wv = threadIdx.y;
-  int t = blockIdx.x;
-  if (g.remap) {  // XCD-contiguous tile order: y-adjacent tiles share their halo rows in one L2
-    const int per = g.nblocks >> 3;
-    if (t < (per << 3)) t = (t & 7) * per + (t >> 3);
-  }
-  const int tx = t % g.ntx;
-  t /= g.ntx;
-  const int ty = t % g.nty;
-  const int tz = t / g.nty;
-
-  const int xa = box.b0 - 2 + TS_OUT * tx + 2 * lane;  // this lane's points: xa, xa + 1
-  const int xpar = (box.b0 + TS_OUT * tx) & 1;         // parity of xa, the same in every lane
-  const int rw = box.b1 + (ty * WY + wv) * RY;           // first own row
-  const int mb = box.b2 + tz * g.zc;
-  const int me = min(mb + g.zc, box.e2);
-  if (rw >= box.e1) return;  // wave-uniform
-
-  const bool alloc_a = xa >= g.ax0 && xa < g.ax1, alloc_b = xa + 1 >= g.ax0 && xa + 1 < g.ax1;
-  const bool inx_a = xa >= box.b0 && xa < box.e0, inx_b = xa + 1 >= box.b0 && xa + 1 < box.e0;
-  const Box &box1 = g.box1;
-  const bool in1_a = xa >= box1.b0 && xa < box1.e0, in1_b = xa + 1 >= box1.b0 && xa + 1 < box1.e0;
-  // lanes 1..62 produce output (window-relative points 2..125)
-  const bool out_lane = lane >= 1 && lane <= 62;
-
-  const double *ubase = u + lu.origin + xa;
-  const double *fbase = rhs + lf.origin + xa;
-  double *obase = out + lu.origin + xa;
-
-  // input ring: U[s][i] = plane slot s, row rw - 2 + i ; stage-1 ring: V[s][i] = row rw - 1 + i.
-  // Four slots: while plane q is processed the loads of plane q+2 (and rhs of q+1) are already in flight.
-  d2 U[4][RU], V[4][RV];
-  d2 F[2][RV];  // rhs on the stage-1 rows: F[q & 1] belongs to plane q
-  d2 Fown[RY];  // rhs of the own rows on the plane that stage 2 handles next
-
-  auto row_ok = [&](int row) { return row >= g.ay0 && row < g.ay1; };
-  auto load_plane = [&](d2 (&P)[RU], int p) {
-    const bool pok = p >= g.az0 && p < g.az1;
-#pragma unroll
-    for (int i = 0; i < RU; ++i) {
-      const int row = rw - 2 + i;
-      const bool ok = pok && row_ok(row);
-      P[i] = load2g(ubase + lu.s1 * row + lu.s2 * p, ok && alloc_a, ok && alloc_b);
-    }
-  };
-
-  // stage 1 on plane p: VP = stage-1 field from input planes Um (p-1), Uc (p), Up (p+1)
-  auto load_rhs = [&](d2 (&FP)[RV], int p) {
-    const bool pin = p >= box1.b2 && p < box1.e2;
-#pragma unroll
-    for (int i = 0; i < RV; ++i) {
-      const int row = rw - 1 + i;
-      const bool rin = pin && row >= box1.b1 && row < box1.e1;
-      FP[i] = load2g(fbase + lf.s1 * row + lf.s2 * p, rin && in1_a, rin && in1_b);
-    }
-  };
-  auto stage1 = [&](d2 (&VP)[RV], const d2 (&Um)[RU], const d2 (&Uc)[RU], const d2 (&Up)[RU], const d2 (&FP)[RV], int p) {
-    const bool pin = p >= box1.b2 && p < box1.e2;
-#pragma unroll
-    for (int i = 0; i < RV; ++i) {
-      const int row = rw - 1 + i;
-      const d2 c = Uc[i + 1];
-      d2 v = c;
-      const bool rin = pin && row >= box1.b1 && row < box1.e1;  // wave-uniform
-      if (rin) {
-        const bool da = in1_a, db = in1_b;
-        const d2 f = FP[i];
-        // parity of point a (b has the other one); 2*lane does not change it, so it is wave-uniform: scalar branches
-        const int par = (xpar + row + p) & 1;
-        if (COL) {
-          // exactly one point of the pair carries the stage-1 colour: one convolution and one lane exchange per pair
-          if (par == g.first) {
-            const double xl = lane_below(c.y);
-            const double acc = conv7<ORDER>(k, c.x, xl, c.y, Uc[i].x, Uc[i + 2].x, Um[i + 1].x, Up[i + 1].x);
-            const double nv = c.x + w * (f.x - acc);
-            v.x = da ? nv : c.x;
-          } else {
-            const double xr = lane_above(c.x);
-            const double acc = conv7<ORDER>(k, c.y, c.x, xr, Uc[i].y, Uc[i + 2].y, Um[i + 1].y, Up[i + 1].y);
-            const double nv = c.y + w * (f.y - acc);
-            v.y = db ? nv : c.y;
-          }
-        } else {
-          const double xl = lane_below(c.y), xr = lane_above(c.x);
-          const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Uc[i].x, Uc[i + 2].x, Um[i + 1].x, Up[i + 1].x);
-          const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Uc[i].y, Uc[i + 2].y, Um[i + 1].y, Up[i + 1].y);
-          const double na = c.x + w * (f.x - acc_a);
-          const double nb = c.y + w * (f.y - acc_b);
-          v.x = da ? na : c.x;
-          v.y = db ? nb : c.y;
-        }
-      }
-      VP[i] = v;
-    }
-  };
-
-  // stage 2 on plane m: result from stage-1 planes Vm (m-1), Vc (m), Vp (m+1); own rows only
-  auto stage2 = [&](const d2 (&Vm)[RV], const d2 (&Vc)[RV], const d2 (&Vp)[RV], const d2 (&F)[RY], int m) {
-#pragma unroll
-    for (int r = 0; r < RY; ++r) {
-      const int row = rw + r;
-      if (row >= box.e1) continue;  // wave-uniform
-      const d2 c = Vc[r + 1];
-      const int par = (xpar + row + m) & 1;   // wave-uniform
-      d2 o = c;
-      if (COL) {
-        if (par != g.first) {   // point a carries the stage-2 colour
-          const double xl = lane_below(c.y);
-          const double acc = conv7<ORDER>(k, c.x, xl, c.y, Vc[r].x, Vc[r + 2].x, Vm[r + 1].x, Vp[r + 1].x);
-          const double nv = c.x + w * (F[r].x - acc);
-          o.x = inx_a ? nv : c.x;
-        } else {
-          const double xr = lane_above(c.x);
-          const double acc = conv7<ORDER>(k, c.y, c.x, xr, Vc[r].y, Vc[r + 2].y, Vm[r + 1].y, Vp[r + 1].y);
-          const double nv = c.y + w * (F[r].y - acc);
-          o.y = inx_b ? nv : c.y;
-        }
-      } else {
-        const double xl = lane_below(c.y), xr = lane_above(c.x);
-        const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, Vc[r].x, Vc[r + 2].x, Vm[r + 1].x, Vp[r + 1].x);
-        const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, Vc[r].y, Vc[r + 2].y, Vm[r + 1].y, Vp[r + 1].y);
-        const double na = c.x + w * (F[r].x - acc_a);
-        const double nb = c.y + w * (F[r].y - acc_b);
-        o.x = inx_a ? na : c.x;
-        o.y = inx_b ? nb : c.y;
-      }
-      if (out_lane) {
-        double *q = obase + lu.s1 * row + lu.s2 * m;
-        if (inx_a && inx_b) {
-          if (NT) {
-            __builtin_nontemporal_store(o.x, q);
-            __builtin_nontemporal_store(o.y, q + 1);
-          } else {
-            d2u s;
-            s.a = o.x;
-            s.b = o.y;
-            *reinterpret_cast<d2u *>(q) = s;
-          }
-        } else if (inx_a) {
-          q[0] = o.x;
-        } else if (inx_b) {
-          q[1] = o.y;
-        }
-      }
-    }
-  };
-
-  // pipeline over q = mb-1 .. me: prefetch u(q+2) and rhs(q+1), stage 1 on plane q, stage 2 on plane q-1.
-  // ring slot of plane p: (p - (mb - 2)) & 3 ; rhs buffer of plane p: (p - (mb - 1)) & 1
-  load_plane(U[0], mb - 2);
-  load_plane(U[1], mb - 1);
-  load_plane(U[2], mb);
-  load_rhs(F[0], mb - 1);
-  int q = mb - 1;
-  while (q <= me) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (q <= me) {
-        // slots: plane q-1 -> j, q -> j+1, q+1 -> j+2, q+2 -> j+3 (mod 4); plane q-2 (stage-1 field) -> j+3
-        if (q + 1 <= me) {
-          load_plane(U[(j + 3) & 3], q + 2);
-          load_rhs(F[(j + 1) & 1], q + 1);
-        }
-        stage1(V[(j + 1) & 3], U[j], U[(j + 1) & 3], U[(j + 2) & 3], F[j & 1], q);
-        if (q - 1 >= mb) stage2(V[(j + 3) & 3], V[j], V[(j + 1) & 3], Fown, q - 1);
-#pragma unroll
-        for (int r = 0; r < RY; ++r) Fown[r] = F[j & 1][r + 1];
-        ++q;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// LDS variant: the NW waves of a workgroup share one 128-point x window and a stack of 2*NW stage-1 rows.  Every wave
+// The NW waves of a workgroup share one 128-point x window and a stack of 2*NW stage-1 rows.  Every wave
 // owns two consecutive rows: it keeps their z pipeline (input planes q-1, q, q+1 and stage-1 planes m-1, m, m+1) in
 // registers and publishes plane q+1 of the input and plane q of the stage-1 field in LDS, from where the waves above
 // and below read their y-neighbour rows.  Each input row is loaded from memory once per workgroup (2*NW + 2 rows for
@@ -238,8 +61,9 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   t /= g.ntx;
   const int ty = t % g.nty;
   const int tz = t / g.nty;
-  const int xa = box.b0 - 2 + TS_OUT * tx + 2 * lane;
-  const int xpar = (box.b0 + TS_OUT * tx) & 1;
+  const int xw = box.b0 - 2 - g.xs + TS_OUT * tx;   // first point of the window
+  const int xa = xw + 2 * lane;
+  const int xpar = xw & 1;                          // parity of xa, the same in every lane
   const int rw0 = box.b1 + ty * NO;             // first output row of the workgroup
   const int mb = box.b2 + tz * g.zc;
   const int me = min(mb + g.zc, box.e2);
@@ -265,13 +89,13 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   // lowest address, and clamped into the array.  A window that sticks out of the allocation then reads some other
   // in-bounds value, which no valid output depends on (the first and the last element of an array, which the clamp
   // can substitute for their neighbours, are corner points that no 7-point update and no pass-through reads).
-  const long long org_u = lu.origin + (long long)(box.b0 - 2 + TS_OUT * tx) + lu.s1 * (rw0 - 2) + lu.s2 * (mb - 2);
+  const long long org_u = lu.origin + (long long)xw + lu.s1 * (rw0 - 2) + lu.s2 * (mb - 2);
   const long long orc_u = min(max(org_u, 0LL), lu.size - 2);
   const double *ub = u + orc_u;
   const int hi_u = (int)min(lu.size - 2 - orc_u, 2147483000LL);
   const int s1u = (int)lu.s1, s2u = (int)lu.s2;
   const int lane_u = (int)(org_u - orc_u) + 2 * lane;
-  const long long org_f = lf.origin + (long long)(box.b0 - 2 + TS_OUT * tx) + lf.s1 * (rw0 - 1) + lf.s2 * (mb - 1);
+  const long long org_f = lf.origin + (long long)xw + lf.s1 * (rw0 - 1) + lf.s2 * (mb - 1);
   const long long orc_f = min(max(org_f, 0LL), lf.size - 2);
   const double *fb = rhs + orc_f;
   const int hi_f = (int)min(lf.size - 2 - orc_f, 2147483000LL);
@@ -406,8 +230,7 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
         if (st_a && st_b) {
           double *qp = obase + lu.s1 * grow[r] + lu.s2 * m;
           if (NT) {
-            __builtin_nontemporal_store(o.x, qp);
-            __builtin_nontemporal_store(o.y, qp + 1);
+            store2_nt(qp, o);
           } else {
             d2u sv;
             sv.a = o.x;
@@ -453,52 +276,16 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   }
 }
 
-// launch knobs of the register variant (8 waves per workgroup, plain tile order) and the workgroup count target
-static int g_ts_blocks = 3072;
-static int g_ts_disable = 0;
-static int g_ts_remap = 0;
-static int g_ts_wy = 8;
-// Which implementation: 0 = register variant; 5 / 8 / 9 = LDS variant with that many waves per workgroup; -2 = by size.
+// launch knobs (debug build: examg_debug_two_stage*; per host thread): workgroup count target, tile order
+static thread_local int g_ts_blocks = 3072;
+static thread_local int g_ts_disable = 0;
+static thread_local int g_ts_remap = 0;
+// Which implementation: 5 / 8 = that many waves per workgroup; -2 = by size.
 // tools/tune_two_stage.py on MI355X, ms for a Jacobi pair / a red-black sweep (all variants bit-identical):
 //   512^3: registers 0.97 / 0.93, LDS-5 0.79 / 0.77, LDS-8 0.717 / 0.716 (3072 workgroups), LDS-9 0.87 / 0.85
 //   256^3: LDS-5 0.138, LDS-8 0.119-0.124;  128^3: LDS-5 0.028, LDS-8 0.031
 // ~120 VGPRs -> 4 waves per SIMD = 16 per CU: two 8-wave workgroups fill a CU (a 9-wave workgroup runs alone)
-static int g_ts_lds_default = -2;
-static int g_ts_lds = -2;
-
-template <bool COL, int WY>
-static int launch_two_stage_w(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
-                              double *out, const examg_stencil_t *st, double w, int first, const Box &box, const Box &box1,
-                              hipStream_t s) {
-  constexpr int RY = 2;
-  const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
-  TSGeom g;
-  g.ntx = (box.n0() + TS_OUT - 1) / TS_OUT;
-  g.nty = (box.n1() + RY * WY - 1) / (RY * WY);
-  const int xy = g.ntx * g.nty;
-  int ntz = (g_ts_blocks + xy - 1) / xy;
-  if (ntz < 1) ntz = 1;
-  int zc = (box.n2() + ntz - 1) / ntz;
-  if (zc < 16) zc = 16;
-  if (zc > box.n2()) zc = box.n2();
-  g.zc = zc;
-  g.ntz = (box.n2() + zc - 1) / zc;
-  g.nblocks = xy * g.ntz;
-  g.remap = g_ts_remap;
-  g.first = first;
-  g.box1 = box1;
-  g.ax0 = -lu.ref0; g.ax1 = lu.tot0 - lu.ref0;
-  g.ay0 = -lu.ref1; g.ay1 = lu.tot1 - lu.ref1;
-  g.az0 = -lu.ref2; g.az1 = lu.tot2 - lu.ref2;
-  Coef7 k;
-  for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
-  const int ord = canonical_order7(st);
-  dim3 block(64, WY, 1), grid(g.nblocks, 1, 1);
-  if (ord == 0) hipLaunchKernelGGL((k_two_stage7<0, COL, RY, WY, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
-  else hipLaunchKernelGGL((k_two_stage7<1, COL, RY, WY, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
-  EXAMG_CHECK_LAUNCH("k_two_stage7");
-  return 0;
-}
+static thread_local int g_ts_lds = -2;
 
 template <bool COL, int NW, int WPE = 1>
 static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
@@ -507,7 +294,10 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   constexpr int NO = 2 * NW - 2;
   const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
   TSGeom g;
-  g.ntx = (box.n0() + TS_OUT - 1) / TS_OUT;
+  // padded layouts (even strides): start the windows so that every 16-byte access is aligned (kernels_stencil.hip: launch_zmarch)
+  const bool even = !(lu.s1 & 1) && !(lu.s2 & 1) && !(lf.s1 & 1) && !(lf.s2 & 1);
+  g.xs = (even && ((lu.origin + box.b0) & 1) && ((lf.origin + box.b0) & 1)) ? 1 : 0;
+  g.ntx = (box.n0() + g.xs + TS_OUT - 1) / TS_OUT;
   g.nty = (box.n1() + NO - 1) / NO;
   const int xy = g.ntx * g.nty;
   int ntz = (g_ts_blocks + xy - 1) / xy;
@@ -547,12 +337,8 @@ static int launch_two_stage(const examg_layout_t *lu_, const double *u, const ex
                             const Box *box1 = nullptr) {
   const Box &b1 = box1 ? *box1 : box;
   const int impl = g_ts_lds == -2 ? (box.n1() >= 192 ? 8 : 5) : g_ts_lds;
-  if (impl == 9) return launch_two_stage_lds<COL, 9>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
   if (impl == 8) return launch_two_stage_lds<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
-  if (impl == 5) return launch_two_stage_lds<COL, 5>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
-  if (g_ts_wy == 8) return launch_two_stage_w<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
-  if (g_ts_wy == 2) return launch_two_stage_w<COL, 2>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
-  return launch_two_stage_w<COL, 4>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
+  return launch_two_stage_lds<COL, 5>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
 }
 
 static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
@@ -564,8 +350,9 @@ static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, con
 
 using namespace examg;
 
+#ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_two_stage_lds(int nw) {
-  g_ts_lds = nw < 0 ? g_ts_lds_default : nw;
+  g_ts_lds = nw < 0 ? -2 : nw;
   return 0;
 }
 
@@ -573,9 +360,10 @@ extern "C" int examg_debug_two_stage(int disable, int blocks, int remap, int wy)
   g_ts_disable = disable;
   if (blocks > 0) g_ts_blocks = blocks;
   if (remap >= 0) g_ts_remap = remap;
-  if (wy > 0) g_ts_wy = wy;
+  (void)wy;
   return 0;
 }
+#endif
 
 // One full red-black sweep, out of place.
 extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_in, double *u_out,

@@ -62,6 +62,8 @@ class ExamgError(RuntimeError):
 
 
 _lib = None
+_libs = {}
+DBG_LIB_PATH = os.path.join(_HERE, "libexamg_dbg.so")   # -DEXAMG_DEBUG_HOOKS build: variant selection for the parity tests
 
 # every symbol include/examg.h declares
 SYMBOLS = [
@@ -73,20 +75,21 @@ SYMBOLS = [
 ]
 
 
-def load():
-    """Load libexamg.so and declare the prototypes.  Raises if the HIP library is not built."""
+def load(path=None):
+    """Load libexamg.so (or the library at `path`) and declare the prototypes.  Raises if the HIP library is not built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ExamgError(
-            "libexamg.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
-            "there is no CPU fallback" % LIB_PATH)
+            "%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback" % path)
     # torch first: libexamg.so needs libamdhip64.so.7 and must bind to the one HIP runtime of the process,
     # the copy PyTorch ships and loads (two runtimes in one process do not both see the device)
     import torch  # noqa: F401
 
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, ip = C.c_void_p, C.POINTER(C.c_int32)
     lp, sp, gp, dp = C.POINTER(LayoutC), C.POINTER(StencilC), C.POINTER(GeomC), C.POINTER(C.c_double)
     L.examg_version.restype = C.c_int
@@ -127,9 +130,12 @@ def load():
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
         if name not in ("examg_version", "examg_last_error", "examg_device_count", "examg_reduce_work_bytes"):
             fn.restype = C.c_int
-    L.examg_debug_force_generic.argtypes = [C.c_int]
-    L.examg_debug_force_generic.restype = C.c_int
-    _lib = L
+    if hasattr(L, "examg_debug_force_generic"):      # debug build only
+        L.examg_debug_force_generic.argtypes = [C.c_int]
+        L.examg_debug_force_generic.restype = C.c_int
+    _libs[path] = L
+    if path == LIB_PATH:
+        _lib = L
     return L
 
 

@@ -18,11 +18,11 @@ from .lib import ExamgError, check, dvec4, ivec
 class HipOps:
     name = "hip"
 
-    def __init__(self, device: Optional[int] = None):
+    def __init__(self, device: Optional[int] = None, lib_path: Optional[str] = None):
         import torch
 
         self.torch = torch
-        self.L = _lib.load()   # raises if libexamg.so is missing
+        self.L = _lib.load(lib_path)   # raises if libexamg.so is missing
         if not torch.cuda.is_available():
             raise ExamgError("HipOps needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         if self.L.examg_device_count() < 1:

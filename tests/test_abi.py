@@ -13,7 +13,17 @@ def _header_functions():
     return sorted(set(re.findall(r"\b(examg_[a-z0-9_]+)\s*\(", src)))
 
 
-def test_library_exports_every_declared_symbol():
+def _exported(path):
+    """Dynamic symbols a shared library defines whose names start with examg_ (C linkage)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-1].startswith("examg_")})
+
+
+def test_library_exports_exactly_the_declared_symbols():
+    """Both directions: every function include/examg.h declares is exported, and the product library exports no examg_*
+    symbol the header does not declare (variant-selection hooks live in the debug build only)."""
     import __graft_entry__ as ge
 
     ge.build_examg()
@@ -25,6 +35,17 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libexamg.so does not export %s" % name
     assert sorted(lib.SYMBOLS) == declared, "exastencils_amd.lib.SYMBOLS is out of sync with include/examg.h"
+    assert _exported(lib.LIB_PATH) == declared, "libexamg.so exports symbols include/examg.h does not declare"
+
+
+def test_debug_build_adds_only_debug_hooks():
+    import __graft_entry__ as ge
+
+    ge.build_examg_dbg()
+    from exastencils_amd import lib
+
+    extra = sorted(set(_exported(lib.DBG_LIB_PATH)) - set(_header_functions()))
+    assert extra and all(name.startswith("examg_debug_") for name in extra), extra
 
 
 def test_struct_mirrors_match_header_sizes():

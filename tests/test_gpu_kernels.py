@@ -24,6 +24,16 @@ def hip():
 
 
 @pytest.fixture(scope="module")
+def hipd():
+    """Kernel layer bound to the debug build (libexamg_dbg.so, -DEXAMG_DEBUG_HOOKS): same kernels plus the examg_debug_* entry
+    points that force the generic / alternative variants.  The product library does not export them (tests/test_abi.py)."""
+    from exastencils_amd import lib
+    from exastencils_amd.ops import HipOps
+
+    return HipOps(0, lib.DBG_LIB_PATH)
+
+
+@pytest.fixture(scope="module")
 def orc():
     return OracleOps()
 
@@ -174,24 +184,25 @@ def _two_stage_reference(orc, kind, shape, st, b, e, first=0):
     return [orc.to_host(out), orc.to_host(u)]
 
 
-@pytest.fixture(params=[0, 5, 8, 9], ids=["registers", "lds5", "lds8", "lds9"])
-def two_stage_variant(request, hip):
-    """Both implementations of the two-stage kernel: register rings (one wave per row pair, halo recomputed) and the
-    LDS variant (5 or 9 waves share a row stack through LDS)."""
+@pytest.fixture(params=[5, 8], ids=["lds5", "lds8"])
+def two_stage_variant(request, hipd):
+    """Both workgroup shapes of the two-stage kernel (5 or 8 waves share a row stack through LDS), forced through the debug
+    build; yields the kernel layer to use."""
     import ctypes as C
 
-    hip.L.examg_debug_two_stage_lds.argtypes = [C.c_int]
-    hip.L.examg_debug_two_stage_lds(request.param)
-    yield request.param
-    hip.L.examg_debug_two_stage_lds(-1)     # back to the shipped default
+    hipd.L.examg_debug_two_stage_lds.argtypes = [C.c_int]
+    hipd.L.examg_debug_two_stage_lds(request.param)
+    yield hipd
+    hipd.L.examg_debug_two_stage_lds(-1)     # back to the shipped default
 
 
 @pytest.mark.parametrize("kind", ["rbgs", "jacobi2"])
 @pytest.mark.parametrize("order", ["mp", "pm"])
 @pytest.mark.parametrize("n,first", [(65, 0), (130, 1), (200, 0)])
-def test_two_stage_kernel_bit_exact(hip, orc, two_stage_variant, kind, order, n, first):
+def test_two_stage_kernel_bit_exact(orc, two_stage_variant, kind, order, n, first):
     """Fused red-black sweep / two Jacobi steps in one pass == the two loops run one after the other, bit for bit;
     130 and 200 leave ragged 124-point x windows, row groups and z chunks."""
+    hip = two_stage_variant
     st = laplace_fd(3, (1.0 / n,) * 3, order)
     b, e = box(3, n)
     g = _two_stage_case(hip, kind, (n, n, n), st, b, e, first)
@@ -201,9 +212,10 @@ def test_two_stage_kernel_bit_exact(hip, orc, two_stage_variant, kind, order, n,
 
 
 @pytest.mark.parametrize("kind", ["rbgs", "jacobi2"])
-def test_two_stage_interior_faces_anisotropic(hip, orc, two_stage_variant, kind):
+def test_two_stage_interior_faces_anisotropic(orc, two_stage_variant, kind):
     """Block with neighbours on some faces: the loop includes the duplicate planes (begin 0 / end n+1), so the
     two-point input halo reaches the ghost layer and beyond the allocation (guarded)."""
+    hip = two_stage_variant
     shape = (150, 36, 20)
     st = laplace_unit(3)
     b, e = [0, 1, 0], [151, 36, 21]
@@ -218,9 +230,10 @@ def test_two_stage_interior_faces_anisotropic(hip, orc, two_stage_variant, kind)
     ((130, 70, 33), [1, 0, 1], [130, 71, 33], [1, 1, 1], [130, 71, 33]),     # lower y neighbour only
     ((40, 20, 20), [0, 1, 1], [41, 20, 20], [1, 1, 1], [41, 20, 20]),        # small rows: fallback path
 ])
-def test_jacobi2_boxes_bit_exact(hip, orc, two_stage_variant, shape, b, e, b2, e2):
+def test_jacobi2_boxes_bit_exact(orc, two_stage_variant, shape, b, e, b2, e2):
     """Two Jacobi steps with the first step on the loop's box and the second on the box without the duplicate planes at
     interior faces (what a block with neighbours runs, exastencils_amd/smoothers.py)."""
+    hip = two_stage_variant
     st = laplace_unit(3)
 
     def f(ops):
@@ -242,9 +255,10 @@ def test_jacobi2_boxes_bit_exact(hip, orc, two_stage_variant, shape, b, e, b2, e
     ((130, 70, 33), [1, 1, 1], [130, 71, 33], [1, 2, 1], [130, 71, 33]),     # lower y neighbour only
     ((40, 20, 20), [1, 1, 1], [41, 20, 20], [2, 1, 1], [41, 20, 20]),        # short rows: fallback path
 ])
-def test_rbgs_sweep_fused_boxes_bit_exact(hip, orc, two_stage_variant, shape, b1, e1, b2, e2, first):
+def test_rbgs_sweep_fused_boxes_bit_exact(orc, two_stage_variant, shape, b1, e1, b2, e2, first):
     """Red-black sweep of a block with neighbours: first colour on the box shrunk by one point at interior faces, second
     colour on the box shrunk by two; u_out is written on the second box only (exastencils_amd/smoothers.py: rbgs_sweep)."""
+    hip = two_stage_variant
     st = laplace_fd(3, tuple(1.0 / s_ for s_ in shape))
 
     def f(ops):
@@ -275,7 +289,8 @@ def test_two_stage_fallback_small_and_2d(hip, orc):
         assert np.array_equal(got[0].reshape(lu.shape_zyx)[sl], c[0].reshape(lu.shape_zyx)[sl]), kind
 
 
-def test_generic_path_equals_fast_path(hip, orc):
+def test_generic_path_equals_fast_path(hipd, orc):
+    hip = hipd
     n = 96
     st = laplace_fd(3, (1.0 / n,) * 3)
     b, e = box(3, n)
@@ -626,10 +641,11 @@ def test_init_helmholtz27(hip, orc):
     assert np.allclose(g[0], c[0], rtol=1e-13, atol=0.0)      # exp() through device libm
 
 
-def test_fused_kernels_on_a_large_odd_block(hip):
+def test_fused_kernels_on_a_large_odd_block(hipd):
     """640^3 cells (2.1 GB per array, byte offsets beyond 2^31, a size that is no power of two): the fused two-step kernel,
     the fused red-black sweep and the wide restriction equal their unfused forms bit for bit (GPU against GPU; the oracle
     covers the unfused forms at sizes it finishes in seconds)."""
+    hip = hipd
     import torch
 
     n = 640

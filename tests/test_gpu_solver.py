@@ -249,11 +249,14 @@ def test_rbgs_sweep_overlap_equals_sequential(hip, rank):
     assert np.array_equal(outs[0], outs[2])
 
 
-def test_lds_resident_coarse_cg_equals_global_memory_solver(hip):
+def test_lds_resident_coarse_cg_equals_global_memory_solver():
     """Coarsest grids of up to 4096 points run the CG with its vectors in registers / LDS: same iterates, bit for bit, as
     the global-memory form of the kernel (3-D 16^3 and 8^3 coarsest grids, 2-D 16^2)."""
+    from exastencils_amd import lib
+    from exastencils_amd.ops import HipOps
     from exastencils_amd.solver import ConfigL4, SolverFromL4
 
+    hip = HipOps(0, lib.DBG_LIB_PATH)      # debug build: examg_debug_cg selects the form of the solver
     for kw in (dict(nd=3, min_level=4, max_level=6), dict(nd=3, min_level=3, max_level=5),
                dict(nd=2, min_level=4, max_level=7, bc_fn=2, rhs_fn=3)):
         hist = []

@@ -7,10 +7,11 @@ sys.path.insert(0, ROOT)
 import torch
 from exastencils_amd.field import laplace_fd
 from exastencils_amd.layout import FieldLayout
+from exastencils_amd import lib
 from exastencils_amd.ops import HipOps
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-ops = HipOps(0)
+ops = HipOps(0, lib.DBG_LIB_PATH)      # debug build: examg_debug_restrict selects the restriction kernel
 lu, lf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0)
 lc = FieldLayout.node(3, (n // 2,) * 3, 0)
 u, a, b_, t, f = (ops.new_array(lu.size) for _ in range(4)), None, None, None, ops.new_array(lf.size)

@@ -11,10 +11,11 @@ import torch
 
 from exastencils_amd.field import Stencil, helmholtz27_offsets, stencil_field_offsets
 from exastencils_amd.layout import FieldLayout
+from exastencils_amd import lib
 from exastencils_amd.ops import HipOps
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-ops = HipOps(0)
+ops = HipOps(0, lib.DBG_LIB_PATH)      # debug build: examg_debug_stencilfield / examg_debug_sf27 select the kernel variant
 ops.L.examg_debug_stencilfield.argtypes = [C.c_int, C.c_int]
 n = 1 << level
 lu, lf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0)
