@@ -10,16 +10,22 @@ metric    = LU/s (lattice updates per second, the authors' formula Testing/PolyE
             K steps run as K/2 two-step passes (exastencils_amd/smoothers.py: temporal blocking, the reference's
             contracting-loop idea; bit-identical to K single steps, also across block neighbours) unless
             --no-temporal-blocking.
-roofline  = HBM: 24 algorithmic bytes per update (read u, read rhs, write u_next;
-            Compiler/src/exastencils/performance/ir/IR_EvaluatePerformanceEstimates.scala:206-215)
-            x updates per launch / average launch time of the dominant kernel (events on the launch stream);
-            the single-step kernel's figures are reported next to it.
-cpu_baseline = the restated reference CPU path (oracle/examg_oracle.c:orc_jacobi7_const, generator-shaped
-            OpenMP loop) timed on this host's cores on a bounded 256^3 sample.
-Also reported (extra keys): one V(3,3) RBGS cycle of the Benchmark/Poisson3D program at 512^3 (config 3).
+roofline  = HBM.  `achieved` = compulsory bytes of ONE launch of the dominant kernel / its average duration (HIP events on
+            the launch stream).  Compulsory bytes follow the reference's own rule
+            (Compiler/src/exastencils/performance/ir/IR_EvaluatePerformanceEstimates.scala:206-215): 8 B x points x distinct
+            (field, slot, read/write) streams of the launch = 24 B per point for a Jacobi pass -- also for the two-step
+            kernel, which reads u and rhs once and writes once for TWO updates per point.  `frac` = achieved / 8 TB/s is
+            therefore a fraction of the roofline for every kernel; the per-update figure (24 B per lattice update, which
+            exceeds the peak when two updates share a pass) is reported separately as `lu_equivalent_*`.
+            `traffic` = fabric-side bytes per launch from rocprofv3 PMC passes (profiles/r02_pmc_kernels.json), given only
+            when that profile was taken for this kernel at this block size and layout.
+            `roofline_kernels` = the same accounting, timed live, for every hot kernel of the V-cycle and the V-cycle itself.
+cpu_baseline = the restated reference CPU path (oracle/examg_oracle.c, generator-shaped OpenMP loops) timed on this host's
+            cores on a bounded sample of the same 512^3 workload: Jacobi sweeps (the headline `value`), and per kernel
+            (red-black sweep, residual, restriction, prolongation, one V-cycle) as BASELINE.md section 3 lists.
 
 Launch: `python bench.py` (1 GPU) or
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W`.
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W [--scaling strong]`.
 """
 import argparse
 import json
@@ -33,6 +39,7 @@ if ROOT not in sys.path:
 
 BYTES_PER_LU = 24.0
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
 
 
 def parse():
@@ -41,18 +48,39 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--level", type=int, default=9, help="finest level: 2^level cells per dim per GPU (9 => 512^3)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 2^level cells per dim PER GPU (default); strong: 2^level cells per dim in TOTAL, divided among the blocks")
+    ap.add_argument("--align", type=int, default=0,
+                    help="row padding of the field layouts in doubles (IR_AddPaddingToFieldLayouts); 0 = the verbatim reference layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-temporal-blocking", action="store_true", help="one kernel launch per smoother step")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--extras-timeout", type=float, default=240.0, help="seconds the extra measurements may take")
+    ap.add_argument("--check-duplicates", action="store_true",
+                    help="exchange the duplicate planes once and verify them bit for bit before leaving that exchange out")
     ap.add_argument("--backend", default="nccl", help="'gloo': rehearsal with several ranks on ONE GPU (messages staged through the host)")
     return ap.parse_args()
 
 
+def host_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS")}
+
+
 def cpu_baseline(seconds: float):
-    """Restated reference CPU path on a bounded sample of the same workload: 512^3 Jacobi sweeps for ~`seconds` s on the
-    hardware threads this process is allowed to use."""
+    """Restated reference CPU path on a bounded sample of the same workload (512^3 cells, reference layout) on the hardware
+    threads this process is allowed to use: Jacobi sweeps for ~`seconds` s (`value`), then ~2 s per other kernel and one
+    V(3,3) cycle of the Benchmark/Poisson3D program."""
     import ctypes as C
 
     from oracle import mg
@@ -61,37 +89,86 @@ def cpu_baseline(seconds: float):
     L.orc_set_num_threads(min(int(L.orc_num_threads()), mg.cpu_budget()))   # affinity mask capped by the cgroup CPU quota
     n = 512
     lu, lf = mg.Layout.node(3, (n, n, n), 1), mg.Layout.node(3, (n, n, n), 0)
+    lcu, lcf = mg.Layout.node(3, (n // 2,) * 3, 1), mg.Layout.node(3, (n // 2,) * 3, 0)
     u, un, f = lu.alloc(), lu.alloc(), lf.alloc()
+    uc, fc = lcu.alloc(), lcf.alloc()
     L.orc_fill_random(u.ctypes.data, u.size, 12345)
     L.orc_fill_random(f.ctypes.data, f.size, 777)
+    L.orc_fill_random(uc.ctypes.data, uc.size, 5)
     st = mg.laplace_examples(3, (1.0 / n,) * 3)
-    sc, luc, lfc = st.c(), lu.c(), lf.c()
+    sc, luc, lfc, lcuc, lcfc = st.c(), lu.c(), lf.c(), lcu.c(), lcf.c()
     w = 0.8 / st.coefs[0]
     b, e = (C.c_int * 3)(1, 1, 1), (C.c_int * 3)(n, n, n)
+    bc, ec = (C.c_int * 3)(1, 1, 1), (C.c_int * 3)(n // 2, n // 2, n // 2)
     ptr = [u.ctypes.data, un.ctypes.data]
+    pts, cpts = (n - 1) ** 3, (n // 2 - 1) ** 3
 
-    def sweep(i):
+    def timed(fn, budget, min_reps=2):
+        fn(0)
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            fn(k)
+            k += 1
+            dt = time.perf_counter() - t0
+            if (dt >= budget and k >= min_reps) or k >= 100000:
+                return k, dt
+
+    def jac(i):
         L.orc_jacobi7_const(C.byref(luc), ptr[i % 2], C.byref(lfc), f.ctypes.data, ptr[(i + 1) % 2], C.byref(sc), w, b, e)
 
-    sweep(0)
-    sweep(1)
-    t0 = time.perf_counter()
-    k = 0
-    while True:
-        sweep(k)
-        k += 1
-        dt = time.perf_counter() - t0
-        if (dt >= seconds and k >= 4) or k >= 100000:
-            break
-    pts = (n - 1) ** 3
-    return {
+    def rbgs(i):
+        for colour in (0, 1):
+            L.orc_stencil_op(2, C.byref(luc), u.ctypes.data, C.byref(lfc), f.ctypes.data, C.byref(luc), u.ctypes.data, C.byref(sc), w, colour, b, e)
+
+    def residual(i):
+        L.orc_stencil_op(1, C.byref(luc), u.ctypes.data, C.byref(lfc), f.ctypes.data, C.byref(luc), un.ctypes.data, C.byref(sc), 0.0, -1, b, e)
+
+    def restrict(i):
+        L.orc_restrict(C.byref(luc), un.ctypes.data, C.byref(lcfc), fc.ctypes.data, 1.0, bc, ec)
+
+    def prolong(i):
+        L.orc_prolong_add(C.byref(lcuc), uc.ctypes.data, C.byref(luc), u.ctypes.data, b, e)
+
+    k, dt = timed(jac, seconds, 4)
+    out = {
         "value": pts * k / dt,
         "unit": "LU/s",
         "cores": int(L.orc_num_threads()),
         "kind": "port",
-        "sample": "%d Jacobi 7-pt sweeps of 512^3 cells (511^3 updates each), restated generator-shaped OpenMP loop, %.1f s"
-                  % (k, dt),
+        "sample": "%d Jacobi 7-pt sweeps of 512^3 cells (511^3 updates each), restated generator-shaped OpenMP loop, %.1f s; "
+                  "per kernel ~2 s each; one V(3,3) cycle (levels 4..9) of the Benchmark/Poisson3D program" % (k, dt),
     }
+    out.update(host_info())
+    per = {}
+    for name, fn, units, bpu in (("rbgs_sweep", rbgs, pts, 48.0), ("residual", residual, pts, 24.0), ("restrict", restrict, cpts, 72.0),
+                                 ("prolong_add", prolong, pts, 17.0)):
+        k, dt = timed(fn, 2.0)
+        per[name] = {"ms": dt / k * 1e3, "units_per_s": units * k / dt, "algorithmic_gbs": units * bpu * k / dt / 1e9}
+    per["jacobi"] = {"ms": 1e3 * pts / out["value"], "units_per_s": out["value"], "algorithmic_gbs": out["value"] * 24.0 / 1e9}
+    del u, un, f, uc, fc
+    P = mg.ProgramA(mg.ConfigA(nd=3, min_level=4, max_level=9, tol=1e-6))
+    P.setup()
+    P.mgCycle(9)
+    t0 = time.perf_counter()
+    P.mgCycle(9)
+    per["vcycle"] = {"ms": (time.perf_counter() - t0) * 1e3, "levels": 6}
+    out["kernels"] = per
+    return out
+
+
+def pmc_traffic(case, level, align):
+    """Fabric-side bytes per launch from the committed counter profile -- only for this kernel case, block size and layout."""
+    try:
+        prof = json.load(open(PMC_PROFILE))
+    except (OSError, ValueError):
+        return None
+    if prof.get("level") != level or prof.get("align", 0) != align:
+        return None
+    for k in prof.get("kernels", []):
+        if k.get("case") == case and "traffic" in k:
+            return {"traffic": k["traffic"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"], "source": "profiles/r02_pmc_kernels.json"}
+    return None
 
 
 def main():
@@ -124,19 +201,26 @@ def main():
 
     ops = HipOps(local_rank)
     nd, L = 3, args.level
-    # weak scaling keeps the mesh width: the physical domain grows with the blocks, [0,1]^3 per block (a unit cube cut into
-    # 1 x 2 x 4 blocks of 512^3 cells would be an anisotropic mesh, on which point smoothers with full coarsening degrade)
     blocks = RectDomain.blocks_for(world, nd)
-    dom = RectDomain(nd, blocks, rank, hi=tuple(float(b) for b in blocks))
+    if args.scaling == "weak":
+        # weak scaling keeps the mesh width: the physical domain grows with the blocks, [0,1]^3 per block (a unit cube cut into
+        # 1 x 2 x 4 blocks of 512^3 cells would be an anisotropic mesh, on which point smoothers with full coarsening degrade)
+        dom = RectDomain(nd, blocks, rank, hi=tuple(float(b) for b in blocks))
+    else:
+        # strong scaling: 2^level cells per dimension in total, the unit cube; a block keeps
+        # 2^level / blocks[d] cells in dimension d = frag_len[d] * 2^(level - shift) with shift = log2(max blocks)
+        shift = max(blocks).bit_length() - 1
+        L = args.level - shift
+        dom = RectDomain(nd, blocks, rank, tuple(max(blocks) // b for b in blocks))
     # 7-point loops read face ghosts only (one batch per exchange); duplicate planes are computed to the same bits on
     # both sides by every loop of these programs, so their upstream exchange is left out (exastencils_amd/comm.py)
     comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
     nc = dom.ncells(L)
-    Solution = Field("Solution", L, FieldLayout.node(nd, nc, 1), ops, 2, None)
-    RHS = Field("RHS", L, FieldLayout.node(nd, nc, 0, False, False), ops, 1, None)
-    ops.fill_random(Solution.data(0), 12345 + rank)
-    ops.fill_random(Solution.data(1), 999 + rank)
-    ops.fill_random(RHS.data(), 777 + rank)
+    Solution = Field("Solution", L, FieldLayout.node(nd, nc, 1, True, True, args.align), ops, 2, None)
+    RHS = Field("RHS", L, FieldLayout.node(nd, nc, 0, False, False, args.align), ops, 1, None)
+    # synthetic data: one global random field, so that the duplicate planes two blocks share hold the same values on both
+    for t, seed in ((Solution.data(0), 12345), (Solution.data(1), 12345), (RHS.data(), 777)):
+        ops.fill_random(t, seed + (0 if world == 1 else 1000 * rank))
     A = laplace_fd(nd, dom.h(L), "mp")
     w = 0.8 / A.diag
     b, e = dom.loop_bounds(Solution.layout)
@@ -145,6 +229,16 @@ def main():
     from exastencils_amd.smoothers import jacobi_pair
 
     Tmp = Field("SolutionTmp", L, Solution.layout, ops, 1, None)
+
+    dup_check = None
+    if world > 1:
+        # make the synthetic field consistent across blocks (duplicate planes from the upstream block, ghosts from the
+        # neighbours) with the full exchange; --check-duplicates then verifies what `consistent_duplicates` relies on
+        full = Communicator(dom, ops)
+        for s_ in (0, 1):
+            full.exchange(Solution, s_, "all")
+        if args.check_duplicates:
+            dup_check = comm.check_duplicates(Solution, 0)
 
     def step():
         # Function Smoother@finest: communicate ghost of Solution<active>; Jacobi loop; advance
@@ -193,7 +287,7 @@ def main():
     else:
         total_updates = updates
 
-    # the two hot kernels alone, events on the launch stream
+    # the two smoother kernels alone, events on the launch stream
     stream = torch.cuda.current_stream()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     nk = max(10, min(args.steps, 100))
@@ -206,7 +300,6 @@ def main():
     ev1.record(stream)
     torch.cuda.synchronize()
     single_ms = ev0.elapsed_time(ev1) / nk
-    single_gbs = BYTES_PER_LU * updates / (single_ms * 1e-3) / 1e9
     ev0.record(stream)
     for _ in range(nk):
         ops.jacobi2(Solution.lc, Solution.data(Solution.active), Solution.data(Solution.next), Tmp.data(), RHS.lc, RHS.data(),
@@ -215,29 +308,24 @@ def main():
     ev1.record(stream)
     torch.cuda.synchronize()
     pair_ms = ev0.elapsed_time(ev1) / nk
-    pair_gbs = 2.0 * BYTES_PER_LU * updates / (pair_ms * 1e-3) / 1e9
+    compulsory = BYTES_PER_LU * updates          # one pass: read u, read rhs, write u' -- for either kernel
+    single_gbs = compulsory / (single_ms * 1e-3) / 1e9
+    pair_gbs = compulsory / (pair_ms * 1e-3) / 1e9
     if args.no_temporal_blocking:
-        kernel_name, kernel_ms, achieved, units = "k_stencil7_zmarch (one Jacobi step per launch)", single_ms, single_gbs, updates
+        case, kernel_name, kernel_ms, achieved, lus = "jacobi_1step", "k_stencil7_zmarch (one Jacobi step per launch)", single_ms, single_gbs, updates
     else:
-        kernel_name, kernel_ms, achieved, units = "k_two_stage7 (two Jacobi steps per launch)", pair_ms, pair_gbs, 2 * updates
+        case, kernel_name, kernel_ms, achieved, lus = "jacobi_2step", "k_two_stage7_lds (two Jacobi steps per launch)", pair_ms, pair_gbs, 2 * updates
 
     extra = {
         "jacobi_single_step_kernel_ms": single_ms,
-        "jacobi_single_step_algorithmic_gbs": single_gbs,
+        "jacobi_single_step_frac": single_gbs / HBM_PEAK_GBS,
         "jacobi_two_step_kernel_ms": pair_ms,
-        "jacobi_two_step_algorithmic_gbs": pair_gbs,
+        "jacobi_two_step_frac": pair_gbs / HBM_PEAK_GBS,
         "temporal_blocking": not args.no_temporal_blocking,
     }
     out = None
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj["single_step" if args.no_temporal_blocking else "two_step"]["bytes_per_launch"]
-            except Exception:
-                traffic = None
+        pmc = pmc_traffic(case, L, args.align) if nc[0] == nc[1] == nc[2] == (1 << L) else None
         out = {
             "metric": "LU/s",
             "value": total_updates * args.steps / dt,
@@ -247,18 +335,21 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "3D Poisson 7-point Jacobi smoother steps (ghost exchange + sweep + advance), %d^3 cells per GPU, "
-                            "reference field layout (%d^3 doubles per slot)%s"
-                            % (nc[0], Solution.layout.tot(0),
+                "workload": "3D Poisson 7-point Jacobi smoother steps (ghost exchange + sweep + advance), %d x %d x %d cells per GPU, "
+                            "%s (%d-double rows)%s"
+                            % (nc[0], nc[1], nc[2],
+                               "reference field layout" if not args.align else "reference layout model with rows padded to multiples of %d doubles" % args.align,
+                               Solution.layout.tot(0),
                                "" if args.no_temporal_blocking else "; consecutive step pairs fused (temporal blocking, bit-identical)"),
                 "blocks": list(dom.num_blocks),
                 "updates_per_step_per_gpu": updates,
                 "levels": L,
+                "align": args.align,
             },
             "roofline": {
                 "bound": "hbm",
@@ -266,23 +357,27 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": pmc["traffic"] if pmc else None,
                 "kernel": kernel_name,
                 "kernel_ms": kernel_ms,
-                "bytes_per_lu": BYTES_PER_LU,
-                "lu_per_launch": units,
-                # two updates share one pass in the dominant kernel, so `achieved` (algorithmic bytes / time) can exceed the
-                # peak; the bytes that really moved at the L2's fabric side (`traffic`, PMC) per second, and the one-step-
-                # per-launch kernel against the same peak, for orientation
-                "traffic_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-                "frac_one_step_per_launch": single_gbs / HBM_PEAK_GBS,
+                "compulsory_bytes_per_launch": compulsory,
+                "compulsory_bytes_per_point": BYTES_PER_LU,
+                "lu_per_launch": lus,
+                # 24 B per lattice UPDATE: with two updates per pass this exceeds the peak -- a throughput
+                # statement, not a roofline fraction
+                "lu_equivalent_gbs": BYTES_PER_LU * lus / (kernel_ms * 1e-3) / 1e9,
+                "lu_equivalent_frac": BYTES_PER_LU * lus / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic_over_compulsory": (pmc["traffic"] / compulsory) if pmc else None,
+                "traffic_source": pmc["source"] if pmc else None,
             },
         }
+        if dup_check is not None:
+            out["duplicate_planes_bit_identical"] = dup_check
         out.update(extra)
 
-    # Extra measurements (256^3 block of configs[1], V-cycle / Solve of config 3).  They run collectives at N > 1; the
-    # headline above must survive whatever happens here: a watchdog thread prints it without the extras and ends the
-    # process if they do not finish in time (a blocked collective keeps the main thread inside a C call).
+    # Extra measurements (kernel table, 256^3 block of configs[1], V-cycle / Solve of config 3).  They run collectives at
+    # N > 1; the headline above must survive whatever happens here: a watchdog thread prints it without the extras and ends
+    # the process with a non-zero code if they do not finish in time (a blocked collective keeps the main thread in a C call).
     if not args.no_vcycle:
         import threading
 
@@ -293,20 +388,30 @@ def main():
                 if rank == 0:
                     out["vcycle_error"] = "extras did not finish within %g s" % args.extras_timeout
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         more = {}
+        if world == 1 and not args.no_kernel_table:
+            try:
+                more["roofline_kernels"] = kernel_table(ops, L, args.align)
+            except Exception as ex:
+                more["roofline_kernels_error"] = repr(ex)[:300]
         try:
             more.update(config1(ops, world))
         except Exception as ex:
             more["config1_error"] = repr(ex)[:300]
         try:
-            more.update(vcycle(ops, dom, comm, L, world))
+            more.update(vcycle(ops, dom, comm, L, world, args.align))
         except Exception as ex:  # the headline number must not depend on the extra measurement
             more["vcycle_error"] = repr(ex)[:300]
         done.set()
         if rank == 0:
+            if "roofline_kernels" in more and "vcycle_ms" in more:
+                cb = more.pop("vcycle_compulsory_bytes")
+                more["roofline_kernels"].append({"case": "vcycle_v33_6levels", "kernel": "hipGraph of one mgCycle@finest", "ms": more["vcycle_ms"],
+                                                 "compulsory_bytes": cb, "frac": cb / (more["vcycle_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
+            more.pop("vcycle_compulsory_bytes", None)
             out.update(more)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -315,6 +420,41 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_table(ops, level, align):
+    """Every hot kernel of the V-cycle at the finest level, one launch each between HIP events: compulsory bytes (reference
+    rule), ms, frac of the 8 TB/s roofline, and the PMC traffic of profiles/ when it was taken for this size."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_kernels
+
+    cs, keep = pmc_kernels.cases(ops, level, True, align)
+    rows = []
+    stream = torch.cuda.current_stream()
+    for name, fn, pattern, comp, lus in cs:
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        row = {"case": name, "kernel": pattern, "ms": ms, "compulsory_bytes": comp, "lattice_updates": lus,
+               "frac": comp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        pmc = pmc_traffic(name, level, align)
+        if pmc:
+            row["traffic"] = pmc["traffic"]
+            row["traffic_over_compulsory"] = pmc["traffic"] / comp
+        rows.append(row)
+        ops.fill_random(keep["u"], 100)
+    del cs, keep
+    torch.cuda.empty_cache()
+    return rows
 
 
 def config1(ops, world):
@@ -351,10 +491,11 @@ def config1(ops, world):
         ms = ev0.elapsed_time(ev1) / 50
         out["jacobi_256cube_%s_kernel_ms" % name] = ms
         out["jacobi_256cube_%s_lups" % name] = steps * (n - 1) ** 3 / (ms * 1e-3)
+        out["jacobi_256cube_%s_frac" % name] = 24.0 * (n - 1) ** 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     return out
 
 
-def vcycle(ops, dom, comm, L, world):
+def vcycle(ops, dom, comm, L, world, align=0):
     """Config 3: one V(3,3) red-black cycle of Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4, 6 levels."""
     import torch
 
@@ -366,7 +507,7 @@ def vcycle(ops, dom, comm, L, world):
     # coarsens log2(max blocks per dimension) levels further, back to a few hundred points
     extra = max(dom.num_blocks).bit_length() - 1 if world > 1 else 0
     cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True, agglomerate_level=agg,
-                   agglomerate_extra_levels=extra)
+                   agglomerate_extra_levels=extra, align=align)
     P = SolverFromL4(cfg, ops, dom, comm)
     P.setup()
     P._update_residual(L)
@@ -396,16 +537,26 @@ def vcycle(ops, dom, comm, L, world):
     its = Q.Solve(use_graph=use_graph)
     torch.cuda.synchronize()
     solve_s = time.perf_counter() - t0
+    # compulsory bytes of one cycle with the fused kernels, per level above the coarsest: 6 sweeps x 24 B per point, residual +
+    # restriction (16 B per point + 8 B per coarse point), zeroing the coarse solution (8 B per coarse point), prolongation +
+    # correction (16 B per point + 8 B per coarse point)
+    comp = 0.0
+    for l in range(L - 4, L + 1):
+        lb, le = dom.loop_bounds(P.Solution[l].layout)
+        lcb, lce = dom.loop_bounds(P.Solution[l - 1].layout)
+        p = float((le[0] - lb[0]) * (le[1] - lb[1]) * (le[2] - lb[2]))
+        c = float((lce[0] - lcb[0]) * (lce[1] - lcb[1]) * (lce[2] - lcb[2]))
+        comp += 6 * 24.0 * p + 16.0 * p + 8.0 * c + 8.0 * c + 16.0 * p + 8.0 * c
     npts = 1
     b, e = dom.loop_bounds(P.Solution[L].layout)
     for d in range(3):
         npts *= e[d] - b[d]
-    # 223 algorithmic bytes per finest-grid point per V(3,3) cycle with the 24 B/LU red-black floor
     return {
         "vcycle_ms": ms,
         "vcycle_levels": 6 + extra,
         "vcycle_residual_reduction": r1 / r0 if r0 else None,
-        "vcycle_gbs_algorithmic": 223.0 * npts / (ms * 1e-3) / 1e9,
+        "vcycle_compulsory_bytes": comp,
+        "vcycle_gbs_algorithmic_223B_per_point": 223.0 * npts / (ms * 1e-3) / 1e9,   # SURVEY.md 8d's per-point figure
         "totalTimeSolve": solve_s,                 # seconds
         "totalTimeSolve_ms": solve_s * 1e3,        # the unit the reference's getTotalTime / printJSON reports (timing/ir/IR_GetTime.scala:33-45)
         "solve_iterations": its,

@@ -9,10 +9,15 @@ become valid with 6 neighbours only (comm_syncGhostData; ranges IR_PackInfoDupli
 IR_PackInfoGhost.scala:13-60); pack -> send / recv -> unpack (:194-219); MPI_Allreduce after reduction
 loops (parallelization/api/mpi/MPI_Reduction.scala:100-126).
 
-Transport here: torch.distributed point-to-point batches -- backend "nccl" is RCCL (one process per
-GPU; each pair of GPUs has its own xGMI link, so the three axis exchanges of a 2x2x2 decomposition use
-three different links), backend "gloo" on CPU for the multi-process tests.  Packing is done by the
-kernel layer (`ops.pack/unpack`) into persistent buffers; nothing is staged through the host.
+Transport, two forms behind one interface:
+  * "c": libexamg's own transport (include/examg.h: examg_exchange / examg_allreduce / examg_allgather,
+    exastencils_amd/csrc/examg_comm.hip) -- ncclSend / ncclRecv groups of RCCL between the axis neighbours (one process per
+    GPU; each pair of GPUs has its own xGMI link), pack / unpack kernels, all stream-ordered and capturable into a hipGraph.
+    This is the product path on GPUs and the one a generated C++ host shares; the 128-byte RCCL id of rank 0 travels through
+    torch.distributed (whatever backend the launcher initialised), which otherwise carries no data.
+  * "torch": torch.distributed point-to-point batches around `ops.pack/unpack` -- backend "gloo" with the CPU oracle ops in the
+    multi-process CPU tests, or "gloo" with device arrays staged through the host (several ranks rehearsing on ONE GPU, where
+    RCCL refuses two ranks on one device).
 """
 from __future__ import annotations
 
@@ -24,7 +29,7 @@ from .field import Field
 
 class Communicator:
     def __init__(self, domain: RectDomain, ops, group=None, concurrent_ghost_axes: bool = False,
-                 consistent_duplicates: bool = False):
+                 consistent_duplicates: bool = False, transport: str = "auto"):
         """concurrent_ghost_axes: where the caller declares that only face ghosts will be read (`axis_only=True`:
         5/7-point stencil loops), send the ghost planes of all axes in ONE point-to-point batch instead of axis by axis.
         Face ghosts are identical; edge/corner ghosts -- which only the axis-by-axis order makes valid and which
@@ -54,6 +59,71 @@ class Communicator:
                            and getattr(ops.device, "type", "cpu") != "cpu")
         self._bufs: Dict[Tuple, object] = {}
         self.stats = {"messages": 0, "bytes": 0}
+        # transport selection: the C transport whenever the kernel layer is libexamg on a GPU and messages need no host staging
+        on_gpu = hasattr(ops, "L") and hasattr(ops.L, "examg_exchange") and getattr(getattr(ops, "device", None), "type", "cpu") != "cpu"
+        if transport == "auto":
+            transport = "c" if (on_gpu and not self._stage) else "torch"
+        if transport == "c" and not on_gpu:
+            raise RuntimeError("the C transport needs the HIP kernel layer (HipOps)")
+        self.transport = transport
+        self._c = None
+        self._ws: Dict[Tuple, object] = {}
+        self._nb = None
+        if transport == "c" and (self.dist is not None or any(domain.periodic)):
+            self._c_create()
+
+    # -- C transport (libexamg / RCCL) -----------------------------------------------------------------
+    def _c_create(self):
+        import ctypes as C
+
+        from . import lib as _lib
+
+        L, dom = self.ops.L, self.domain
+        idbuf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+        if self.dist is not None:
+            torch = self.ops.torch
+            if dom.rank == 0:
+                _lib.check(L.examg_comm_unique_id(idbuf), "examg_comm_unique_id")
+            dev = self.ops.device if self.dist.get_backend(self.group) == "nccl" else "cpu"
+            t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=dev)
+            self.dist.broadcast(t, 0, group=self.group)
+            idbuf = (C.c_ubyte * _lib.COMM_ID_BYTES)(*t.cpu().tolist())
+            idp = C.cast(idbuf, C.c_void_p)
+        else:
+            idp = None
+            import os
+
+            if os.environ.get("EXAMG_COMM_SELF_RCCL") == "1":     # one-GPU test of the RCCL path: self-messages through RCCL
+                _lib.check(L.examg_comm_unique_id(idbuf), "examg_comm_unique_id")
+                idp = C.cast(idbuf, C.c_void_p)
+        h = C.c_void_p()
+        _lib.check(L.examg_comm_create(C.byref(h), idp, dom.world_size, dom.rank), "examg_comm_create")
+        self._c = h
+        nb = _lib.NeighborsC()
+        for d in range(3):
+            for s_, side in enumerate((-1, +1)):
+                r = dom.neighbor(d, side) if d < dom.nd else None
+                nb.rank[d][s_] = -1 if r is None else int(r)
+        self._nb = nb
+
+    def close(self):
+        if self._c is not None:
+            self.ops.L.examg_comm_destroy(self._c)
+            self._c = None
+
+    def _c_exchange(self, f: Field, x, what: int):
+        import ctypes as C
+
+        from . import lib as _lib
+
+        L = self.ops.L
+        key = (f.layout,)
+        ws = self._ws.get(key)
+        nbytes = int(L.examg_exchange_workspace_bytes(C.byref(f.lc)))
+        if ws is None:
+            ws = self._ws[key] = self.ops.new_array(max(1, nbytes // 8))
+        _lib.check(L.examg_exchange(self._c, C.byref(f.lc), self.ops.ptr(x), C.byref(self._nb), int(what), self.ops.ptr(ws), nbytes,
+                                    self.ops._stream()), "examg_exchange")
 
     # -- buffers -----------------------------------------------------------------------------------
     def _buf(self, key, n: int):
@@ -109,6 +179,19 @@ class Communicator:
             return   # single block, non-periodic: no neighbours, the generated exch function is empty
         lay, dom, nd = f.layout, self.domain, self.domain.nd
         x = f.data(slot)
+        if self._c is not None:
+            from .lib import EXCH_CONCURRENT_AXES, EXCH_DUP, EXCH_GHOST
+
+            w = 0
+            if what in ("all", "dup") and lay.communicates_dup and max(lay.dup) > 0 and not self.consistent_duplicates:
+                w |= EXCH_DUP
+            if what in ("all", "ghost") and lay.communicates_ghost and max(lay.ghost) > 0:
+                w |= EXCH_GHOST
+                if self.concurrent_ghost_axes and axis_only:
+                    w |= EXCH_CONCURRENT_AXES
+            if w:
+                self._c_exchange(f, x, w)
+            return
         if what in ("all", "dup") and lay.communicates_dup and max(lay.dup) > 0 and not self.consistent_duplicates:
             for d in range(nd):
                 plus, minus = dom.neighbor(d, +1), dom.neighbor(d, -1)
@@ -184,6 +267,12 @@ class Communicator:
         """MPI_Allreduce(MPI_IN_PLACE, &x, 1, MPI_DOUBLE, op) on a device scalar."""
         if self.dist is None:
             return t
+        if self._c is not None:
+            from .lib import check
+
+            check(self.ops.L.examg_allreduce(self._c, self.ops.ptr(t), int(t.numel()), 0 if op == "sum" else 1, self.ops._stream()),
+                  "examg_allreduce")
+            return t
         rop = self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX
         if self._stage:
             c = t.cpu()
@@ -194,7 +283,18 @@ class Communicator:
         return t
 
     def all_gather(self, outs: List, t):
-        """Every rank's `t` into `outs[rank]` (coarse-level agglomeration, exastencils_amd/solver.py)."""
+        """Every rank's `t` into `outs[rank]` (coarse-level agglomeration, exastencils_amd/solver.py); `outs` are consecutive
+        pieces of ONE array (solver.py allocates them that way), which is what the C transport writes into."""
+        if self._c is not None:
+            from .lib import check
+
+            n = int(t.numel())
+            base = outs[0]
+            for r, o in enumerate(outs):
+                if o.data_ptr() != base.data_ptr() + 8 * n * r:
+                    raise RuntimeError("all_gather: the receive pieces must be consecutive parts of one array")
+            check(self.ops.L.examg_allgather(self._c, self.ops.ptr(t), self.ops.ptr(base), n, self.ops._stream()), "examg_allgather")
+            return
         if self._stage:
             couts = [o.cpu() for o in outs]
             self.dist.all_gather(couts, t.cpu(), group=self.group)
@@ -202,3 +302,49 @@ class Communicator:
                 o.copy_(c)
             return
         self.dist.all_gather(outs, t, group=self.group)
+
+    # -- assertion mode for `consistent_duplicates` ---------------------------------------------------------
+    def check_duplicates(self, f: Field, slot: Optional[int] = None) -> bool:
+        """Exchange the duplicate planes of `f` into scratch buffers (the field is not touched) and compare them bit for bit
+        with the planes this block holds: True on every rank iff all shared planes agree.  Run once before relying on
+        `consistent_duplicates=True` (which leaves the upstream duplicate exchange out because both owners of a shared
+        plane compute it from the same inputs with the same kernel)."""
+        if self.dist is None:
+            return True
+        lay, dom, nd, ops = f.layout, self.domain, self.domain.nd, self.ops
+        x = f.data(slot)
+        bad = 0
+        # this one-time check travels through torch.distributed: device buffers on the "nccl" backend, host copies on "gloo"
+        host_wire = self.dist.get_backend(self.group) != "nccl" and getattr(getattr(ops, "device", None), "type", "cpu") != "cpu"
+        for d in range(nd):
+            plus, minus = dom.neighbor(d, +1), dom.neighbor(d, -1)
+            sbox, rbox = self.dup_ranges(lay, nd, d)
+            n = self._count(sbox)
+            p2p = []
+            rbuf = sbuf = None
+            if minus is not None and minus != dom.rank:
+                rbuf = self._buf(("dupcheck", d, "r"), n)
+                wire_r = rbuf.cpu() if host_wire else rbuf
+                p2p.append(self.dist.P2POp(self.dist.irecv, wire_r, minus, self.group))
+            if plus is not None and plus != dom.rank:
+                sbuf = self._buf(("dupcheck", d, "s"), n)
+                ops.pack(f.lc, x, sbuf, sbox[0], sbox[1])
+                ops.synchronize()
+                p2p.append(self.dist.P2POp(self.dist.isend, sbuf.cpu() if host_wire else sbuf, plus, self.group))
+            if p2p:
+                for w in self.dist.batch_isend_irecv(p2p):
+                    w.wait()
+            if rbuf is not None:
+                mine = self._buf(("dupcheck", d, "m"), n)
+                ops.pack(f.lc, x, mine, rbox[0], rbox[1])
+                ops.synchronize()
+                import numpy as np
+
+                got = wire_r.detach().cpu().numpy()
+                if not np.array_equal(got.view(np.uint64), np.asarray(ops.to_host(mine)).view(np.uint64)):
+                    bad += 1
+        t = self.ops.torch.tensor([float(bad)], dtype=self.ops.torch.float64)
+        if self.dist.get_backend(self.group) == "nccl":
+            t = t.to(ops.device)
+        self.dist.all_reduce(t, group=self.group)
+        return float(t.item()) == 0.0

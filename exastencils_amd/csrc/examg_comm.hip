@@ -1,0 +1,368 @@
+// Block-to-block transport of libexamg over RCCL: `communicate <field>` (exch<Field>_<level>(slot)) and the scalar
+// all-reduce that follows a reduction loop, as C entry points a generated C++ host (or the Python mirror, through ctypes)
+// calls -- one process per GPU, ncclSend / ncclRecv groups between the axis neighbours (each GPU pair has its own xGMI link),
+// everything stream-ordered: no host synchronisation, capturable into a hipGraph.
+//
+// Replaces, in the generated program: IR_CommunicateFunction.compileBody
+// (Compiler/src/exastencils/communication/ir/IR_CommunicateFunction.scala:194-219,412-471: duplicate layers first -- per
+// axis the own UPPER duplicate plane to the '+' neighbour, received into the LOWER plane from the '-' neighbour -- then ghost
+// layers per axis in both directions with tangential extent GLB..GRE, so that edge/corner ghosts become valid with six
+// neighbours only; index ranges IR_PackInfoDuplicate.scala:15-39 / IR_PackInfoGhost.scala:13-60; pack / unpack
+// IR_NoInterpPacking.scala:53-83; MPI_Isend / MPI_Irecv + waits IR_RemoteSend.scala:48-58, IR_RemoteRecv.scala:50-65;
+// local exchange between fragments of one process IR_NoInterpPacking.scala:101-131) and MPI_Allreduce(MPI_IN_PLACE, ..)
+// (parallelization/api/mpi/MPI_Reduction.scala:100-126).
+//
+// RCCL is bound at run time (dlopen of librccl.so.1, or $EXAMG_RCCL_LIB): a single-GPU host never needs it, and inside a
+// PyTorch process the copy PyTorch has already loaded is the one that is used (same soname).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+
+#include "examg_common.h"
+
+using namespace examg;
+
+namespace {
+
+struct Rccl {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.handle) return 0;
+  const char *env = getenv("EXAMG_RCCL_LIB");
+  const char *names[] = {env, "librccl.so.1", "librccl.so"};
+  void *h = nullptr;
+  for (const char *n : names) {
+    if (!n || !*n) continue;
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    set_error("examg_comm: cannot load RCCL (librccl.so.1; set EXAMG_RCCL_LIB): %s", dlerror());
+    return 1;
+  }
+#define EXAMG_SYM(field, name)                                             \
+  *(void **)(&g_rccl.field) = dlsym(h, name);                              \
+  if (!g_rccl.field) { set_error("examg_comm: RCCL lacks %s", name); return 1; }
+  EXAMG_SYM(GetUniqueId, "ncclGetUniqueId")
+  EXAMG_SYM(CommInitRank, "ncclCommInitRank")
+  EXAMG_SYM(CommDestroy, "ncclCommDestroy")
+  EXAMG_SYM(Send, "ncclSend")
+  EXAMG_SYM(Recv, "ncclRecv")
+  EXAMG_SYM(GroupStart, "ncclGroupStart")
+  EXAMG_SYM(GroupEnd, "ncclGroupEnd")
+  EXAMG_SYM(AllReduce, "ncclAllReduce")
+  EXAMG_SYM(AllGather, "ncclAllGather")
+  EXAMG_SYM(GetErrorString, "ncclGetErrorString")
+#undef EXAMG_SYM
+  g_rccl.handle = h;
+  return 0;
+}
+
+int check_nccl(ncclResult_t r, const char *what) {
+  if (r == ncclSuccess) return 0;
+  set_error("%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+  return 1;
+}
+
+}  // namespace
+
+struct examg_comm {
+  ncclComm_t nccl = nullptr;   // null for a one-rank communicator created without RCCL
+  int rank = 0, size = 1;
+  bool self_via_rccl = false;  // periodic self-exchange through ncclSend/ncclRecv to the own rank (one-GPU test of the transport)
+};
+
+static_assert(sizeof(ncclUniqueId) == EXAMG_COMM_ID_BYTES, "EXAMG_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+
+extern "C" int examg_comm_unique_id(void *id) {
+  if (!id) { set_error("examg_comm_unique_id: null argument"); return 1; }
+  if (load_rccl()) return 1;
+  ncclUniqueId u;
+  if (check_nccl(g_rccl.GetUniqueId(&u), "ncclGetUniqueId")) return 1;
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+extern "C" int examg_comm_create(examg_comm_t **comm, const void *id, int nranks, int rank) {
+  if (!comm) { set_error("examg_comm_create: null argument"); return 1; }
+  if (nranks < 1 || rank < 0 || rank >= nranks) { set_error("examg_comm_create: rank %d of %d", rank, nranks); return 1; }
+  examg_comm *c = new examg_comm;
+  c->rank = rank;
+  c->size = nranks;
+  const char *sv = getenv("EXAMG_COMM_SELF_RCCL");
+  c->self_via_rccl = sv && *sv == '1';
+  if (nranks > 1 || c->self_via_rccl) {
+    if (!id) { set_error("examg_comm_create: a communicator of %d ranks needs the unique id of rank 0", nranks); delete c; return 1; }
+    if (load_rccl()) { delete c; return 1; }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    if (check_nccl(g_rccl.CommInitRank(&c->nccl, nranks, u, rank), "ncclCommInitRank")) { delete c; return 1; }
+  }
+  *comm = c;
+  return 0;
+}
+
+extern "C" int examg_comm_destroy(examg_comm_t *comm) {
+  if (!comm) return 0;
+  int rc = 0;
+  if (comm->nccl) rc = check_nccl(g_rccl.CommDestroy(comm->nccl), "ncclCommDestroy");
+  delete comm;
+  return rc;
+}
+
+extern "C" int examg_comm_rank(const examg_comm_t *comm) { return comm ? comm->rank : -1; }
+extern "C" int examg_comm_size(const examg_comm_t *comm) { return comm ? comm->size : -1; }
+
+// ---- index ranges (iterator coordinates: 0 = lower duplicate node) -----------------------------------------------------------
+namespace {
+
+struct Marks {
+  int GLB, DLB, DLE, IB, IE, DRB, DRE, GRB, GRE;
+};
+Marks marks(const examg_layout_t *l, int d) {
+  Marks m;
+  m.GLB = -l->ghost_l[d];
+  m.DLB = 0;
+  m.DLE = l->dup_l[d];
+  m.IB = m.DLE;
+  m.IE = m.IB + l->inner[d];
+  m.DRB = m.IE;
+  m.DRE = m.DRB + l->dup_r[d];
+  m.GRB = m.DRE;
+  m.GRE = m.GRB + l->ghost_r[d];
+  return m;
+}
+
+struct Range {
+  int32_t b[3], e[3];
+  long long count() const {
+    long long n = 1;
+    for (int d = 0; d < 3; ++d) n *= (e[d] > b[d] ? e[d] - b[d] : 0);
+    return n;
+  }
+};
+
+// duplicate layers along axis d (IR_PackInfoDuplicate.scala:15-39): send DRB..DRE, receive into DLB..DLE, tangentially DLB..DRE
+void dup_ranges(const examg_layout_t *l, int d, Range &snd, Range &rcv) {
+  for (int t = 0; t < 3; ++t) {
+    snd.b[t] = rcv.b[t] = 0;
+    snd.e[t] = rcv.e[t] = 1;
+  }
+  for (int t = 0; t < l->nd; ++t) {
+    const Marks m = marks(l, t);
+    if (t == d) {
+      snd.b[t] = m.DRB; snd.e[t] = m.DRE;
+      rcv.b[t] = m.DLB; rcv.e[t] = m.DLE;
+    } else {
+      snd.b[t] = rcv.b[t] = m.DLB;
+      snd.e[t] = rcv.e[t] = m.DRE;
+    }
+  }
+}
+
+// ghost layers along axis d towards `side` (IR_PackInfoGhost.scala:13-60): send the first / last inner planes, receive into the
+// ghost planes of that side; tangentially GLB..GRE (ghosts of earlier axes travel along)
+void ghost_ranges(const examg_layout_t *l, int d, int side, Range &snd, Range &rcv) {
+  for (int t = 0; t < 3; ++t) {
+    snd.b[t] = rcv.b[t] = 0;
+    snd.e[t] = rcv.e[t] = 1;
+  }
+  for (int t = 0; t < l->nd; ++t) {
+    const Marks m = marks(l, t);
+    if (t == d) {
+      // what goes towards - fills the neighbour's + ghost layers (all blocks share the layout) and vice versa
+      if (side < 0) {
+        snd.b[t] = m.IB; snd.e[t] = m.IB + l->ghost_r[t];
+        rcv.b[t] = m.DLB - l->ghost_l[t]; rcv.e[t] = m.DLB;
+      } else {
+        snd.b[t] = m.IE - l->ghost_l[t]; snd.e[t] = m.IE;
+        rcv.b[t] = m.GRB; rcv.e[t] = m.GRB + l->ghost_r[t];
+      }
+    } else {
+      snd.b[t] = rcv.b[t] = m.GLB;
+      snd.e[t] = rcv.e[t] = m.GRE;
+    }
+  }
+}
+
+long long face_count(const examg_layout_t *l, int d) {   // points of the largest message of axis d (one ghost or duplicate slab)
+  long long n = 1;
+  for (int t = 0; t < l->nd; ++t) {
+    const Marks m = marks(l, t);
+    if (t == d) {
+      int w = l->ghost_l[t] > l->ghost_r[t] ? l->ghost_l[t] : l->ghost_r[t];
+      if (l->dup_r[t] > w) w = l->dup_r[t];
+      n *= w;
+    } else {
+      n *= (m.GRE - m.GLB);
+    }
+  }
+  return n;
+}
+
+// workspace: per axis d and side s (0 = minus, 1 = plus) one send and one receive slab
+long long slot_offset(const examg_layout_t *l, int d, int s, int recv) {
+  long long off = 0;
+  for (int t = 0; t < d; ++t) off += 4 * face_count(l, t);
+  return off + (2 * s + recv) * face_count(l, d);
+}
+
+struct Msg {
+  int peer;
+  Range box;
+  double *buf;
+};
+
+// one phase: pack -> group(recv.., send..) -> unpack  (IR_CommunicateFunction.scala:194-219)
+int phase(examg_comm_t *c, const examg_layout_t *l, double *x, Msg *sends, int ns, Msg *recvs, int nr, hipStream_t s) {
+  if (ns == 0 && nr == 0) return 0;
+  for (int i = 0; i < ns; ++i)
+    if (examg_pack(l, x, sends[i].buf, sends[i].box.b, sends[i].box.e, s)) return 1;
+  bool any_remote = false;
+  for (int i = 0; i < ns; ++i) any_remote = any_remote || sends[i].peer != c->rank || c->self_via_rccl;
+  for (int i = 0; i < nr; ++i) any_remote = any_remote || recvs[i].peer != c->rank || c->self_via_rccl;
+  if (any_remote) {
+    if (!c->nccl) { set_error("examg_exchange: neighbour on another rank but the communicator has no RCCL handle"); return 1; }
+    if (check_nccl(g_rccl.GroupStart(), "ncclGroupStart")) return 1;
+  }
+  // a block that is its own neighbour (periodic dimension with one block): what leaves on one side arrives on the other --
+  // the message sent towards `side` pairs with the receive from `-side`; without RCCL the receive slab is the send slab
+  for (int i = 0; i < nr; ++i) {
+    if (recvs[i].peer == c->rank && !c->self_via_rccl) continue;
+    if (check_nccl(g_rccl.Recv(recvs[i].buf, (size_t)recvs[i].box.count(), ncclDouble, recvs[i].peer, c->nccl, s), "ncclRecv")) return 1;
+  }
+  for (int i = 0; i < ns; ++i) {
+    if (sends[i].peer == c->rank && !c->self_via_rccl) continue;
+    if (check_nccl(g_rccl.Send(sends[i].buf, (size_t)sends[i].box.count(), ncclDouble, sends[i].peer, c->nccl, s), "ncclSend")) return 1;
+  }
+  if (any_remote && check_nccl(g_rccl.GroupEnd(), "ncclGroupEnd")) return 1;
+  for (int i = 0; i < nr; ++i) {
+    const double *src = recvs[i].buf;
+    if (recvs[i].peer == c->rank && !c->self_via_rccl) {
+      // pairing by position: sends are listed towards (-, +), receives from (+, -) -- what went out towards - is what
+      // comes in from + (see examg_exchange); a block is its own neighbour on both sides of an axis or on neither
+      if (ns != nr) { set_error("examg_exchange: a self-neighbour needs both sides of the axis"); return 1; }
+      src = sends[i].buf;
+    }
+    if (examg_unpack(l, x, src, recvs[i].box.b, recvs[i].box.e, s)) return 1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t examg_exchange_workspace_bytes(const examg_layout_t *l) {
+  if (!l) return 0;
+  long long n = 0;
+  for (int d = 0; d < l->nd; ++d) n += 4 * face_count(l, d);
+  return (size_t)n * sizeof(double);
+}
+
+extern "C" int examg_exchange(examg_comm_t *comm, const examg_layout_t *l, double *x, const examg_neighbors_t *nb, int what,
+                              void *workspace, size_t workspace_bytes, examg_stream_t stream) {
+  if (!comm || !l || !x || !nb) { set_error("examg_exchange: null argument"); return 1; }
+  if (!(what & (EXAMG_EXCH_DUP | EXAMG_EXCH_GHOST))) return 0;
+  bool any = false;
+  for (int d = 0; d < l->nd; ++d) any = any || nb->rank[d][0] >= 0 || nb->rank[d][1] >= 0;
+  if (!any) return 0;   // no neighbours: the generated exch function is empty
+  if (!workspace || workspace_bytes < examg_exchange_workspace_bytes(l)) { set_error("examg_exchange: workspace too small"); return 1; }
+  for (int d = 0; d < l->nd; ++d)
+    for (int s = 0; s < 2; ++s)
+      if (nb->rank[d][s] >= comm->size) { set_error("examg_exchange: neighbour rank %d outside the communicator", nb->rank[d][s]); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  double *ws = (double *)workspace;
+  const int nd = l->nd;
+  if (what & EXAMG_EXCH_DUP) {
+    for (int d = 0; d < nd; ++d) {
+      if (l->dup_l[d] == 0 && l->dup_r[d] == 0) continue;
+      Msg snd[1], rcv[1];
+      int ns = 0, nr = 0;
+      Range sb, rb;
+      dup_ranges(l, d, sb, rb);
+      if (nb->rank[d][1] >= 0) snd[ns++] = Msg{nb->rank[d][1], sb, ws + slot_offset(l, d, 1, 0)};
+      if (nb->rank[d][0] >= 0) rcv[nr++] = Msg{nb->rank[d][0], rb, ws + slot_offset(l, d, 0, 1)};
+      if (phase(comm, l, x, snd, ns, rcv, nr, s)) return 1;
+    }
+  }
+  if (what & EXAMG_EXCH_GHOST) {
+    Msg snd[6], rcv[6];
+    int ns = 0, nr = 0;
+    for (int d = 0; d < nd; ++d) {
+      if (l->ghost_l[d] == 0 && l->ghost_r[d] == 0) continue;
+      // sends towards minus, then plus; receives from plus, then minus: when both neighbours of an axis are the same rank
+      // (two blocks, periodic) the first message sent (towards -) is the first one the peer expects (from its +)
+      const int d_ns = ns, d_nr = nr;
+      for (int side = 0; side < 2; ++side) {
+        if (nb->rank[d][side] < 0) continue;
+        Range sb, rb;
+        ghost_ranges(l, d, side ? +1 : -1, sb, rb);
+        snd[ns++] = Msg{nb->rank[d][side], sb, ws + slot_offset(l, d, side, 0)};
+      }
+      for (int side = 1; side >= 0; --side) {
+        if (nb->rank[d][side] < 0) continue;
+        Range sb, rb;
+        ghost_ranges(l, d, side ? +1 : -1, sb, rb);
+        rcv[nr++] = Msg{nb->rank[d][side], rb, ws + slot_offset(l, d, side, 1)};
+      }
+      if (!(what & EXAMG_EXCH_CONCURRENT_AXES)) {
+        if (phase(comm, l, x, snd + d_ns, ns - d_ns, rcv + d_nr, nr - d_nr, s)) return 1;
+        ns = d_ns;
+        nr = d_nr;
+      }
+    }
+    if (what & EXAMG_EXCH_CONCURRENT_AXES) {
+      // face ghosts only (5/7-point loops): all axes in one group; per axis the receive order still mirrors the send order.
+      // phase() pairs self-messages by position within an axis, so the axes go through it one at a time when a block is its
+      // own neighbour, and as ONE group otherwise
+      bool self = false;
+      for (int i = 0; i < ns; ++i) self = self || snd[i].peer == comm->rank;
+      if (!self) {
+        if (phase(comm, l, x, snd, ns, rcv, nr, s)) return 1;
+      } else {
+        int is = 0, ir = 0;
+        for (int d = 0; d < nd; ++d) {
+          int cs = 0, cr = 0;
+          for (int side = 0; side < 2; ++side)
+            if (nb->rank[d][side] >= 0 && (l->ghost_l[d] || l->ghost_r[d])) { ++cs; ++cr; }
+          if (phase(comm, l, x, snd + is, cs, rcv + ir, cr, s)) return 1;
+          is += cs;
+          ir += cr;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+extern "C" int examg_allreduce(examg_comm_t *comm, double *x, int n, int op, examg_stream_t stream) {
+  if (!comm || !x || n < 0) { set_error("examg_allreduce: bad argument"); return 1; }
+  if (op < 0 || op > 2) { set_error("examg_allreduce: op must be 0 (sum), 1 (max) or 2 (min)"); return 1; }
+  if (comm->size == 1 && !comm->self_via_rccl) return 0;
+  if (!comm->nccl) { set_error("examg_allreduce: communicator has no RCCL handle"); return 1; }
+  const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
+  return check_nccl(g_rccl.AllReduce(x, x, (size_t)n, ncclDouble, rop, comm->nccl, (hipStream_t)stream), "ncclAllReduce");
+}
+
+extern "C" int examg_allgather(examg_comm_t *comm, const double *send, double *recv, int64_t n, examg_stream_t stream) {
+  if (!comm || !send || !recv || n < 0) { set_error("examg_allgather: bad argument"); return 1; }
+  if (comm->size == 1 && !comm->self_via_rccl) {
+    if (send != recv) return check_hip(hipMemcpyAsync(recv, send, (size_t)n * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream), "examg_allgather");
+    return 0;
+  }
+  if (!comm->nccl) { set_error("examg_allgather: communicator has no RCCL handle"); return 1; }
+  return check_nccl(g_rccl.AllGather(send, recv, (size_t)n, ncclDouble, comm->nccl, (hipStream_t)stream), "ncclAllGather");
+}

@@ -72,7 +72,17 @@ SYMBOLS = [
     "examg_set", "examg_axpby", "examg_axpby_dev", "examg_reduce_work_bytes", "examg_dot", "examg_max_err_fn",
     "examg_fill_fn", "examg_apply_dirichlet", "examg_fill_expr", "examg_apply_dirichlet_expr", "examg_max_err_expr", "examg_init_varcoeff7", "examg_init_helmholtz27", "examg_pack", "examg_unpack",
     "examg_cg_coarse", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
+    "examg_comm_unique_id", "examg_comm_create", "examg_comm_destroy", "examg_comm_rank", "examg_comm_size",
+    "examg_exchange_workspace_bytes", "examg_exchange", "examg_allreduce", "examg_allgather",
 ]
+
+COMM_ID_BYTES = 128
+EXCH_DUP, EXCH_GHOST, EXCH_ALL, EXCH_CONCURRENT_AXES = 1, 2, 3, 4
+
+
+class NeighborsC(C.Structure):
+    """examg_neighbors_t"""
+    _fields_ = [("rank", (C.c_int32 * 2) * 3)]
 
 
 def load(path=None):
@@ -126,9 +136,19 @@ def load(path=None):
     L.examg_copy_to_external.argtypes = [lp, vp, lp, vp, vp]
     L.examg_copy_from_external.argtypes = [lp, vp, lp, vp, vp]
     L.examg_fill_random.argtypes = [vp, C.c_int64, C.c_uint64, vp]
+    L.examg_comm_unique_id.argtypes = [vp]
+    L.examg_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int]
+    L.examg_comm_destroy.argtypes = [vp]
+    L.examg_comm_rank.argtypes = [vp]
+    L.examg_comm_size.argtypes = [vp]
+    L.examg_exchange_workspace_bytes.argtypes = [lp]
+    L.examg_exchange_workspace_bytes.restype = C.c_size_t
+    L.examg_exchange.argtypes = [vp, lp, vp, C.POINTER(NeighborsC), C.c_int, vp, C.c_size_t, vp]
+    L.examg_allreduce.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.examg_allgather.argtypes = [vp, vp, vp, C.c_int64, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
-        if name not in ("examg_version", "examg_last_error", "examg_device_count", "examg_reduce_work_bytes"):
+        if name not in ("examg_version", "examg_last_error", "examg_device_count", "examg_reduce_work_bytes", "examg_exchange_workspace_bytes"):
             fn.restype = C.c_int
     if hasattr(L, "examg_debug_force_generic"):      # debug build only
         L.examg_debug_force_generic.argtypes = [C.c_int]

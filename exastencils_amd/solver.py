@@ -171,7 +171,8 @@ class SolverFromL4(_Program):
                 n_own *= nc[d] + 1
                 n_halo *= nc[d] + 3
             self._agg_send = ops.new_array(n_own)
-            self._agg_recv = [ops.new_array(n_own) for _ in range(dom.world_size)]
+            self._agg_recv_all = ops.new_array(n_own * dom.world_size)     # one array: consecutive pieces, one per rank
+            self._agg_recv = [self._agg_recv_all[r * n_own:(r + 1) * n_own] for r in range(dom.world_size)]
             self._agg_back = ops.new_array(n_halo)
 
     def _agg_cycle(self, k: int):

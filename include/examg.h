@@ -283,6 +283,43 @@ int examg_copy_to_external(const examg_layout_t *l_int, const double *x_int, con
 int examg_copy_from_external(const examg_layout_t *l_ext, const double *src, const examg_layout_t *l_int, double *x_int,
                              examg_stream_t stream);
 
+/* ---- a-13 / e: block-to-block transport over RCCL (one process per GPU) -----------------------------------------------
+ * What the generated host calls `exch<Field>_<level>(slot)` (communication/ir/IR_CommunicateFunction.scala:194-219,412-480,
+ * naming IR_SetupCommunication.scala:119-147) and the MPI_Allreduce after a reduction loop
+ * (parallelization/api/mpi/MPI_Reduction.scala:100-126).  The communicator stands where MPI_COMM_WORLD does; it is created
+ * from a 128-byte id that rank 0 obtains and the host distributes by its own means (MPI_Bcast in a generated program, a
+ * file, torch.distributed).  All calls are asynchronous on `stream` (ncclSend / ncclRecv groups, pack / unpack kernels) and
+ * capturable into a hipGraph.  A communicator of one rank needs no RCCL (id may be NULL). */
+typedef struct examg_comm examg_comm_t;
+#define EXAMG_COMM_ID_BYTES 128
+int examg_comm_unique_id(void *id /* EXAMG_COMM_ID_BYTES */);
+int examg_comm_create(examg_comm_t **comm, const void *id, int nranks, int rank);   /* collective; binds the current HIP device */
+int examg_comm_destroy(examg_comm_t *comm);
+int examg_comm_rank(const examg_comm_t *comm);
+int examg_comm_size(const examg_comm_t *comm);
+
+/* Ranks of the axis neighbours of this block, rank[d][0] across the lower and rank[d][1] across the upper face of dimension d;
+ * -1 = physical boundary (IR_IV_NeighborIsValid false, domain/ir/IR_ConnectFragments.scala:110-151); the own rank = periodic
+ * dimension with one block. */
+typedef struct examg_neighbors {
+  int32_t rank[3][2];
+} examg_neighbors_t;
+
+/* what: EXAMG_EXCH_DUP  duplicate layers, upstream (own upper plane -> '+' neighbour's lower plane), axis by axis;
+ *       EXAMG_EXCH_GHOST ghost layers both ways, axis by axis with tangential extent GLB..GRE (corner ghosts become valid);
+ *       | EXAMG_EXCH_CONCURRENT_AXES: ghost layers of all axes as ONE send/recv group -- face ghosts only, for loops that read
+ *       nothing else (5/7-point stencils).  Which parts a field communicates is the layout declaration's business
+ *       (`ghostLayers = [..] with communication`): the caller passes `what` accordingly. */
+enum { EXAMG_EXCH_DUP = 1, EXAMG_EXCH_GHOST = 2, EXAMG_EXCH_ALL = 3, EXAMG_EXCH_CONCURRENT_AXES = 4 };
+/* caller-owned device scratch for the packed slabs (the generated program's buffer_Send / buffer_Recv arrays) */
+size_t examg_exchange_workspace_bytes(const examg_layout_t *l);
+int examg_exchange(examg_comm_t *comm, const examg_layout_t *l, double *x, const examg_neighbors_t *nb, int what,
+                   void *workspace, size_t workspace_bytes, examg_stream_t stream);
+/* MPI_Allreduce(MPI_IN_PLACE, x, n, MPI_DOUBLE, op): x is device memory; op 0 = sum, 1 = max, 2 = min */
+int examg_allreduce(examg_comm_t *comm, double *x, int n, int op, examg_stream_t stream);
+/* every rank's n doubles, in rank order (coarse-level agglomeration: fewer, larger collectives over xGMI) */
+int examg_allgather(examg_comm_t *comm, const double *send, double *recv, int64_t n, examg_stream_t stream);
+
 /* Deterministic synthetic field (SplitMix64 of the linear index, U(-1,1)); same bits as the oracle's. */
 int examg_fill_random(double *x, int64_t n, uint64_t seed, examg_stream_t stream);
 

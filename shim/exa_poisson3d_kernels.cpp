@@ -1,0 +1,276 @@
+// libexamg bodies for the reference-named kernel wrappers, exchange and boundary functions of
+// Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4 (names and numbering: exa_poisson3d.h).  This file stands where the generator
+// prints Kernel/Kernel_<fn>_k<NNN>.cu (cuda/CUDA_KernelFunctions.scala:100-110) and the communication / boundary functions
+// (IR_CommunicateFunction.scala, IR_ApplyBCFunction.scala); the global arrays, layouts and loop bounds are the generator's.
+// Errors print and exit, as the reference's CUDA_CheckError does (cuda/CUDA_Error.scala); every wrapper returns void.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "exa_poisson3d.h"
+
+extern "C" {
+double *fieldDeviceData_Solution[EXA_NUM_LEVELS];
+double *fieldDeviceData_RHS[EXA_NUM_LEVELS];
+double *fieldDeviceData_Residual[EXA_NUM_LEVELS];
+double *fieldDeviceData_cgTmp0[1];
+double *fieldDeviceData_cgTmp1[1];
+}
+
+namespace {
+
+void check(int rc, const char *what) {
+  if (rc) { std::fprintf(stderr, "%s: %s\n", what, examg_last_error()); std::exit(1); }
+}
+void checkHip(hipError_t e, const char *what) {
+  if (e != hipSuccess) { std::fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); std::exit(1); }
+}
+
+struct LevelInfo {
+  examg_layout_t withComm, noGhost;   // Layout NodeWithComm / NodeNoGhost (...exa4:13-21)
+  const examg_layout_t *resLayout;    // Field Residual: NodeNoGhost on the coarsest level, NodeWithComm elsewhere (:29-30)
+  examg_stencil_t Laplace;            // Stencil Laplace@all (:39-47), coefficients folded as the generator folds them
+  examg_geom_t geom;
+  int32_t begin[3], end[3];           // loop over <node field>: [DLB + iterationOffsetBegin, DRE + iterationOffsetEnd)
+  int32_t rbegin[3];                  // reduction loops skip the lower duplicate plane at interior faces
+  void *wsWith, *wsNo;                // buffer_Send / buffer_Recv of the exchange functions
+  size_t wsWithBytes, wsNoBytes;
+};
+LevelInfo g_lv[EXA_NUM_LEVELS];
+int g_blocks[3] = {1, 1, 1}, g_pos[3] = {0, 0, 0}, g_rank = 0, g_size = 1;
+examg_comm_t *g_comm = nullptr;
+examg_neighbors_t g_nb;
+uint32_t g_faceMask = 63u;
+double *g_scalar = nullptr, *g_work = nullptr;
+examg_expr_t g_bcSolution, g_bcZero;   // Field Solution's boundary expression at the finest level (:24): x^2 - 0.5 y^2 - 0.5 z^2
+
+LevelInfo &lv(int level) { return g_lv[level - EXA_MIN_LEVEL]; }
+
+examg_layout_t nodeLayout(int level, int ghost) {
+  examg_layout_t l;
+  std::memset(&l, 0, sizeof(l));
+  l.nd = 3;
+  for (int d = 0; d < 3; ++d) {
+    l.ghost_l[d] = l.ghost_r[d] = ghost;
+    l.dup_l[d] = l.dup_r[d] = 1;
+    l.inner[d] = (1 << level) - 1;
+  }
+  return l;
+}
+size_t layoutSize(const examg_layout_t &l) {
+  size_t n = 1;
+  for (int d = 0; d < 3; ++d) n *= l.pad_l[d] + l.ghost_l[d] + l.dup_l[d] + l.inner[d] + l.dup_r[d] + l.ghost_r[d] + l.pad_r[d];
+  return n;
+}
+double *deviceZeros(size_t n) {
+  double *p;
+  checkHip(hipMalloc(&p, n * sizeof(double)), "hipMalloc");
+  checkHip(hipMemset(p, 0, n * sizeof(double)), "hipMemset");   // initFieldsWithZero
+  return p;
+}
+
+void smoothColour(int level, int colour, const char *what) {   // Solution += 0.8 / diag(Laplace) * (RHS - Laplace * Solution), one colour
+  LevelInfo &v = lv(level);
+  const double w = 0.8 / v.Laplace.coef[v.Laplace.diag];
+  check(examg_rbgs_colour(&v.withComm, fieldDeviceData_Solution[level - EXA_MIN_LEVEL], &v.noGhost, fieldDeviceData_RHS[level - EXA_MIN_LEVEL],
+                          &v.Laplace, w, colour, v.begin, v.end, nullptr), what);
+}
+void residual(int level, const char *what) {
+  LevelInfo &v = lv(level);
+  const int i = level - EXA_MIN_LEVEL;
+  check(examg_residual(&v.withComm, fieldDeviceData_Solution[i], &v.noGhost, fieldDeviceData_RHS[i], v.resLayout, fieldDeviceData_Residual[i],
+                       &v.Laplace, v.begin, v.end, nullptr), what);
+}
+void reduceDot(const examg_layout_t *lx, const double *x, const examg_layout_t *ly, const double *y, int level, double *reductionTmp,
+               const char *what) {
+  // kernel + DefaultReductionKernel + the blocking copy of the result (cuda/CUDA_Kernel.scala:595-616); the host code adds the
+  // MPI_Allreduce itself (exa_allreduce_sum)
+  LevelInfo &v = lv(level);
+  check(examg_dot(lx, x, ly, y, v.rbegin, v.end, g_scalar, g_work, nullptr), what);
+  checkHip(hipMemcpy(reductionTmp, g_scalar, sizeof(double), hipMemcpyDeviceToHost), what);
+}
+void exchange(const examg_layout_t *l, double *x, void *ws, size_t wsBytes, int what, const char *name) {
+  if (g_size == 1) return;   // no neighbours: the generated function is empty
+  check(examg_exchange(g_comm, l, x, &g_nb, what, ws, wsBytes, nullptr), name);
+}
+void applyBC(const examg_layout_t *l, double *x, int level, const examg_expr_t *e, const char *name) {
+  if (g_faceMask) check(examg_apply_dirichlet_expr(l, x, &lv(level).geom, e, g_faceMask, nullptr), name);
+}
+
+}  // namespace
+
+extern "C" {
+
+void initGlobals(const int numBlocks[3], int mpiRank, const void *commId) {
+  g_size = numBlocks[0] * numBlocks[1] * numBlocks[2];
+  g_rank = mpiRank;
+  for (int d = 0; d < 3; ++d) g_blocks[d] = numBlocks[d];
+  g_pos[0] = mpiRank % numBlocks[0];                       // domain/ir/IR_ConnectFragments.scala:46-52: x fastest
+  g_pos[1] = (mpiRank / numBlocks[0]) % numBlocks[1];
+  g_pos[2] = mpiRank / (numBlocks[0] * numBlocks[1]);
+  g_faceMask = 0;
+  for (int d = 0; d < 3; ++d) {
+    int q[3] = {g_pos[0], g_pos[1], g_pos[2]};
+    for (int s = 0; s < 2; ++s) {
+      q[d] = g_pos[d] + (s ? 1 : -1);
+      const bool valid = q[d] >= 0 && q[d] < numBlocks[d];  // neighbor_isValid
+      g_nb.rank[d][s] = valid ? q[0] + numBlocks[0] * (q[1] + numBlocks[1] * q[2]) : -1;
+      if (!valid) g_faceMask |= 1u << (2 * d + s);
+      q[d] = g_pos[d];
+    }
+  }
+  check(examg_comm_create(&g_comm, commId, g_size, mpiRank), "examg_comm_create");
+  // boundary expressions as postfix programs (the generator inlines them into the boundary kernels)
+  std::memset(&g_bcSolution, 0, sizeof(g_bcSolution));
+  std::memset(&g_bcZero, 0, sizeof(g_bcZero));
+  // ( ( vf_boundaryCoord_x ** 2 ) - ( 0.5 * ( vf_boundaryCoord_y ** 2 ) ) ) - ( 0.5 * ( vf_boundaryCoord_z ** 2 ) ), folded: x*x - 0.5*y*y - 0.5*z*z
+  const int ops[] = {EXAMG_OP_X, EXAMG_OP_X, EXAMG_OP_MUL, EXAMG_OP_CONST, EXAMG_OP_Y, EXAMG_OP_MUL, EXAMG_OP_Y, EXAMG_OP_MUL, EXAMG_OP_SUB,
+                     EXAMG_OP_CONST, EXAMG_OP_Z, EXAMG_OP_MUL, EXAMG_OP_Z, EXAMG_OP_MUL, EXAMG_OP_SUB};
+  g_bcSolution.n = (int)(sizeof(ops) / sizeof(ops[0]));
+  for (int i = 0; i < g_bcSolution.n; ++i) {
+    g_bcSolution.op[i] = ops[i];
+    g_bcSolution.c[i] = ops[i] == EXAMG_OP_CONST ? 0.5 : 0.0;
+  }
+  g_bcZero.n = 1;
+  g_bcZero.op[0] = EXAMG_OP_CONST;
+  g_bcZero.c[0] = 0.0;
+}
+
+void setupBuffers(void) {
+  for (int level = EXA_MIN_LEVEL; level <= EXA_MAX_LEVEL; ++level) {
+    LevelInfo &v = lv(level);
+    const int i = level - EXA_MIN_LEVEL;
+    v.withComm = nodeLayout(level, 1);
+    v.noGhost = nodeLayout(level, 0);
+    v.resLayout = (level == EXA_MIN_LEVEL) ? &v.noGhost : &v.withComm;
+    fieldDeviceData_Solution[i] = deviceZeros(layoutSize(v.withComm));
+    fieldDeviceData_RHS[i] = deviceZeros(layoutSize(v.noGhost));
+    fieldDeviceData_Residual[i] = deviceZeros(layoutSize(*v.resLayout));
+    for (int d = 0; d < 3; ++d) {
+      const double width = 1.0 / g_blocks[d];                                   // unit cube, equal blocks
+      v.geom.h[d] = width / (1 << level);                                       // domain/ir/IR_DomainFromAABB.scala:31-40
+      v.geom.pos_begin[d] = g_pos[d] * width;
+      v.begin[d] = 0 + (g_nb.rank[d][0] < 0 ? 1 : 0);                           // iterationOffsetBegin
+      v.end[d] = (1 << level) + 1 + (g_nb.rank[d][1] < 0 ? -1 : 0);             // iterationOffsetEnd
+      v.rbegin[d] = v.begin[d] > 1 ? v.begin[d] : 1;
+    }
+    examg_stencil_t &A = v.Laplace;
+    std::memset(&A, 0, sizeof(A));
+    A.nent = 7;
+    A.diag = 0;
+    const int off[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+    for (int k = 0; k < 7; ++k) for (int d = 0; d < 3; ++d) A.off[k][d] = off[k][d];
+    // 2.0 / ( vf_gridWidth_x ** 2 ) + 2.0 / ( vf_gridWidth_y ** 2 ) + 2.0 / ( vf_gridWidth_z ** 2 ) ; -1.0 / ( vf_gridWidth_d ** 2 )
+    A.coef[0] = 2.0 / std::pow(v.geom.h[0], 2) + 2.0 / std::pow(v.geom.h[1], 2) + 2.0 / std::pow(v.geom.h[2], 2);
+    for (int k = 1; k < 7; ++k) A.coef[k] = -1.0 / std::pow(v.geom.h[(k - 1) / 2], 2);
+    v.wsWithBytes = examg_exchange_workspace_bytes(&v.withComm);
+    v.wsNoBytes = examg_exchange_workspace_bytes(&v.noGhost);
+    v.wsWith = deviceZeros(v.wsWithBytes / 8 + 1);
+    v.wsNo = deviceZeros(v.wsNoBytes / 8 + 1);
+  }
+  fieldDeviceData_cgTmp0[0] = deviceZeros(layoutSize(lv(EXA_MIN_LEVEL).withComm));
+  fieldDeviceData_cgTmp1[0] = deviceZeros(layoutSize(lv(EXA_MIN_LEVEL).noGhost));
+  g_scalar = deviceZeros(1);
+  checkHip(hipMalloc(&g_work, examg_reduce_work_bytes()), "hipMalloc");
+}
+
+void destroyGlobals(void) {
+  checkHip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  for (int i = 0; i < EXA_NUM_LEVELS; ++i) {
+    (void)hipFree(fieldDeviceData_Solution[i]);
+    (void)hipFree(fieldDeviceData_RHS[i]);
+    (void)hipFree(fieldDeviceData_Residual[i]);
+    (void)hipFree(g_lv[i].wsWith);
+    (void)hipFree(g_lv[i].wsNo);
+  }
+  (void)hipFree(fieldDeviceData_cgTmp0[0]);
+  (void)hipFree(fieldDeviceData_cgTmp1[0]);
+  (void)hipFree(g_scalar);
+  (void)hipFree(g_work);
+  check(examg_comm_destroy(g_comm), "examg_comm_destroy");
+}
+
+void exa_allreduce_sum(double *x) {
+  if (g_size == 1) return;
+  checkHip(hipMemcpy(g_scalar, x, sizeof(double), hipMemcpyHostToDevice), "exa_allreduce_sum");
+  check(examg_allreduce(g_comm, g_scalar, 1, 0, nullptr), "examg_allreduce");
+  checkHip(hipMemcpy(x, g_scalar, sizeof(double), hipMemcpyDeviceToHost), "exa_allreduce_sum");
+}
+
+#define EXA_I(L) ((L) - EXA_MIN_LEVEL)
+
+#define EXA_KERNELS_COMMON(L)                                                                                                        \
+  void EXA_CAT3(exchSolution_, L, )(int) { exchange(&lv(L).withComm, fieldDeviceData_Solution[EXA_I(L)], lv(L).wsWith, lv(L).wsWithBytes, EXAMG_EXCH_ALL, "exchSolution"); } \
+  void EXA_CAT3(exchResidual_, L, )(int) {                                                                                           \
+    const bool g = lv(L).resLayout == &lv(L).withComm;                                                                               \
+    exchange(lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], g ? lv(L).wsWith : lv(L).wsNo, g ? lv(L).wsWithBytes : lv(L).wsNoBytes, \
+             g ? EXAMG_EXCH_ALL : EXAMG_EXCH_DUP, "exchResidual");                                                                   \
+  }                                                                                                                                  \
+  void EXA_CAT3(applyBCsSolution_, L, )(int) {                                                                                       \
+    applyBC(&lv(L).withComm, fieldDeviceData_Solution[EXA_I(L)], L, (L) == EXA_MAX_LEVEL ? &g_bcSolution : &g_bcZero, "applyBCsSolution"); \
+  }                                                                                                                                  \
+  void EXA_CAT3(applyBCsResidual_, L, )(int) { applyBC(lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], L, &g_bcZero, "applyBCsResidual"); } \
+  void EXA_CAT3(ResNorm_, L, _k000_wrapper)(double *reductionTmp) {                                                                  \
+    reduceDot(lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], L, reductionTmp, "ResNorm_k000"); \
+  }
+
+#define EXA_KERNELS_FINE(L, LM1)                                                                                                     \
+  void EXA_CAT3(mgCycle_, L, _k000_wrapper)(void) { smoothColour(L, 0, "mgCycle_k000"); }                                            \
+  void EXA_CAT3(mgCycle_, L, _k001_wrapper)(void) { smoothColour(L, 1, "mgCycle_k001"); }                                            \
+  void EXA_CAT3(mgCycle_, L, _k002_wrapper)(void) { residual(L, "mgCycle_k002"); }                                                   \
+  void EXA_CAT3(mgCycle_, L, _k003_wrapper)(void) {                                                                                  \
+    check(examg_restrict(lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], &lv(LM1).noGhost, fieldDeviceData_RHS[EXA_I(LM1)], 1.0, \
+                         lv(LM1).begin, lv(LM1).end, nullptr), "mgCycle_k003");                                                      \
+  }                                                                                                                                  \
+  void EXA_CAT3(mgCycle_, L, _k004_wrapper)(void) {                                                                                  \
+    check(examg_set(&lv(LM1).withComm, fieldDeviceData_Solution[EXA_I(LM1)], 0.0, lv(LM1).begin, lv(LM1).end, nullptr), "mgCycle_k004"); \
+  }                                                                                                                                  \
+  void EXA_CAT3(mgCycle_, L, _k005_wrapper)(void) {                                                                                  \
+    check(examg_prolong_add(&lv(LM1).withComm, fieldDeviceData_Solution[EXA_I(LM1)], &lv(L).withComm, fieldDeviceData_Solution[EXA_I(L)], \
+                            lv(L).begin, lv(L).end, nullptr), "mgCycle_k005");                                                       \
+  }                                                                                                                                  \
+  void EXA_CAT3(mgCycle_, L, _k006_wrapper)(void) { smoothColour(L, 0, "mgCycle_k006"); }                                            \
+  void EXA_CAT3(mgCycle_, L, _k007_wrapper)(void) { smoothColour(L, 1, "mgCycle_k007"); }
+
+#define EXA_KERNELS_COARSEST(L)                                                                                                      \
+  void EXA_CAT3(exchcgTmp0_, L, )(int) { exchange(&lv(L).withComm, fieldDeviceData_cgTmp0[0], lv(L).wsWith, lv(L).wsWithBytes, EXAMG_EXCH_ALL, "exchcgTmp0"); } \
+  void EXA_CAT3(applyBCscgTmp0_, L, )(int) { applyBC(&lv(L).withComm, fieldDeviceData_cgTmp0[0], L, &g_bcZero, "applyBCscgTmp0"); }  \
+  void EXA_CAT3(mgCycle_, L, _k000_wrapper)(void) { residual(L, "mgCycle_k000"); }                                                   \
+  void EXA_CAT3(mgCycle_, L, _k001_wrapper)(void) {                                                                                  \
+    check(examg_axpby(lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], &lv(L).withComm, fieldDeviceData_cgTmp0[0], 1.0, 0.0, lv(L).begin, \
+                      lv(L).end, nullptr), "mgCycle_k001");                                                                          \
+  }                                                                                                                                  \
+  void EXA_CAT3(mgCycle_, L, _k002_wrapper)(void) {                                                                                  \
+    check(examg_stencil_op(EXAMG_APPLY, &lv(L).withComm, fieldDeviceData_cgTmp0[0], nullptr, nullptr, &lv(L).noGhost, fieldDeviceData_cgTmp1[0], \
+                           &lv(L).Laplace, 0.0, -1, lv(L).begin, lv(L).end, nullptr), "mgCycle_k002");                                \
+  }                                                                                                                                  \
+  void EXA_CAT3(mgCycle_, L, _k003_wrapper)(double *reductionTmp) {                                                                  \
+    reduceDot(lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], L, reductionTmp, "mgCycle_k003"); \
+  }                                                                                                                                  \
+  void EXA_CAT3(mgCycle_, L, _k004_wrapper)(double *reductionTmp) {                                                                  \
+    reduceDot(&lv(L).withComm, fieldDeviceData_cgTmp0[0], &lv(L).noGhost, fieldDeviceData_cgTmp1[0], L, reductionTmp, "mgCycle_k004"); \
+  }                                                                                                                                  \
+  void EXA_CAT3(mgCycle_, L, _k005_wrapper)(double alpha) {                                                                          \
+    check(examg_axpby(&lv(L).withComm, fieldDeviceData_cgTmp0[0], &lv(L).withComm, fieldDeviceData_Solution[EXA_I(L)], alpha, 1.0, lv(L).begin, \
+                      lv(L).end, nullptr), "mgCycle_k005");                                                                          \
+  }                                                                                                                                  \
+  void EXA_CAT3(mgCycle_, L, _k006_wrapper)(double alpha) {                                                                          \
+    check(examg_axpby(&lv(L).noGhost, fieldDeviceData_cgTmp1[0], lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], -alpha, 1.0, lv(L).begin, \
+                      lv(L).end, nullptr), "mgCycle_k006");                                                                          \
+  }                                                                                                                                  \
+  void EXA_CAT3(mgCycle_, L, _k007_wrapper)(double beta) {                                                                           \
+    check(examg_axpby(lv(L).resLayout, fieldDeviceData_Residual[EXA_I(L)], &lv(L).withComm, fieldDeviceData_cgTmp0[0], 1.0, beta, lv(L).begin, \
+                      lv(L).end, nullptr), "mgCycle_k007");                                                                          \
+  }
+
+#define EXA_LEVEL_KERNELS
+#include "exa_levels.inc"
+#undef EXA_LEVEL_KERNELS
+
+void EXA_CAT3(Solve_, EXA_MAX_LEVEL, _k000_wrapper)(void) { residual(EXA_MAX_LEVEL, "Solve_k000"); }
+void EXA_CAT3(Solve_, EXA_MAX_LEVEL, _k001_wrapper)(void) { residual(EXA_MAX_LEVEL, "Solve_k001"); }
+
+}  // extern "C"

@@ -85,3 +85,22 @@ def test_hipops_refuses_to_run_without_gpu():
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("HipOps() must raise without a GPU")
+
+
+def test_shim_host_references_only_reference_names():
+    """shim/exa_poisson3d_host.cpp -- the generated-style host -- must bind nothing of libexamg but the communicator bootstrap
+    of main(): every loop goes through <fn>_<L>_k<NNN>_wrapper / exch<Field>_<L> / applyBCs<Field>_<L> names."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        obj = os.path.join(td, "host.o")
+        subprocess.run(["g++", "-c", "-x", "c++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "shim"), "-DEXA_MIN_LEVEL=2", "-DEXA_MAX_LEVEL=6",
+                        os.path.join(ROOT, "shim", "exa_poisson3d_host.cpp"), "-o", obj], check=True, capture_output=True)
+        und = subprocess.run(["nm", "-u", obj], capture_output=True, text=True, check=True).stdout.split()
+    lib_syms = sorted(s for s in und if s.startswith("examg_"))
+    assert set(lib_syms) <= {"examg_comm_unique_id", "examg_last_error", "examg_device_count"}, lib_syms
+    wrappers = [s for s in und if s.endswith("_wrapper")]
+    assert any(s.startswith("mgCycle_6_k00") for s in wrappers) and any(s.startswith("ResNorm_") for s in wrappers)
+    assert any(s.startswith("exchSolution_") for s in und) and any(s.startswith("applyBCsSolution_") for s in und)

@@ -1,0 +1,107 @@
+"""libexamg's C transport (examg_exchange / examg_allreduce / examg_allgather, exastencils_amd/csrc/examg_comm.hip) on ONE
+GPU: a block with periodic directions is its own neighbour, so the whole `communicate` path -- index ranges, pack, message
+pairing, unpack, for duplicate and ghost layers, axis by axis and as one group -- runs for real and is compared bit for bit
+with the torch.distributed-style path (pack / unpack through the kernel layer, the form the gloo tests pin against the oracle
+on several ranks).  With EXAMG_COMM_SELF_RCCL=1 the self-messages travel through ncclSend / ncclRecv of RCCL (a one-rank
+communicator): first contact of the RCCL code path on hardware.  The >= 2-GPU form is tests/test_gpu_multi.py (skipped on a
+one-GPU box)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from exastencils_amd.comm import Communicator
+from exastencils_amd.domain import RectDomain
+from exastencils_amd.field import Field
+from exastencils_amd.layout import FieldLayout
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from exastencils_amd.ops import HipOps
+
+    return HipOps(0)
+
+
+def _run(hip, transport, periodic, what, concurrent, ghost=1, nc=(24, 20, 16)):
+    dom = RectDomain(3, (1, 1, 1), 0, (1, 1, 1), periodic=periodic)
+    comm = Communicator(dom, hip, concurrent_ghost_axes=concurrent, transport=transport)
+    f = Field("U", 0, FieldLayout.node(3, nc, ghost), hip, 1, None)
+    hip.fill_random(f.data(), 4242)
+    comm.exchange(f, None, what, axis_only=concurrent)
+    hip.synchronize()
+    out = hip.to_host(f.data()).copy()
+    comm.close()
+    return out
+
+
+@pytest.mark.parametrize("rccl", [False, True], ids=["direct", "rccl-to-self"])
+@pytest.mark.parametrize("periodic", [(True, True, True), (False, True, False), (True, False, True)])
+@pytest.mark.parametrize("what,concurrent", [("all", False), ("ghost", False), ("ghost", True), ("dup", False)])
+def test_c_exchange_equals_python_exchange(hip, monkeypatch, rccl, periodic, what, concurrent):
+    want = _run(hip, "torch", periodic, what, concurrent)
+    if rccl:
+        monkeypatch.setenv("EXAMG_COMM_SELF_RCCL", "1")
+    got = _run(hip, "c", periodic, what, concurrent)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    if what != "dup":
+        fresh = np.empty_like(want)
+        hip2 = hip.new_array(want.size)
+        hip.fill_random(hip2, 4242)
+        fresh[:] = hip.to_host(hip2)
+        assert not np.array_equal(fresh, want)       # the exchange did change the ghost layers
+
+
+def test_c_exchange_two_ghost_layers(hip):
+    want = _run(hip, "torch", (True, True, True), "all", False, ghost=2)
+    got = _run(hip, "c", (True, True, True), "all", False, ghost=2)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_rccl_collectives_one_rank(hip, monkeypatch):
+    """examg_allreduce / examg_allgather through RCCL on a one-rank communicator: values unchanged / copied."""
+    from exastencils_amd import lib
+
+    monkeypatch.setenv("EXAMG_COMM_SELF_RCCL", "1")
+    L = hip.L
+    idbuf = (C.c_ubyte * lib.COMM_ID_BYTES)()
+    lib.check(L.examg_comm_unique_id(idbuf), "examg_comm_unique_id")
+    h = C.c_void_p()
+    lib.check(L.examg_comm_create(C.byref(h), C.cast(idbuf, C.c_void_p), 1, 0), "examg_comm_create")
+    assert L.examg_comm_size(h) == 1 and L.examg_comm_rank(h) == 0
+    x = hip.from_host(np.array([3.25, -1.5, 7.0]))
+    for op in (0, 1, 2):
+        lib.check(L.examg_allreduce(h, hip.ptr(x), 3, op, hip._stream()), "examg_allreduce")
+    y = hip.new_array(3)
+    lib.check(L.examg_allgather(h, hip.ptr(x), hip.ptr(y), 3, hip._stream()), "examg_allgather")
+    hip.synchronize()
+    assert hip.to_host(x).tolist() == [3.25, -1.5, 7.0]
+    assert hip.to_host(y).tolist() == [3.25, -1.5, 7.0]
+    lib.check(L.examg_comm_destroy(h), "examg_comm_destroy")
+
+
+def test_exchange_argument_errors(hip):
+    from exastencils_amd import lib
+
+    L = hip.L
+    h = C.c_void_p()
+    lib.check(L.examg_comm_create(C.byref(h), None, 1, 0), "examg_comm_create")
+    lay = FieldLayout.node(3, (8, 8, 8), 1)
+    x = hip.new_array(lay.size)
+    nb = lib.NeighborsC()
+    for d in range(3):
+        nb.rank[d][0] = nb.rank[d][1] = -1
+    lc = lay.c_struct()
+    assert L.examg_exchange(h, C.byref(lc), hip.ptr(x), C.byref(nb), 3, None, 0, hip._stream()) == 0     # no neighbours: empty function
+    nb.rank[2][0] = nb.rank[2][1] = 0
+    assert L.examg_exchange(h, C.byref(lc), hip.ptr(x), C.byref(nb), 3, None, 0, hip._stream()) != 0     # workspace missing
+    assert b"workspace" in L.examg_last_error()
+    nb.rank[2][1] = 5
+    ws = hip.new_array(int(L.examg_exchange_workspace_bytes(C.byref(lc))) // 8)
+    assert L.examg_exchange(h, C.byref(lc), hip.ptr(x), C.byref(nb), 3, hip.ptr(ws), ws.numel() * 8, hip._stream()) != 0
+    assert b"outside the communicator" in L.examg_last_error()
+    assert L.examg_comm_create(C.byref(C.c_void_p()), None, 2, 0) != 0                                    # two ranks need the id
+    lib.check(L.examg_comm_destroy(h), "examg_comm_destroy")
