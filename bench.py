@@ -512,7 +512,7 @@ def vcycle(ops, dom, comm, L, world, align=0):
     P.setup()
     P._update_residual(L)
     r0 = P.ResNorm(L)
-    use_graph = world == 1
+    use_graph = world == 1       # N > 1: eager (RCCL groups inside a stream capture hang on this stack); the agglomerated levels replay from a graph
     if use_graph:
         P.capture_cycle()
         run = P.replay_cycle

@@ -27,6 +27,9 @@ from .domain import RectDomain
 from .field import Field
 
 
+_SHARED_C_COMMS: Dict[Tuple, object] = {}     # (library, world size, rank) -> examg_comm_t*: one RCCL communicator per process
+
+
 class Communicator:
     def __init__(self, domain: RectDomain, ops, group=None, concurrent_ghost_axes: bool = False,
                  consistent_duplicates: bool = False, transport: str = "auto"):
@@ -70,7 +73,13 @@ class Communicator:
         self._ws: Dict[Tuple, object] = {}
         self._nb = None
         if transport == "c" and (self.dist is not None or any(domain.periodic)):
-            self._c_create()
+            try:
+                self._c_create()
+            except Exception as ex:      # RCCL not loadable, id exchange failed: the torch.distributed path still works
+                import warnings
+
+                warnings.warn("libexamg transport unavailable (%s); using torch.distributed point-to-point" % (ex,))
+                self._c, self.transport = None, "torch"
 
     # -- C transport (libexamg / RCCL) -----------------------------------------------------------------
     def _c_create(self):
@@ -79,6 +88,17 @@ class Communicator:
         from . import lib as _lib
 
         L, dom = self.ops.L, self.domain
+        nb = _lib.NeighborsC()
+        for d in range(3):
+            for s_, side in enumerate((-1, +1)):
+                r = dom.neighbor(d, side) if d < dom.nd else None
+                nb.rank[d][s_] = -1 if r is None else int(r)
+        self._nb = nb
+        key = (id(L), dom.world_size, dom.rank)
+        if self.dist is not None and self.group is None and key in _SHARED_C_COMMS:
+            self._c, self._c_shared = _SHARED_C_COMMS[key], True
+            return
+        self._c_shared = False
         idbuf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
         if self.dist is not None:
             torch = self.ops.torch
@@ -99,17 +119,14 @@ class Communicator:
         h = C.c_void_p()
         _lib.check(L.examg_comm_create(C.byref(h), idp, dom.world_size, dom.rank), "examg_comm_create")
         self._c = h
-        nb = _lib.NeighborsC()
-        for d in range(3):
-            for s_, side in enumerate((-1, +1)):
-                r = dom.neighbor(d, side) if d < dom.nd else None
-                nb.rank[d][s_] = -1 if r is None else int(r)
-        self._nb = nb
+        if self.dist is not None and self.group is None:
+            _SHARED_C_COMMS[key] = h
+            self._c_shared = True
 
     def close(self):
-        if self._c is not None:
+        if self._c is not None and not getattr(self, "_c_shared", False):
             self.ops.L.examg_comm_destroy(self._c)
-            self._c = None
+        self._c = None
 
     def _c_exchange(self, f: Field, x, what: int):
         import ctypes as C

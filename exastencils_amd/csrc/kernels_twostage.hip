@@ -365,6 +365,23 @@ extern "C" int examg_debug_two_stage(int disable, int blocks, int remap, int wy)
 }
 #endif
 
+// Will examg_jacobi2_boxes / examg_rbgs_sweep_fused_boxes take the one-pass kernel for these arguments (1) or their
+// fallback through `tmp` (0)?  The ONE place this is decided: callers that overlap the pass with work on another stream ask
+// here, because the fallback writes `tmp` on the launch stream.
+extern "C" int examg_two_stage_eligible(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st,
+                                        const int32_t *begin1, const int32_t *end1, const int32_t *begin2, const int32_t *end2) {
+  if (!lu || !lf || !st || !begin1 || !end1 || !begin2 || !end2) return 0;
+  const Box box1 = make_box(begin1, end1), box2 = make_box(begin2, end2);
+  if (box2.count() == 0) return 0;
+  if (box2.b0 < box1.b0 || box2.b1 < box1.b1 || box2.b2 < box1.b2 || box2.e0 > box1.e0 || box2.e1 > box1.e1 || box2.e2 > box1.e2) return 0;
+  if (!(two_stage_ok(lu, lf, st, box2) && box_inside(lu, box1, 1) && box_inside(lf, box1, 0))) return 0;
+  // launch_two_stage_lds: 32-bit window offsets must cover a 16-plane chunk plus halo
+  const LayoutDev u = make_layout(lu), f = make_layout(lf);
+  const LayoutDev &big = u.s2 > f.s2 ? u : f;
+  const long long zmax = (2147483000LL - big.s1 * (2 * 8 + 6) - 512) / big.s2 - 8;
+  return zmax >= 16 ? 1 : 0;
+}
+
 // One full red-black sweep, out of place.
 extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_in, double *u_out,
                                       const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w,

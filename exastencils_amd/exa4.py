@@ -693,8 +693,12 @@ class Exa4Program:
             self.launches += 1
         self.launches += 1
         if multi:
-            # fused deep interior + two-point shell with its exchanges on a side stream (exastencils_amd/smoothers.py)
+            # fused deep interior + two-point shell with its exchanges on a side stream (exastencils_amd/smoothers.py): rbgs_sweep
+            # exchanges ghost layers only -- a `communicate u` (duplicate + ghost) in the body keeps its duplicate part here
             from .smoothers import rbgs_sweep
+
+            if any(st[0] == "comm" and st[2] == "all" for st in body):
+                self.comm.exchange(U, us, "dup")
 
             tmp = self._pair_tmp.get((U.name, U.level))
             if tmp is None:
@@ -718,6 +722,8 @@ class Exa4Program:
         fb = fn.body
         if len(fb) != 3 or fb[0][0] != "comm" or fb[1][0] != "loop" or fb[2][0] != "advance":
             return False
+        if fb[0][2] != "ghost":
+            return False        # jacobi_pair exchanges ghost layers only: `communicate u` / `communicate dup of u` keep the plain path
         cfr = _Frame(lvl if fn.levels is not None else None, {})
         lp = fb[1]
         if lp[2] is not None or lp[3] is not None or lp[4] is not None or len(lp[5]) != 1:

@@ -91,6 +91,11 @@ class HipOps:
                                          C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin1), ivec(end1),
                                          ivec(begin2), ivec(end2), self._stream()), "examg_jacobi2_boxes")
 
+    def two_stage_eligible(self, lu, lf, st: Stencil, begin1, end1, begin2, end2) -> bool:
+        """Will jacobi2_boxes / rbgs_sweep_fused_boxes run their one-pass kernel (True) or the fallback that writes `tmp`?"""
+        sc = st.c_struct(self.ptr)
+        return bool(self.L.examg_two_stage_eligible(C.byref(lu), C.byref(lf), C.byref(sc), ivec(begin1), ivec(end1), ivec(begin2), ivec(end2)))
+
     # -- inter-grid -------------------------------------------------------------------------------
     def restrict(self, lfine, rf, lc, fc, scale: float, begin, end):
         check(self.L.examg_restrict(C.byref(lfine), self.ptr(rf), C.byref(lc), self.ptr(fc), float(scale), ivec(begin),

@@ -89,9 +89,12 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool =
 
     # The fallback of examg_jacobi2_boxes (short rows on coarse levels, other stencils) uses tmp as scratch for its whole
     # first step: it must then finish before the shell work writes tmp -- sequential order, no overlap.
+    # The kernel layer decides (ONE place: examg_two_stage_eligible -- stencil kind AND entry order, row length, box inside the
+    # allocation): only then may the shell work on tmp run concurrently on the side stream.
+    b1, e1 = shrunk(1)
     b2, e2 = shrunk(2)
-    canonical7 = nd == 3 and A.cfield is None and len(A.offsets) == 7 and axis_only
-    fused = canonical7 and (e2[0] - b2[0]) >= 64
+    fused = hasattr(ops, "two_stage_eligible") and all(e2[d] > b2[d] for d in range(nd)) and \
+        ops.two_stage_eligible(S.lc, F.lc, A, b1, e1, b2, e2)
     side_stream = ops.side_stream() if (overlap and fused and hasattr(ops, "side_stream")) else None
     if side_stream is not None:
         torch = ops.torch
@@ -147,8 +150,10 @@ def rbgs_sweep(ops, comm, domain, S, F, A, w: float, alt, tmp_field, first: int 
 
     b1, e1 = shrunk(1)
     b2, e2 = shrunk(2)
-    canonical7 = nd == 3 and A.cfield is None and len(A.offsets) == 7 and axis_only
-    fused = canonical7 and (e2[0] - b2[0]) >= 64
+    # eligibility of the one-pass kernel is the kernel layer's decision (examg_two_stage_eligible); without it the fallback
+    # needs tmp as scratch on the main stream and everything runs in sequence
+    fused = hasattr(ops, "two_stage_eligible") and all(e2[d] > b2[d] for d in range(nd)) and \
+        ops.two_stage_eligible(S.lc, F.lc, A, b1, e1, b2, e2)
 
     def interior(scratch):
         if all(e2[d] > b2[d] for d in range(nd)):
@@ -190,3 +195,53 @@ def rbgs_sweep(ops, comm, domain, S, F, A, w: float, alt, tmp_field, first: int 
         shell()
     S.slots[S.active] = alt
     return src
+
+
+def overlapped_loop(ops, domain, b, e, exchange_ghost, kernel, overlap: bool = True):
+    """`communicate ghost of f; loop over g { ... reads f within one point ... }` on a block with neighbours, as the
+    reference's core/boundary split does it (Compiler/src/exastencils/baseExt/ir/IR_LoopOverPointsInOneFragment.scala:143-222,
+    experimental_splitLoopsForAsyncComm): the loop's box shrunk by one point at every interior face reads no ghost value
+    and starts at once; the exchange (pack, RCCL send / recv, unpack) runs on the side stream meanwhile; the one-point
+    shell -- disjoint slabs, so that accumulating loops (`+=`) stay correct -- follows when the halo is in.  Used for
+    the residual (reads Solution's ghosts) and for the restriction (its coarse box shrunk by one point reads no fine ghost).
+    `kernel(begin, end)` launches the loop on a sub-box; same bits as exchange + one launch over [b, e)."""
+    nd = domain.nd
+    faces = [(d, side) for d in range(nd) for side in (-1, 1) if domain.neighbor(d, side) is not None]
+    if not faces:
+        exchange_ghost()
+        kernel(b, e)
+        return
+    ib, ie = list(b), list(e)
+    for d, side in faces:
+        if side < 0:
+            ib[d] = b[d] + 1
+        else:
+            ie[d] = e[d] - 1
+    if any(ie[d] - ib[d] < 1 for d in range(nd)):      # a block this thin has no interior: plain order
+        exchange_ghost()
+        kernel(b, e)
+        return
+    side_stream = ops.side_stream() if (overlap and hasattr(ops, "side_stream")) else None
+    if side_stream is not None:
+        torch = ops.torch
+        main = torch.cuda.current_stream(ops.device)
+        side_stream.wait_stream(main)
+        with torch.cuda.stream(side_stream):
+            exchange_ghost()
+        kernel(ib, ie)
+        main.wait_stream(side_stream)
+    else:
+        exchange_ghost()
+        kernel(ib, ie)
+    lo, hi = list(b), list(e)
+    for d in range(nd):
+        for side in (-1, 1):
+            if (d, side) not in faces:
+                continue
+            sb, se = list(lo), list(hi)
+            if side < 0:
+                se[d] = b[d] + 1
+            else:
+                sb[d] = e[d] - 1
+            kernel(sb, se)
+        lo[d], hi[d] = ib[d], ie[d]

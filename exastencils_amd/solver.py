@@ -117,8 +117,10 @@ class ConfigL4:
     fused_coarse: bool = True     # single block: mgCycle@coarsest as one persistent kernel
     fused_rbgs: bool = False      # one-pass red-black sweep (out of place, pointer swap)
     fused_residual_restrict: bool = False   # single block: `Residual = ...` + restriction as one pass, fine residual not stored
+    overlap_transfers: bool = True            # blocks > 1: residual / restriction as interior + shell around their halo exchange
     agglomerate_level: Optional[int] = None   # blocks > 1: levels <= this are solved redundantly on every rank (see _agg_cycle)
     agglomerate_extra_levels: int = 0         # the gathered hierarchy coarsens this many levels below min_level
+    graph_agglomerated: bool = True           # GPU: the cycle on the gathered levels (no communication) replays from a hipGraph
 
 
 class SolverFromL4(_Program):
@@ -164,6 +166,8 @@ class SolverFromL4(_Program):
                             fused_rbgs=cfg.fused_rbgs)
             self._agg = SolverFromL4(acfg, ops, whole, Communicator(whole, ops))
             self._agg.setup()
+            if cfg.graph_agglomerated and hasattr(ops, "torch") and getattr(getattr(ops, "device", None), "type", "cpu") != "cpu":
+                self._agg.capture_cycle()
             nc = dom.ncells(k)
             n_own = 1
             n_halo = 1
@@ -192,7 +196,10 @@ class SolverFromL4(_Program):
         b, e = A.bounds(AS)
         ops.set(AS.lc, AS.data(), 0.0, b, e)
         A.apply_bc(AS)
-        A.mgCycle(k)
+        if "cycle" in A._graphs:
+            A.replay_cycle()      # the gathered levels are one block without communication: ~60 launches as one graph replay
+        else:
+            A.mgCycle(k)
         # own part of the correction, ghost layers included (the neighbours' inner planes come straight from the whole level)
         lb = [-S.layout.ghost[d] if d < nd else 0 for d in range(3)]
         le = [nc[d] + 1 + S.layout.ghost[d] if d < nd else 1 for d in range(3)]
@@ -207,10 +214,21 @@ class SolverFromL4(_Program):
 
     def _update_residual(self, l: int):
         S, R = self.Solution[l], self.Residual[l]
-        self.communicate(S, axis_only=self._faces_only(self.Laplace[l]))
         b, e = self.bounds(R)
-        self.ops.stencil_op(RESIDUAL, S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), R.lc, R.data(), self.Laplace[l],
-                            0.0, -1, b, e)
+        A = self.Laplace[l]
+
+        def loop(bb, ee):
+            self.ops.stencil_op(RESIDUAL, S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), R.lc, R.data(), A, 0.0, -1, bb, ee)
+
+        if self.cfg.overlap_transfers and not self._single_block() and self._faces_only(A):
+            # `communicate Solution` = duplicate layers (in sequence: the loop reads them) + ghost layers (overlapped)
+            from .smoothers import overlapped_loop
+
+            self.communicate(S, None, "dup")
+            overlapped_loop(self.ops, self.domain, b, e, lambda: self.communicate(S, None, "ghost", axis_only=True), loop)
+        else:
+            self.communicate(S, axis_only=self._faces_only(A))
+            loop(b, e)
         self.apply_bc(R)
 
     # Function Application (...exa4:251-277): init part
@@ -324,17 +342,38 @@ class SolverFromL4(_Program):
                                   Fc.data(), 1.0, fb, fe, b, e)
         else:
             self._update_residual(l)
-            self.communicate(R)
             b, e = self.bounds(Fc)
-            ops.restrict(R.lc, R.data(), Fc.lc, Fc.data(), 1.0, b, e)
+            if self.cfg.overlap_transfers and not self._single_block():
+                from .smoothers import overlapped_loop
+
+                self.communicate(R, None, "dup")
+                overlapped_loop(ops, self.domain, b, e, lambda: self.communicate(R, None, "ghost"),
+                                lambda bb, ee: ops.restrict(R.lc, R.data(), Fc.lc, Fc.data(), 1.0, bb, ee))
+            else:
+                self.communicate(R)
+                ops.restrict(R.lc, R.data(), Fc.lc, Fc.data(), 1.0, b, e)
         Sc, S = self.Solution[l - 1], self.Solution[l]
         b, e = self.bounds(Sc)
         ops.set(Sc.lc, Sc.data(), 0.0, b, e)
         self.apply_bc(Sc)
         self.mgCycle(l - 1)
-        self.communicate(Sc)
         b, e = self.bounds(S)
-        ops.prolong_add(Sc.lc, Sc.data(), S.lc, S.data(), b, e)
+        side = ops.side_stream() if (self.cfg.overlap_transfers and not self._single_block() and hasattr(ops, "side_stream")) else None
+        if side is not None:
+            # `communicate Solution@coarser`: the interpolation of node values reads duplicate and inner points of the coarse
+            # block only (fine node i lies between coarse nodes i/2 and (i+1)/2, both inside [0, n]) -- the ghost part of the
+            # exchange runs beside the kernel, the duplicate part (which the kernel reads) before it
+            torch = ops.torch
+            self.communicate(Sc, None, "dup")
+            main = torch.cuda.current_stream(ops.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.communicate(Sc, None, "ghost")
+            ops.prolong_add(Sc.lc, Sc.data(), S.lc, S.data(), b, e)
+            main.wait_stream(side)
+        else:
+            self.communicate(Sc)
+            ops.prolong_add(Sc.lc, Sc.data(), S.lc, S.data(), b, e)
         self.apply_bc(S)
         self._smooth(l)
 
@@ -385,6 +424,10 @@ class SolverFromL4(_Program):
 
     # -- hipGraph capture of one V-cycle (single block, fused coarse solve: no host round trips) ----
     def capture_cycle(self):
+        """One mgCycle@finest of a single block as a hipGraph (fused coarse solve: no host round trip).  Cycles with block
+        neighbours are not captured: RCCL point-to-point groups inside a stream capture hung on this stack (ROCm 7.2, one-GPU
+        self-exchange test, round 2) -- there the comm-free part, the agglomerated coarse levels, is what gets captured
+        (_agg_cycle)."""
         if not (self._single_block() and self.cfg.fused_coarse):
             raise RuntimeError("graph capture needs a single block and the fused coarse solve")
         torch = self.ops.torch
@@ -398,7 +441,8 @@ class SolverFromL4(_Program):
             self.mgCycle(hi)      # warm-up outside capture (lazy allocations)
         torch.cuda.current_stream(self.ops.device).wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: other threads of the process (RCCL's proxy threads at N > 1) may issue HIP calls during the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.mgCycle(hi)
         self._graphs["cycle"] = g
         return g

@@ -164,6 +164,12 @@ int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in, double *u_
                         const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin1, const int32_t *end1,
                         const int32_t *begin2, const int32_t *end2, examg_stream_t stream);
 
+/* 1 if examg_jacobi2_boxes / examg_rbgs_sweep_fused_boxes will run their one-pass kernel for these arguments, 0 if they will
+ * take the fallback that writes `tmp` on the launch stream (other stencils or entry orders, short rows, boxes at the edge of
+ * the allocation).  A caller that overlaps the pass with work on `tmp` on another stream must ask here first. */
+int examg_two_stage_eligible(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const int32_t *begin1,
+                             const int32_t *end1, const int32_t *begin2, const int32_t *end2);
+
 /* `Residual = RHS - A * Solution` followed by `RHS@coarser = scale * R * Residual` (mgCycle,
  * Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:215-223) as ONE pass when nothing else reads the fine residual: it is never
  * written (48 + 8 B per fine point -> 16 B).  [fbegin,fend): the residual loop's box; [cbegin,cend): the restriction loop's

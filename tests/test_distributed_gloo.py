@@ -314,3 +314,42 @@ def test_eight_blocks_as_on_a_full_node(tmp_path):
             assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * O.res_history[0], (v["res"], O.res_history)
         for x, y in zip(v["res_jac"], J.res_history):
             assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * J.res_history[0], (v["res_jac"], J.res_history)
+
+
+# -------------------------------------------------------------------------------------------------
+def _worker_dupcheck(rank, world, port, out_dir):
+    """Communicator.check_duplicates: True while both owners of every shared plane hold the same bits, False on every rank
+    as soon as one value of one shared plane differs."""
+    _init(rank, world, port)
+    from oracle_ops import OracleOps
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.field import Field
+    from exastencils_amd.layout import FieldLayout
+
+    ops = OracleOps()
+    dom = RectDomain(3, (1, 2, 2), rank)
+    comm = Communicator(dom, ops, consistent_duplicates=True)
+    full = Communicator(dom, ops)
+    lay = FieldLayout.node(3, dom.ncells(3), 1)
+    U = Field("U", 3, lay, ops)
+    U.data().copy_(torch.from_numpy(np.random.RandomState(10 + rank).rand(lay.size)))
+    before = comm.check_duplicates(U)            # random per-rank data: shared planes differ
+    full.exchange(U, None, "dup")                # upstream duplicate exchange makes them agree
+    after = comm.check_duplicates(U)
+    if rank == world - 1:                        # one value of this block's lower z duplicate plane
+        u = U.data().numpy().reshape(lay.shape_zyx)
+        u[lay.ref(2), lay.ref(1) + 3, lay.ref(0) + 2] += 1e-9
+    broken = comm.check_duplicates(U)
+    json.dump({"before": before, "after": after, "broken": broken}, open(os.path.join(out_dir, "d_%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_check_duplicates_assertion_mode(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_dupcheck, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    for r in range(4):
+        d = json.load(open(tmp_path / ("d_%d.json" % r)))
+        assert d == {"before": False, "after": True, "broken": False}, (r, d)

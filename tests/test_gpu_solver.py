@@ -249,6 +249,73 @@ def test_rbgs_sweep_overlap_equals_sequential(hip, rank):
     assert np.array_equal(outs[0], outs[2])
 
 
+def _permuted7(h):
+    """A 7-point constant stencil declared in an entry order that is neither of the two the one-pass kernel knows
+    (c, -y, +y, -x, +x, -z, +z): valid program text, different summation order, so the fused kernels must not be taken."""
+    from exastencils_amd.field import Stencil
+
+    offs = [(0, 0, 0), (0, -1, 0), (0, 1, 0), (-1, 0, 0), (1, 0, 0), (0, 0, -1), (0, 0, 1)]
+    co = [2.0 / h[0] ** 2 + 2.0 / h[1] ** 2 + 2.0 / h[2] ** 2] + [-1.0 / h[d] ** 2 for d in (1, 1, 0, 0, 2, 2)]
+    return Stencil(offs, co)
+
+
+@pytest.mark.parametrize("kind", ["jacobi_pair", "rbgs_sweep"])
+def test_non_canonical_entry_order_with_neighbours(hip, kind):
+    """A 7-point stencil in a non-canonical entry order on a block with loop-back neighbours: the kernel layer reports the
+    one-pass kernel as not eligible (examg_two_stage_eligible), jacobi_pair / rbgs_sweep then run interior and shell in
+    sequence through the fallback -- no race on the scratch field, no 'needs a distinct tmp' error -- and give the bits of
+    the plain statement-by-statement form."""
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.field import Field
+    from exastencils_amd.layout import FieldLayout
+    from exastencils_amd.smoothers import jacobi_pair, rbgs_sweep
+
+    dom = RectDomain(3, (2, 2, 2), 5)
+    L = 7
+    lay, layf = FieldLayout.node(3, dom.ncells(L), 1), FieldLayout.node(3, dom.ncells(L), 0, True, False)
+    A = _permuted7(dom.h(L))
+    w = 0.8 / A.diag
+    b, e = dom.loop_bounds(lay)
+    b1 = [b[d] + (1 if dom.neighbor(d, -1) is not None else 0) for d in range(3)]
+    e1 = [e[d] - (1 if dom.neighbor(d, +1) is not None else 0) for d in range(3)]
+    b2 = [b[d] + (2 if dom.neighbor(d, -1) is not None else 0) for d in range(3)]
+    e2 = [e[d] - (2 if dom.neighbor(d, +1) is not None else 0) for d in range(3)]
+    assert not hip.two_stage_eligible(lay.c_struct(), layf.c_struct(), A, b1, e1, b2, e2)
+    from exastencils_amd.field import laplace_fd
+    assert hip.two_stage_eligible(lay.c_struct(), layf.c_struct(), laplace_fd(3, dom.h(L)), b1, e1, b2, e2)
+    outs = []
+    for mode in ("fused-api", "plain"):
+        nslots = 2 if kind == "jacobi_pair" else 1
+        S, F, T = Field("S", L, lay, hip, nslots, None), Field("F", L, layf, hip, 1, None), Field("T", L, lay, hip, 1, None)
+        hip.fill_random(S.data(0), 1)
+        if nslots == 2:
+            S.data(1).copy_(S.data(0))
+        T.data().copy_(S.data(0))
+        alt = S.data(0).clone()
+        hip.fill_random(F.data(), 3)
+        comm = _LoopbackComm(dom, hip)
+        for _ in range(2):
+            if kind == "jacobi_pair":
+                if mode == "plain":
+                    for _k in range(2):
+                        comm.exchange(S, S.active, "ghost")
+                        hip.stencil_op(2, S.lc, S.data(S.active), F.lc, F.data(), S.lc, S.data(S.next), A, w, -1, b, e)
+                        S.advance()
+                else:
+                    jacobi_pair(hip, comm, dom, S, F, A, w, T, overlap=True)
+            else:
+                if mode == "plain":
+                    for colour in (0, 1):
+                        comm.exchange(S, None, "ghost")
+                        hip.stencil_op(2, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, w, colour, b, e)
+                else:
+                    alt = rbgs_sweep(hip, comm, dom, S, F, A, w, alt, T, 0, overlap=True)
+        hip.synchronize()
+        v = hip.to_host(S.data()).reshape(lay.shape_zyx)
+        outs.append(v[b[2] + 1:e[2] + 1, b[1] + 1:e[1] + 1, b[0] + 1:e[0] + 1].copy())
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_lds_resident_coarse_cg_equals_global_memory_solver():
     """Coarsest grids of up to 4096 points run the CG with its vectors in registers / LDS: same iterates, bit for bit, as
     the global-memory form of the kernel (3-D 16^3 and 8^3 coarsest grids, 2-D 16^2)."""

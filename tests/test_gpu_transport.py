@@ -105,3 +105,4 @@ def test_exchange_argument_errors(hip):
     assert b"outside the communicator" in L.examg_last_error()
     assert L.examg_comm_create(C.byref(C.c_void_p()), None, 2, 0) != 0                                    # two ranks need the id
     lib.check(L.examg_comm_destroy(h), "examg_comm_destroy")
+
