@@ -419,6 +419,8 @@ class Exa4Program:
             return st.diag
         if name in _MATH and name not in self.functions:
             return _MATH[name](*[self._eval(a, fr) for a in args])
+        if name.split("_")[0] in ("printField", "writeField", "readField") and name not in self.functions:
+            return self._field_io(name, args, fr)
         if name == "getKnowledge":
             key = self._eval(args[0], fr)
             return self.k.get(key, {"testing_enabled": False, "testing_printRes": True, "testing_printErr": True}.get(key, False))
@@ -428,6 +430,60 @@ class Exa4Program:
                 lvl = self._level_of(lspec, fr)
             return self.call(name, lvl if lvl is not None else fr.level, [self._eval(a, fr) for a in args], fr)
         return self._builtin(name, [self._eval(a, fr) for a in args], fr)
+
+    # -- field I/O ---------------------------------------------------------------------------------------
+    def _field_io(self, name: str, args: list, fr: _Frame):
+        """printField / writeField / readField [ _lock | _fpp ] ( "file", field [, includeGhost [, binary [, condition [, separator ]]]] )
+        (Compiler/src/exastencils/field/ir/IR_PrintField.scala:38-110, IR_ReadField / IR_WriteField; argument order as in
+        Testing/IOTest/3D_Scalar_CheckEquality_ReadAfterWrite.exa4:78-100).  "$blockId" in the file name becomes the rank.
+        Blocks of a decomposition write one after the other into the same file (the reference's MPI_Sequential, "lock"
+        interface); the data leave / enter the device through the kernel layer's to_host / from_host."""
+        from . import io as xio
+
+        base, iface = (name.split("_") + ["lock"])[:2]
+        pos = [i for i, a in enumerate(args) if a[0] == "fld"]
+        if not pos:
+            raise Exa4Unsupported("%s without a field argument" % name)
+        f, slot = self._field(args[pos[0]], fr)
+        fname = str(self._eval(args[0], fr)).replace("$blockId", str(self.domain.rank))
+        rest = [self._eval(a, fr) for a in args[pos[0] + 1:]]
+        include_ghost = bool(rest[0]) if len(rest) > 0 else False
+        binary = bool(rest[1]) if len(rest) > 1 else (base != "printField" and iface != "lock")
+        condition = rest[2] if len(rest) > 2 else True
+        separator = str(rest[3]) if len(rest) > 3 else " "
+        if not isinstance(condition, bool):
+            raise Exa4Unsupported("%s: only constant conditions" % name)
+        d = os.path.dirname(fname)
+        if d and self.domain.rank == 0:
+            os.makedirs(d, exist_ok=True)
+        dist = getattr(self.comm, "dist", None)
+        shared = dist is not None and "$blockId" not in str(self._eval(args[0], fr))
+        self.ops.synchronize()
+        for turn in range(self.domain.world_size if shared else 1):
+            if not shared or turn == self.domain.rank:
+                if not condition:
+                    if base != "readField" and turn == 0:
+                        open(fname, "w").close()
+                elif base == "readField":
+                    if shared and self.domain.world_size > 1:
+                        raise Exa4Unsupported("readField from one file shared by several blocks")
+                    if binary:
+                        xio.read_field(fname, f, self.ops, slot, include_ghost)
+                    else:
+                        xio.read_field_ascii(fname, f, self.ops, slot, include_ghost, separator)
+                elif binary:
+                    if shared and self.domain.world_size > 1:
+                        raise Exa4Unsupported("binary writeField into one file shared by several blocks")
+                    xio.write_field(fname, f, self.ops, slot, include_ghost)
+                else:
+                    xio.print_field(fname, f, self.ops, self.domain, slot, include_ghost, separator, None, append=shared and turn > 0,
+                                    precision=int(self.k.get("field_printFieldPrecision", -1)))
+            if shared:
+                dist.barrier()
+        if base == "readField":
+            self._bc_valid.discard((f.name, f.level, slot))       # whatever the boundary planes held, the file's values replace it
+            self._bc_epoch[(f.name, f.level)] = self._bc_epoch.get((f.name, f.level), 0) + 1
+        return None
 
     # -- built-in statements ----------------------------------------------------------------------------------------------
     def _emit(self, line: str):
@@ -1108,6 +1164,9 @@ class Exa4Program:
                         return ops.axpby(X.lc, X.data(xs), D.lc, D.data(ds), 1.0, float(self._eval(t[2], fr)), b, e)
         elif op in ("+=", "-="):
             sign = 1.0 if op == "+=" else -1.0
+            if rhs[0] == "fld":          # x += y | x -= y  (y + (-1.0) * x is exactly y - x)
+                X, xs = self._field(rhs, fr)
+                return ops.axpby(X.lc, X.data(xs), D.lc, D.data(ds), sign, 1.0, b, e)
             if rhs[0] == "bin" and rhs[1] == "*":
                 if rhs[3][0] == "fld" and self._is_scalar(rhs[2]):
                     X, xs = self._field(rhs[3], fr)

@@ -425,3 +425,37 @@ def test_periodic_direction_on_two_blocks_matches_single_block(tmp_path):
         assert len(meta["values"]) == len(single.printed_values)
         for x, y in zip(meta["values"], single.printed_values):
             assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * single.printed_values[0]
+
+
+def _iotest(ops, tmp_path, level=3):
+    import numpy as np
+
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        with open(os.path.join(EX, "iotest3d.exa4")) as f:
+            P = exa4.Exa4Program(f.read(), dict(dimensionality=3, minLevel=level, maxLevel=level), ops=ops)
+        P.run()
+    finally:
+        os.chdir(cwd)
+    n = (1 << level) + 1
+    assert P.out[0].startswith("lock ") and P.out[1].startswith("fpp ")
+    lock, fpp = P.printed_values
+    assert fpp == 0.0                              # raw doubles: exact
+    assert 0.0 <= lock < 1e-6 * n ** 1.5           # ascii: std::scientific with 6 digits after the point
+    txt = (tmp_path / "data" / "src_lock.txt").read_text().splitlines()
+    assert len(txt) == (n + 2) ** 3                # GLB..GRE with ghost layers
+    first = txt[0].split(",")
+    assert len(first) == 5 and first[-1] == ""     # x,y,z,value, -- every entry followed by the separator
+    h = 1.0 / (n - 1)
+    assert [float(t) for t in first[:3]] == [float("%g" % -h)] * 3     # the lower ghost corner, positions at %g precision
+    assert (tmp_path / "data" / "src_fpp_0.bin").stat().st_size == 8 * (n + 2) ** 3
+    vis = (tmp_path / "data" / "src_vis.csv").read_text().splitlines()
+    assert len(vis) == n ** 3 and vis[0].endswith(" ")
+    x, y, z, v = [float(t) for t in vis[-1].split()]
+    assert (x, y, z) == (1.0, 1.0, 1.0) and v == -1.0
+    return P
+
+
+def test_field_io_program_on_cpu_ops(tmp_path):
+    _iotest(OracleOps(), tmp_path)

@@ -160,3 +160,13 @@ def test_stencil_field_entries_as_programs_equal_the_dedicated_kernel(hip, monke
     P = example("varcoeff3d.exa4", 1, 5, ops=hip)
     P.run()
     assert P.printed_values == ref.printed_values
+
+
+def test_field_io_round_trip_on_gpu(hip, tmp_path):
+    """examples/exa4/iotest3d.exa4 (shape of the reference's Testing/IOTest/3D_Scalar_CheckEquality_ReadAfterWrite.exa4)
+    through the interpreter on device fields: ascii write / read with ghost layers, raw-double write / read, printField --
+    data cross through to_host / from_host; the binary round trip is exact, the ascii one within its 7 digits."""
+    from test_exa4 import _iotest
+
+    P = _iotest(hip, tmp_path, level=4)
+    assert P.launches >= 6
