@@ -452,8 +452,9 @@ def _iotest(ops, tmp_path, level=3):
     assert (tmp_path / "data" / "src_fpp_0.bin").stat().st_size == 8 * (n + 2) ** 3
     vis = (tmp_path / "data" / "src_vis.csv").read_text().splitlines()
     assert len(vis) == n ** 3 and vis[0].endswith(" ")
-    x, y, z, v = [float(t) for t in vis[-1].split()]
-    assert (x, y, z) == (1.0, 1.0, 1.0) and v == -1.0
+    x, y, z, v = [float(t) for t in vis[n * n + n + 1].split()]          # the first inner node (h, h, h): h^2 - h^2 - h^2
+    assert (x, y, z) == (h, h, h) and abs(v + h * h) <= 1e-6 * h * h
+    assert float(vis[-1].split()[3]) == 0.0                               # `loop over src` leaves the boundary nodes untouched
     return P
 
 
