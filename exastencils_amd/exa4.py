@@ -125,6 +125,7 @@ class _Frame:
     level: Optional[int]
     vars: Dict[str, object]
     colour: Optional[int] = None
+    contract: Optional[tuple] = None     # (extent, posExt, negExt) inside `repeat .. with contraction`: loops widen at interior faces
 
 
 class Exa4Program:
@@ -241,6 +242,9 @@ class Exa4Program:
                 if any(dup[i] != 1 for i in range(nd)):
                     raise Exa4Unsupported("layout %s: node fields need one duplicate layer" % ld.name)
                 inner = tuple(nc[i] - 1 if i < nd else 1 for i in range(3))
+                if ld.inner and tuple(ld.inner[:nd]) != inner[:nd]:
+                    raise Exa4Unsupported("layout %s: innerPoints %s differ from the %s points level %d gives one fragment"
+                                          % (ld.name, list(ld.inner[:nd]), list(inner[:nd]), lvl))
                 lay = FieldLayout(nd, inner, ghost, dup, (0, 0, 0), (0, 0, 0), ld.dup_comm, ld.ghost_comm)
                 bc_fn, bc_par = None, ()
                 if fd.bc is not None:
@@ -485,6 +489,18 @@ class Exa4Program:
             self._bc_epoch[(f.name, f.level)] = self._bc_epoch.get((f.name, f.level), 0) + 1
         return None
 
+    def _range(self, name: str, push: bool):
+        torch = getattr(self.ops, "torch", None)
+        if torch is None or getattr(getattr(self.ops, "device", None), "type", "cpu") == "cpu":
+            return
+        try:
+            if push:
+                torch.cuda.nvtx.range_push(name)
+            else:
+                torch.cuda.nvtx.range_pop()
+        except Exception:       # profiler ranges are an aid, never a reason to stop a program
+            pass
+
     # -- built-in statements ----------------------------------------------------------------------------------------------
     def _emit(self, line: str):
         self.out.append(line)
@@ -512,10 +528,15 @@ class Exa4Program:
             if m and "oldPrec =" not in str(args[0]):
                 self._precision = int(m.group(1)) if m.group(1).isdigit() else 6
         elif name == "startTimer":
+            # IR_Stopwatch (Compiler/src/exastencils/timing/ir/IR_Stopwatch.scala:31-84): wall-clock timer; on the GPU also a
+            # profiler range of the same name (roctx, through torch.cuda.nvtx), so rocprofv3 --marker-trace shows the program's
+            # own timers around the kernels they enclose
             self.ops.synchronize()
+            self._range(str(args[0]), True)
             self._timer_start[args[0]] = time.perf_counter()
         elif name == "stopTimer":
             self.ops.synchronize()
+            self._range(str(args[0]), False)
             self.timers[args[0]] = self.timers.get(args[0], 0.0) + time.perf_counter() - self._timer_start.pop(args[0])
         elif name == "printAllTimers":
             for key, val in self.timers.items():
@@ -660,6 +681,8 @@ class Exa4Program:
                 self._exec_block(s[3], fr)
             if s[2]:
                 fr.vars[s[2]] = n
+        elif k == "contract":
+            self._exec_contract(s, fr)
         elif k == "until":
             while not self._eval(s[1], fr):
                 self._exec_block(s[2], fr)
@@ -813,6 +836,75 @@ class Exa4Program:
         if k:
             self._exec_block(body, fr)
         return True
+
+    # -- `repeat n times with contraction [..] { loop ..; advance .. }` (temporal blocking with deep ghost layers) ------------
+    def _exec_contract(self, s, fr: _Frame):
+        """IR_ContractingLoop.expandSpecial (baseExt/ir/IR_ContractingLoop.scala:130-196): the loop is unrolled; the k-th
+        `loop over` of the unrolled sequence runs on bounds widened by (total - 1 - k) x the contraction at interior faces, so
+        that no exchange is needed inside.  Slotted Jacobi bodies run as two-step passes (examg_jacobi2_boxes: first step on
+        the box widened by e, second on the box widened by e - 1) -- the reference's own use of the construct
+        (Testing/PolyExpl/Jac3Dcc.exa4:27: 5 ghost layers, 5 steps)."""
+        _, nexpr, counter, pos, neg, body = s
+        n = int(self._eval(nexpr, fr))
+        if any(st[0] not in ("loop", "advance") for st in body):
+            raise Exa4Unsupported("repeat ... with contraction: body may hold `loop over` and `advance` statements only")
+        nloops = sum(1 for st in body if st[0] == "loop")
+        expand = n * nloops - 1
+        it = 0
+        if self.fuse and counter is None and nloops == 1 and len(body) == 2 and body[0][0] == "loop" and body[1][0] == "advance":
+            m = self._contract_pair_plan(body, fr)
+            while m is not None and n - it >= 2:
+                U, F, A, w, tmp = m
+                lb, le = self.domain.loop_bounds(U.layout)
+                b1, e1 = self._contract_bounds(U.layout, lb, le, expand, pos, neg)
+                b2, e2 = self._contract_bounds(U.layout, lb, le, expand - 1, pos, neg)
+                self.launches += 1
+                self.ops.jacobi2_boxes(U.lc, U.data(U.active), U.data(U.next), tmp.data(), F.lc, F.data(), A, w, b1, e1, b2, e2)
+                U.advance()
+                expand -= 2
+                it += 2
+        saved = fr.contract
+        try:
+            for k in range(it, n):
+                if counter:
+                    fr.vars[counter] = k
+                for st in body:
+                    if st[0] == "loop":
+                        fr.contract = (expand, pos, neg)
+                        self._exec_loop(st, fr)
+                        expand -= 1
+                    else:
+                        self._exec(st, fr)
+        finally:
+            fr.contract = saved
+        if counter:
+            fr.vars[counter] = n
+
+    def _contract_pair_plan(self, body, fr: _Frame):
+        """(U, F, A, w, scratch) if body is `loop over U { U<next> = U<active> + w (F - A U<active>) }; advance U` on a two-slot
+        field with constant coefficients whose two slots hold the same boundary values (same condition as _try_jacobi_pairs)."""
+        lp = body[0]
+        if lp[2] is not None or lp[3] is not None or lp[4] is not None or len(lp[5]) != 1:
+            return None
+        m = self._match_smoother(lp[5][0], fr)
+        if m is None:
+            return None
+        D, ds, U, us, F, fs, A, w = m
+        if D is not U or U.num_slots != 2 or us != U.active or ds != U.next or A.cfield is not None:
+            return None
+        if self._field(body[1][1], fr)[0] is not U or self._field(lp[1], fr)[0] is not U:
+            return None
+        # both slots must carry the same values on the physical boundary planes (the pass reads <active>'s in both steps):
+        # either `apply bc` put the field's Dirichlet values into both, or nothing has written them since the zero fill
+        valid = [(U.name, U.level, sl) in self._bc_valid for sl in range(2)]
+        untouched = self._bc_epoch.get((U.name, U.level), 0) == 0 and not any(valid)
+        if not (untouched or (U.bc_fn is not None and all(valid))):
+            return None
+        key = (U.name, U.level)
+        tmp = self._pair_tmp.get(key)
+        if tmp is None:
+            tmp = self._pair_tmp[key] = Field(U.name + "Tmp", U.level, U.layout, self.ops, 1, None)
+        return U, F, A, w, tmp
 
     # -- coarse-grid CG as one kernel ---------------------------------------------------------------------------------------
     def _inline(self, body, lvl: int, depth: int = 0):
@@ -1058,7 +1150,23 @@ class Exa4Program:
         for d in range(nd):
             if lower[d]:
                 b[d] = max(b[d], 1)
+        if fr.contract is not None and reduction is None:
+            b, e = self._contract_bounds(lay, b, e, *fr.contract)
         return [(b, e)], colour
+
+    def _contract_bounds(self, lay, b, e, extent: int, pos, neg):
+        """Loop bounds inside `repeat n times with contraction`: widened by `extent` x the contraction per side at interior faces
+        (iteration offset 0), unchanged on physical boundaries (IR_ContractingLoop.extendBoundsBegin / End,
+        Compiler/src/exastencils/baseExt/ir/IR_ContractingLoop.scala:45-87); the layers computed redundantly must exist."""
+        b, e = list(b), list(e)
+        for d in range(self.nd):
+            if self.domain.neighbor(d, -1) is not None:
+                b[d] -= extent * (neg[d] if d < len(neg) else 0)
+            if self.domain.neighbor(d, +1) is not None:
+                e[d] += extent * (pos[d] if d < len(pos) else 0)
+            if b[d] - 1 < lay.idx("GLB", d) or e[d] + 1 > lay.idx("GRE", d):
+                raise Exa4Unsupported("contraction by %d layers needs deeper ghost layers than the layout has" % extent)
+        return b, e
 
     def _exec_loop(self, s, fr: _Frame):
         _, target, only, where, reduction, body = s

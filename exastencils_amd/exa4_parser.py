@@ -71,6 +71,7 @@ class LayoutDecl:
     dup: Tuple[int, ...] = ()
     ghost_comm: bool = False
     dup_comm: bool = False
+    inner: Tuple[int, ...] = ()
 
 
 @dataclass
@@ -234,6 +235,8 @@ class Parser:
                 d.ghost, d.ghost_comm = vals, comm
             elif key == "duplicateLayers":
                 d.dup, d.dup_comm = vals, comm
+            elif key == "innerPoints":
+                d.inner = vals          # explicit inner extent (Testing/PolyExpl/Jac3Dcc.exa4:2-5); must agree with the level
             else:
                 raise Exa4Unsupported("layout option %r" % key)
         self.layouts.append(d)
@@ -445,8 +448,15 @@ class Parser:
                 counter = None
                 if self.accept("count"):
                     counter = self.ident()
-                if self.at("with"):
-                    raise Exa4Unsupported("line %d: repeat ... with contraction" % t.line)
+                if self.accept("with"):
+                    # `repeat n times with contraction [px, py, pz] [, [nx, ny, nz]] { .. }` (parsers/l4/L4_Parser.scala: contractionLoop;
+                    # baseExt/ir/IR_ContractingLoop.scala): positive extents, negative ones default to the same
+                    self.expect("contraction")
+                    pos = tuple(int(_const_value(e)) for e in self._const_list())
+                    neg = pos
+                    if self.accept(","):
+                        neg = tuple(int(_const_value(e)) for e in self._const_list())
+                    return ("contract", n, counter, pos, neg, self.block())
                 return ("repeat", n, counter, self.block())
             if w == "if":
                 self.next()

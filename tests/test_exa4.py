@@ -21,6 +21,7 @@ from golden_cases import golden_text  # noqa: E402
 from oracle_ops import OracleOps  # noqa: E402
 
 from exastencils_amd import exa4, knowledge  # noqa: E402
+from exastencils_amd.domain import RectDomain  # noqa: E402
 
 REF = "/root/reference"
 EX = os.path.join(ROOT, "examples", "exa4")
@@ -247,7 +248,7 @@ Stencil A@all { [0, 0, 0] => 6.0
     ("0.0", "loop over u@finest { u@finest += 0.8 / diag ( A@finest ) * ( f@finest - A@finest * u@finest ) }", "without colouring"),
     ("0.0", "loop over u@finest { u@finest = u@finest * f@finest }", "none of the recognised kernels"),
     ("0.0", "loop over u@finest { u@finest = atan2 ( vf_nodePosition_x, 2.0 ) }", "point expression"),
-    ("0.0", "repeat 2 times with contraction [1, 1, 1] { }", "contraction"),
+    ("0.0", "repeat 2 times with contraction [1, 1, 1] { apply bc to u@finest }", "contraction"),
 ])
 def test_constructs_outside_the_subset_are_refused(bc, body, what):
     text = HEADER % bc + "Function Application { %s }" % body
@@ -460,3 +461,88 @@ def _iotest(ops, tmp_path, level=3):
 
 def test_field_io_program_on_cpu_ops(tmp_path):
     _iotest(OracleOps(), tmp_path)
+
+
+# -- `repeat n times with contraction` (Testing/PolyExpl/Jac3Dcc.exa4:27) ---------------------------------
+def _plain_repeat_program():
+    with open(os.path.join(EX, "jacobi3d_contraction.exa4")) as f:
+        return f.read().replace("repeat 5 times with contraction [1, 1, 1] {", "repeat 5 times {")
+
+
+def test_contracting_loop_single_block():
+    """On one block every face is physical: the contracting loop is the plain repeat (IR_ContractingLoop widens bounds at
+    interior faces only); run as two two-step passes + one step it gives the same bits."""
+    fused = example("jacobi3d_contraction.exa4", 4, 4)
+    fused.run()
+    plain = example("jacobi3d_contraction.exa4", 4, 4, fuse=False)
+    plain.run()
+    ref = exa4.Exa4Program(_plain_repeat_program(), dict(dimensionality=3, minLevel=4, maxLevel=4), ops=OracleOps(), fuse=False)
+    ref.run()
+    assert fused.printed_values == plain.printed_values == ref.printed_values
+    assert fused.launches < plain.launches
+    with pytest.raises(exa4.Exa4Unsupported):       # 5 steps need 5 ghost layers at an interior face
+        bad = exa4.Exa4Program(open(os.path.join(EX, "jacobi3d_contraction.exa4")).read().replace("ghostLayers = [5, 5, 5]", "ghostLayers = [3, 3, 3]"),
+                               dict(dimensionality=3, minLevel=4, maxLevel=4), ops=OracleOps(),
+                               domain=RectDomain(3, (1, 1, 2), 0, (2, 2, 1)), comm=_NoComm())
+        bad.run()
+
+
+class _NoComm:
+    """Stands in for a communicator where only the bounds logic is under test."""
+    dist = None
+    stats = {"messages": 0}
+
+    def exchange(self, *a, **k):
+        pass
+
+    def allreduce(self, t, op="sum"):
+        return t
+
+
+def _worker_contract(rank, world, port, out_dir, fuse):
+    import json
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import mg
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+
+    mg.lib().orc_set_num_threads(2)
+    ops = OracleOps()
+    dom = RectDomain(3, (1, 2, 2), rank, (2, 1, 1))
+    P = example("jacobi3d_contraction.exa4", 3, 3, ops=ops, domain=dom, comm=Communicator(dom, ops), fuse=fuse)
+    P.run()
+    json.dump({"values": P.printed_values, "messages": P.comm.stats["messages"], "launches": P.launches},
+              open(os.path.join(out_dir, "c%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_contracting_loop_on_four_blocks_matches_single_block(tmp_path, fuse):
+    """Four blocks (1 x 2 x 2), 5 ghost layers, ONE exchange per 5 Jacobi steps: the steps in between are computed on boxes
+    4, 3, 2, 1, 0 layers wider at the interior faces; norms equal the single block's (which takes the plain repeat)."""
+    import json
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_contract, args=(4, port, str(tmp_path), fuse), nprocs=4, join=True)
+    single = exa4.Exa4Program(_plain_repeat_program(), dict(dimensionality=3, minLevel=3, maxLevel=3), ops=OracleOps(),
+                              domain=RectDomain(3, (1, 1, 1), 0, (2, 2, 2)), fuse=False)
+    single.run()
+    for r in range(4):
+        meta = json.load(open(tmp_path / ("c%d.json" % r)))
+        assert meta["messages"] > 0
+        for x, y in zip(meta["values"], single.printed_values):
+            assert abs(x - y) <= 1e-12 * abs(y), (meta["values"], single.printed_values)

@@ -170,3 +170,20 @@ def test_field_io_round_trip_on_gpu(hip, tmp_path):
 
     P = _iotest(hip, tmp_path, level=4)
     assert P.launches >= 6
+
+
+def test_contracting_loop_on_gpu(hip):
+    """`repeat 5 times with contraction [1, 1, 1]` (node-grid reduction of the reference's Testing/PolyExpl/Jac3Dcc.exa4:1-33) on the
+    device: two two-step passes + one step per Smoother call, same bits as five plain launches, norms as the CPU ops print them."""
+    from oracle_ops import OracleOps
+    from test_exa4 import example
+
+    P = example("jacobi3d_contraction.exa4", 6, 6, ops=hip)
+    P.run()
+    plain = example("jacobi3d_contraction.exa4", 6, 6, ops=hip, fuse=False)
+    plain.run()
+    assert P.printed_values == plain.printed_values and P.launches < plain.launches
+    O = example("jacobi3d_contraction.exa4", 6, 6, ops=OracleOps(), fuse=False)
+    O.run()
+    for x, y in zip(P.printed_values, O.printed_values):
+        assert abs(x - y) <= 1e-13 * abs(y), (P.printed_values, O.printed_values)
