@@ -53,9 +53,14 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   // threadIdx.y is the same for all lanes of a wave: as a scalar it keeps row predicates and LDS row addresses on the SALU
   const int lane = threadIdx.x, wv = TS_SCALAR_WV ? __builtin_amdgcn_readfirstlane(threadIdx.y) : threadIdx.y;
   int t = blockIdx.x;
-  if (g.remap) {  // XCD-contiguous tile order (workgroups are dealt round-robin to the 8 XCDs): neighbouring tiles share an L2
+  if (g.remap == 1) {  // XCD-contiguous tile order (workgroups are dealt round-robin to the 8 XCDs): neighbouring tiles share an L2
     const int per = g.nblocks >> 3;
     if (t < (per << 3)) t = (t & 7) * per + (t >> 3);
+  } else if (g.remap == 2) {  // XCD-contiguous within every z layer of tiles: all XCDs stay in the same planes, y-neighbours share an L2
+    const int xy = g.ntx * g.nty;
+    const int lz = t / xy, r = t - lz * xy;
+    const int per = xy >> 3;
+    t = lz * xy + (r < (per << 3) ? (r & 7) * per + (r >> 3) : r);
   }
   const int tx = t % g.ntx;
   t /= g.ntx;
@@ -277,9 +282,17 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
 }
 
 // launch knobs (debug build: examg_debug_two_stage*; per host thread): workgroup count target, tile order
-static thread_local int g_ts_blocks = 3072;
+static thread_local int g_ts_blocks = -1;      // workgroup count target; -1: 8192 from 5*10^7 points, 3072 below
 static thread_local int g_ts_disable = 0;
-static thread_local int g_ts_remap = 0;
+// tile order: 0 = plain (x fastest, then y, then z chunk); 1 = one contiguous run of tiles per XCD; 2 = XCD-contiguous within every
+// z layer of tiles: workgroups are dealt round-robin to the 8 XCDs, so within a layer each XCD gets a band of y-adjacent tiles
+// (halo rows shared in its L2) while all XCDs stay in the same few planes (the z-halo planes a layer re-reads are still in the
+// Infinity Cache, DRAM sees one moving front); -1 = default (2).  tools/sweep_two_stage2.py on MI355X, red-black sweep, ms,
+// plain / per-XCD / layered at ~3072 workgroups: 256^3 0.122 / 0.095 / 0.095; 384^3 0.392 / 0.305 / 0.291; 448^3 0.495 / 0.481 / 0.417;
+// 512^3 0.714 / 0.737 / 0.698.  With the layered order more, shorter z chunks pay at 512^3 and above (16 planes per chunk):
+// 3072 / 6144 / 8192 workgroups 0.697 / 0.668 / 0.667 (plain order: 0.733 / 0.780 / -); 256^3 prefers ~3072 (0.098 vs 0.106).
+static thread_local int g_ts_remap = -1;
+static thread_local int g_ts_minzc = 16;
 // Which implementation: 5 / 8 = that many waves per workgroup; -2 = by size.
 // tools/tune_two_stage.py on MI355X, ms for a Jacobi pair / a red-black sweep (all variants bit-identical):
 //   512^3: registers 0.97 / 0.93, LDS-5 0.79 / 0.77, LDS-8 0.717 / 0.716 (3072 workgroups), LDS-9 0.87 / 0.85
@@ -300,10 +313,11 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   g.ntx = (box.n0() + g.xs + TS_OUT - 1) / TS_OUT;
   g.nty = (box.n1() + NO - 1) / NO;
   const int xy = g.ntx * g.nty;
-  int ntz = (g_ts_blocks + xy - 1) / xy;
+  const int blocks_target = g_ts_blocks > 0 ? g_ts_blocks : (box.count() >= 50000000LL ? 8192 : 3072);
+  int ntz = (blocks_target + xy - 1) / xy;
   if (ntz < 1) ntz = 1;
   int zc = (box.n2() + ntz - 1) / ntz;
-  if (zc < 16) zc = 16;
+  if (zc < g_ts_minzc) zc = g_ts_minzc;
   // the kernel addresses a workgroup's window with 32-bit element offsets: plane stride x (chunk + halo planes) must fit
   {
     const LayoutDev lbig = lu.s2 > lf.s2 ? lu : lf;
@@ -315,7 +329,7 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   g.zc = zc;
   g.ntz = (box.n2() + zc - 1) / zc;
   g.nblocks = xy * g.ntz;
-  g.remap = g_ts_remap;
+  g.remap = g_ts_remap >= 0 ? g_ts_remap : 2;
   g.first = first;
   g.box1 = box1;
   g.ax0 = -lu.ref0; g.ax1 = lu.tot0 - lu.ref0;
@@ -360,7 +374,7 @@ extern "C" int examg_debug_two_stage(int disable, int blocks, int remap, int wy)
   g_ts_disable = disable;
   if (blocks > 0) g_ts_blocks = blocks;
   if (remap >= 0) g_ts_remap = remap;
-  (void)wy;
+  if (wy > 0) g_ts_minzc = wy;      // 4th argument: minimum planes per z chunk
   return 0;
 }
 #endif

@@ -54,9 +54,11 @@ k_zm(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__r
      double w, Box box, Geo g) {
   const int lane = threadIdx.x, wv = threadIdx.y / WX, wx = threadIdx.y % WX;
   int t = blockIdx.x;
-  if (REMAP) {
-    const int per = g.nblocks >> 3;
-    if (t < (per << 3)) t = (t & 7) * per + (t >> 3);
+  if (REMAP) {   // XCD-contiguous within every z layer of tiles
+    const int xy = g.ntx * g.nty;
+    const int lz = t / xy, r = t - lz * xy;
+    const int per = xy >> 3;
+    t = lz * xy + (r < (per << 3) ? (r & 7) * per + (r >> 3) : r);
   }
   const int tx = t % g.ntx;
   t /= g.ntx;
@@ -509,6 +511,19 @@ int main(int argc, char **argv) {
   if (want("row")) {
     run_zm<2, 4, 1, false, 0>(c, 1024, "(round-1 shipped)");
     run_zm<2, 4, 1, true, 0>(c, 512, "");
+  }
+  if (want("lay")) {
+    for (int rep = 0; rep < 2; ++rep) {
+      run_zm<2, 4, 1, true, 0>(c, 512, "");
+      run_zm<2, 4, 1, true, 0, false, true>(c, 512, "layered");
+      run_zm<2, 4, 1, true, 0, false, true>(c, 1024, "layered");
+      run_zm<2, 4, 1, true, 0, false, true>(c, 2048, "layered");
+      run_zm<2, 4, 1, true, 0, false, true>(c, 4096, "layered");
+      run_zm<2, 4, 1, true, 0, false, true>(c, 8192, "layered");
+      run_zm<2, 4, 1, true, 0, false, false>(c, 8192, "");
+      run_zm<2, 2, 1, true, 0, false, true>(c, 8192, "layered");
+      run_zm<4, 4, 1, true, 0, false, true>(c, 4096, "layered");
+    }
   }
   if (want("wx")) {
     for (int rep = 0; rep < 2; ++rep) {
