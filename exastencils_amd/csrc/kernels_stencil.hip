@@ -262,6 +262,10 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
 }
 
 static thread_local int g_force_generic = 0;  // test hook (debug build only): examg_debug_force_generic
+// workgroup cap of the unrolled stencil-field kernel: none.  One short-lived workgroup per 256 points, dispatched in order, keeps
+// the front that sweeps the 30 streams (27 coefficient planes, u, rhs, dst) narrow: 512^3, 27 entries: 7.8 ms with 16384
+// grid-striding workgroups, 6.85 ms uncapped (tools/sweep_sf27.py); a tiled form with XCD-contiguous order: 7.7 ms.
+static thread_local int g_sf27_blocks = 1 << 30;
 static thread_local int g_sf27_unrolled = 1;  // examg_debug_sf27(0): 27-entry stencil fields on the generic kernel
 
 // kernels_stencilfield.hip
@@ -312,6 +316,10 @@ using namespace examg;
 // Variant selection for the parity tests (debug build libexamg_dbg.so only; per host thread)
 extern "C" int examg_debug_sf27(int unrolled) {
   g_sf27_unrolled = unrolled;
+  return 0;
+}
+extern "C" int examg_debug_sf27_blocks(int blocks) {
+  g_sf27_blocks = blocks > 0 ? blocks : (1 << 30);
   return 0;
 }
 
@@ -374,7 +382,7 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
     UOffsets uo;
     for (int k = 0; k < 27; ++k) uo.o[k] = st->off[k][0] + lu.s1 * st->off[k][1] + lu.s2 * st->off[k][2];
     long long nb27 = (box.count() + 255) / 256;
-    if (nb27 > 16384) nb27 = 16384;
+    if (nb27 > g_sf27_blocks) nb27 = g_sf27_blocks;
     dim3 grid27((unsigned)nb27), block27(256);
 #define EXAMG_SF27(M) hipLaunchKernelGGL((k_stencilfield_unrolled<M, 27>), grid27, block27, 0, s, lu, u, lf, rhs, ld, dst, lc27, st->cfield, lc27.size, uo, 0, w, box)
     if (mode == EXAMG_APPLY) EXAMG_SF27(EXAMG_APPLY);

@@ -320,7 +320,8 @@ k_prolong_add3_pairs(LayoutDev lc, const double *__restrict__ uc, LayoutDev lfin
   }
 }
 
-static thread_local int g_restrict_wide = 1;   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
+static thread_local int g_restrict_wide = 1;
+static thread_local int g_prolong_zb = 2;    // planes per workgroup of the pair prolongation (examg_debug_prolong)   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
 
 static inline dim3 grid_for(long long total) {
   long long nb = (total + 255) / 256;
@@ -334,6 +335,10 @@ static inline dim3 grid_for(long long total) {
 using namespace examg;
 
 #ifdef EXAMG_DEBUG_HOOKS
+extern "C" int examg_debug_prolong(int zb) {
+  examg::g_prolong_zb = zb > 0 ? zb : 8;
+  return 0;
+}
 extern "C" int examg_debug_restrict(int wide) {
   examg::g_restrict_wide = wide;
   return 0;
@@ -434,7 +439,7 @@ extern "C" int examg_prolong_add(const examg_layout_t *lc_, const double *uc, co
   if (lfine_->nd == 3 && box.n0() >= 32) {
     const int x0 = box.b0 & ~1;
     const int npairs = (box.e0 - x0 + 1) / 2;
-    const int zb = 8;
+    const int zb = g_prolong_zb;
     dim3 grid((npairs + 63) / 64, (box.n1() + 3) / 4, (box.n2() + zb - 1) / zb), block(64, 4, 1);
     hipLaunchKernelGGL(k_prolong_add3_pairs, grid, block, 0, s, lc, uc, lf, uf, box, x0, npairs, zb);
   } else if (lfine_->nd == 3) hipLaunchKernelGGL((k_prolong_add<3>), grid_for(box.count()), dim3(256), 0, s, lc, uc, lf, uf, box);
