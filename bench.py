@@ -160,7 +160,7 @@ def cpu_baseline(seconds: float):
 def pmc_traffic(case, level, align):
     """Fabric-side bytes per launch from the committed counter profile -- only for this kernel case, block size and layout."""
     try:
-        prof = json.load(open(PMC_PROFILE))
+        prof = json.load(open(PMC_PROFILE if not align else PMC_PROFILE.replace(".json", "_align%d.json" % align)))
     except (OSError, ValueError):
         return None
     if prof.get("level") != level or prof.get("align", 0) != align:

@@ -64,7 +64,8 @@ def main():
     cases = json.load(open(os.path.join(go, "pmcK_times_L%d%s.json" % (args.level, args.tag))))
     fetch = per_case(dispatches(os.path.join(go, "pmcK_FETCH" + args.tag), "FETCH_SIZE"), cases)
     write = per_case(dispatches(os.path.join(go, "pmcK_WRITE" + args.tag), "WRITE_SIZE"), cases)
-    out = {"note": __doc__.split("\n\n")[-1].replace("\n", " "), "level": args.level, "cells": "%d^3" % (1 << args.level), "kernels": []}
+    out = {"note": __doc__.split("\n\n")[-1].replace("\n", " "), "level": args.level, "cells": "%d^3" % (1 << args.level),
+           "align": cases[0].get("align", 0) if cases else 0, "kernels": []}
     for c, (fb, kn, nf), (wb, _, nw) in zip(cases, fetch, write):
         rec = dict(c)
         rec["kernel_name"] = kn
