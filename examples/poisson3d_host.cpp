@@ -60,12 +60,26 @@ static double *deviceZeros(size_t n) {
   return p;
 }
 
+// boundary expressions as postfix programs (the generator inlines them into the boundary kernels):
+// Field Solution's at the finest level (...exa4:24-25): x*x - 0.5*y*y - 0.5*z*z ; 0.0 everywhere else
+static examg_expr_t bcSolution, bcZero;
+static void initBoundaryExpressions() {
+  const int ops[] = {EXAMG_OP_X, EXAMG_OP_X, EXAMG_OP_MUL, EXAMG_OP_CONST, EXAMG_OP_Y, EXAMG_OP_MUL, EXAMG_OP_Y, EXAMG_OP_MUL, EXAMG_OP_SUB,
+                     EXAMG_OP_CONST, EXAMG_OP_Z, EXAMG_OP_MUL, EXAMG_OP_Z, EXAMG_OP_MUL, EXAMG_OP_SUB};
+  bcSolution = examg_expr_t{};
+  bcSolution.n = (int)(sizeof(ops) / sizeof(ops[0]));
+  for (int i = 0; i < bcSolution.n; ++i) { bcSolution.op[i] = ops[i]; bcSolution.c[i] = ops[i] == EXAMG_OP_CONST ? 0.5 : 0.0; }
+  bcZero = examg_expr_t{};
+  bcZero.n = 1;
+  bcZero.op[0] = EXAMG_OP_CONST;
+  bcZero.c[0] = 0.0;
+}
 static void applyBCsSolution(int lvl) {  // apply bc to Solution: boundary function at the finest level, 0.0 elsewhere
-  check(examg_apply_dirichlet(&L[lvl].withComm, L[lvl].Solution, &L[lvl].geom, lvl == maxLevel ? EXAMG_FN_POLY3D : EXAMG_FN_ZERO,
-                              nullptr, 63u, nullptr), "applyBCsSolution");
+  check(examg_apply_dirichlet_expr(&L[lvl].withComm, L[lvl].Solution, &L[lvl].geom, lvl == maxLevel ? &bcSolution : &bcZero, 63u, nullptr),
+        "applyBCsSolution");
 }
 static void applyBCsResidual(int lvl) {
-  check(examg_apply_dirichlet(L[lvl].resLayout, L[lvl].Residual, &L[lvl].geom, EXAMG_FN_ZERO, nullptr, 63u, nullptr), "applyBCsResidual");
+  check(examg_apply_dirichlet_expr(L[lvl].resLayout, L[lvl].Residual, &L[lvl].geom, &bcZero, 63u, nullptr), "applyBCsResidual");
 }
 static void updateResidual(int lvl) {  // communicate Solution (empty: one block); Residual = RHS - Laplace * Solution; apply bc
   Level &v = L[lvl];
@@ -141,6 +155,7 @@ int main(int argc, char **argv) {
   cgInfo = deviceZeros(4);
   checkHip(hipMalloc(&work, examg_reduce_work_bytes()), "hipMalloc");
 
+  initBoundaryExpressions();
   applyBCsSolution(maxLevel);               // Function Application (...exa4:251-277)
   // Function Solve@finest (...exa4:121-150)
   updateResidual(maxLevel);

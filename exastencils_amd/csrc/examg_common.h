@@ -79,34 +79,6 @@ int check_hip(hipError_t e, const char *what);
     if (_e != hipSuccess) return examg::check_hip(_e, name);       \
   } while (0)
 
-// Same analytic functions as oracle/examg_oracle.c:orc_eval_fn (expression trees as written in the
-// reference programs; device libm may differ from glibc in the last ulp for cos/sin/exp/sinh).
-__device__ static inline double eval_fn(int fn, const double *p, double x, double y, double z) {
-  const double PI = 3.14159265358979323846;
-  switch (fn) {
-    case EXAMG_FN_ZERO: return 0.0;
-    case EXAMG_FN_POLY3D: return ((x * x) - ((0.5 * y) * y)) - ((0.5 * z) * z);
-    case EXAMG_FN_TRIG2D_SOL: return cos(PI * x) - sin((2.0 * PI) * y);
-    case EXAMG_FN_TRIG2D_RHS: return (PI * PI) * cos(PI * x) - ((4.0 * (PI * PI)) * sin((2.0 * PI) * y));
-    case EXAMG_FN_KAPPA_POLY: return p[0] * (((x - (x * x)) * (y - (y * y))) * (z - (z * z)));
-    case EXAMG_FN_KAPPA_RHS:
-      return (2.0 * p[0]) *
-             ((((x - (x * x)) * (y - (y * y))) + ((x - (x * x)) * (z - (z * z)))) + ((y - (y * y)) * (z - (z * z))));
-    case EXAMG_FN_KAPPA_EXPSOL: return 1.0 - exp((-1.0 * p[0]) * (((x - (x * x)) * (y - (y * y))) * (z - (z * z))));
-    case EXAMG_FN_KAPPA_COEF: return exp(p[0] * (((x - (x * x)) * (y - (y * y))) * (z - (z * z))));
-    case EXAMG_FN_TRIG3D_SOL: return (sin(PI * x) * sin(PI * y)) * sinh((sqrt(2.0) * PI) * z);
-    case EXAMG_FN_SIN3: return (sin(PI * x) * sin(PI * y)) * sin(PI * z);
-    case EXAMG_FN_KAPPA_POLY2D: return p[0] * ((x - (x * x)) * (y - (y * y)));
-    case EXAMG_FN_KAPPA_RHS2D: return (2.0 * p[0]) * ((x - (x * x)) + (y - (y * y)));
-    case EXAMG_FN_KAPPA_EXPSOL2D: return 1.0 - exp((-1.0 * p[0]) * ((x - (x * x)) * (y - (y * y))));
-    case EXAMG_FN_KAPPA_COEF2D: return exp(p[0] * ((x - (x * x)) * (y - (y * y))));
-    case EXAMG_FN_POLY2D: return (x * x) - (y * y);
-    case EXAMG_FN_SINSINH2D: return sin(PI * x) * sinh(PI * y);
-    case EXAMG_FN_XSQ: return x * x;
-    default: return __builtin_nan("");
-  }
-}
-
 // Wavefront-level halo exchange: value of the neighbouring lane through DPP wave shifts (one v_mov_b32_dpp per
 // dword, no LDS crossbar round trip as with ds_bpermute / __shfl).  Lane 0 (resp. 63) keeps its own value.
 __device__ __forceinline__ double lane_below(double v) {   // lane l receives lane l-1

@@ -150,12 +150,7 @@ k_dot_rows(LayoutDev lx, const double *__restrict__ x, LayoutDev ly, const doubl
   if (threadIdx.x == 0) part[blockIdx.x] = r;
 }
 
-// A point function: one of the built-in expressions (fn id + parameters) or a postfix program (include/examg.h).
-struct FnEval {
-  int fn;
-  Params4 p;
-  __device__ __forceinline__ double operator()(double x, double y, double z) const { return eval_fn(fn, p.v, x, y, z); }
-};
+// A point function: a postfix program (include/examg.h), evaluated in the order of the expression tree.
 struct ExprEval {
   examg_expr_t e;
   __device__ double operator()(double x, double y, double z) const {
@@ -247,7 +242,7 @@ __global__ void __launch_bounds__(256) k_apply_dirichlet(LayoutDev l, double *x,
 }
 
 __global__ void __launch_bounds__(256)
-k_init_varcoeff(LayoutDev lc, double *cf, Geom g, int fn, Params4 p, Box box, int nd) {
+k_init_varcoeff(LayoutDev lc, double *cf, Geom g, ExprEval a, Box box, int nd) {
   const long long total = box.count();
   const long long plane = lc.size;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -255,11 +250,11 @@ k_init_varcoeff(LayoutDev lc, double *cf, Geom g, int fn, Params4 p, Box box, in
     unflatten(box, t, i0, i1, i2);
     const double x = i0 * g.h0 + g.pb0, y = i1 * g.h1 + g.pb1, z = i2 * g.h2 + g.pb2;
     const double hx = g.h0, hy = g.h1, hz = g.h2;
-    const double axp = eval_fn(fn, p.v, x + (0.5 * hx), y, z), axm = eval_fn(fn, p.v, x - (0.5 * hx), y, z);
-    const double ayp = eval_fn(fn, p.v, x, y + (0.5 * hy), z), aym = eval_fn(fn, p.v, x, y - (0.5 * hy), z);
+    const double axp = a(x + (0.5 * hx), y, z), axm = a(x - (0.5 * hx), y, z);
+    const double ayp = a(x, y + (0.5 * hy), z), aym = a(x, y - (0.5 * hy), z);
     const long long k = lidx(lc, i0, i1, i2);
     if (nd == 3) {
-      const double azp = eval_fn(fn, p.v, x, y, z + (0.5 * hz)), azm = eval_fn(fn, p.v, x, y, z - (0.5 * hz));
+      const double azp = a(x, y, z + (0.5 * hz)), azm = a(x, y, z - (0.5 * hz));
       cf[k + 0 * plane] = (((axp + axm) / (hx * hx)) + ((ayp + aym) / (hy * hy))) + ((azp + azm) / (hz * hz));
       cf[k + 1 * plane] = (-1.0 * axp) / (hx * hx);
       cf[k + 2 * plane] = (-1.0 * axm) / (hx * hx);
@@ -465,21 +460,10 @@ static bool expr_ok(const examg_expr_t *e) {
   return true;
 }
 
-extern "C" int examg_max_err_fn(const examg_layout_t *l_, const double *x, const examg_geom_t *g, int fn,
-                                const double *params, const int32_t *begin, const int32_t *end, double *result,
-                                void *work, examg_stream_t stream) {
-  return max_err_impl("k_maxerr", l_, x, g, FnEval{fn, make_params(params)}, begin, end, result, work, stream);
-}
-
 extern "C" int examg_max_err_expr(const examg_layout_t *l_, const double *x, const examg_geom_t *g, const examg_expr_t *e,
                                   const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream) {
   if (!expr_ok(e)) return 1;
   return max_err_impl("k_maxerr_expr", l_, x, g, ExprEval{*e}, begin, end, result, work, stream);
-}
-
-extern "C" int examg_fill_fn(const examg_layout_t *l_, double *x, const examg_geom_t *g, int fn, const double *params,
-                             const int32_t *begin, const int32_t *end, examg_stream_t stream) {
-  return fill_impl("k_fill_fn", l_, x, g, FnEval{fn, make_params(params)}, begin, end, stream);
 }
 
 extern "C" int examg_fill_expr(const examg_layout_t *l_, double *x, const examg_geom_t *g, const examg_expr_t *e,
@@ -488,25 +472,20 @@ extern "C" int examg_fill_expr(const examg_layout_t *l_, double *x, const examg_
   return fill_impl("k_fill_expr", l_, x, g, ExprEval{*e}, begin, end, stream);
 }
 
-extern "C" int examg_apply_dirichlet(const examg_layout_t *l, double *x, const examg_geom_t *g, int fn,
-                                     const double *params, uint32_t face_mask, examg_stream_t stream) {
-  return dirichlet_impl("k_apply_dirichlet", l, x, g, FnEval{fn, make_params(params)}, face_mask, stream);
-}
-
 extern "C" int examg_apply_dirichlet_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, const examg_expr_t *e,
                                           uint32_t face_mask, examg_stream_t stream) {
   if (!expr_ok(e)) return 1;
   return dirichlet_impl("k_apply_dirichlet_expr", l, x, g, ExprEval{*e}, face_mask, stream);
 }
 
-extern "C" int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,
-                                    const double *params, const int32_t *begin, const int32_t *end,
-                                    examg_stream_t stream) {
+extern "C" int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, const examg_expr_t *a,
+                                    const int32_t *begin, const int32_t *end, examg_stream_t stream) {
   if (!lc || !cfield || !g || !begin || !end) { set_error("examg_init_varcoeff7: null argument"); return 1; }
+  if (!expr_ok(a)) return 1;
   const Box box = make_box(begin, end);
   if (box.count() == 0) return 0;
   if (!box_inside(lc, box, 0)) { set_error("examg_init_varcoeff7: box leaves the allocation"); return 1; }
-  hipLaunchKernelGGL(k_init_varcoeff, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(lc), cfield, make_geom(g), coef_fn, make_params(params), box, lc->nd);
+  hipLaunchKernelGGL(k_init_varcoeff, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(lc), cfield, make_geom(g), ExprEval{*a}, box, lc->nd);
   EXAMG_CHECK_LAUNCH("k_init_varcoeff");
   return 0;
 }
@@ -580,10 +559,9 @@ extern "C" int examg_copy_from_external(const examg_layout_t *l_ext, const doubl
 // ---- config 4: 27-entry stencil field of -div(a grad u) - k^2 u (trilinear elements, lumped mass); same expression
 // order as oracle/examg_oracle.c:orc_init_helmholtz27 ----------------------------------------------------------
 namespace examg {
-__global__ void __launch_bounds__(256) k_init_helmholtz27(LayoutDev lc, double *cf, Geom g, int fn, Params4 p, Box box) {
+__global__ void __launch_bounds__(256) k_init_helmholtz27(LayoutDev lc, double *cf, Geom g, ExprEval a, double ksq, Box box) {
   const long long total = box.count();
   const long long plane = lc.size;
-  const double ksq = p.v[1];
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     int i0, i1, i2;
     unflatten(box, t, i0, i1, i2);
@@ -596,7 +574,7 @@ __global__ void __launch_bounds__(256) k_init_helmholtz27(LayoutDev lc, double *
       for (int sy = 0; sy < 2; ++sy)
 #pragma unroll
         for (int sz = 0; sz < 2; ++sz)
-          ae[sx][sy][sz] = eval_fn(fn, p.v, x + (sx ? 0.5 : -0.5) * h, y + (sy ? 0.5 : -0.5) * h, z + (sz ? 0.5 : -0.5) * h);
+          ae[sx][sy][sz] = a(x + (sx ? 0.5 : -0.5) * h, y + (sy ? 0.5 : -0.5) * h, z + (sz ? 0.5 : -0.5) * h);
     const long long k = lidx(lc, i0, i1, i2);
     int ent = 1;
 #pragma unroll
@@ -627,15 +605,15 @@ __global__ void __launch_bounds__(256) k_init_helmholtz27(LayoutDev lc, double *
 }
 }  // namespace examg
 
-extern "C" int examg_init_helmholtz27(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,
-                                      const double *params, const int32_t *begin, const int32_t *end,
-                                      examg_stream_t stream) {
+extern "C" int examg_init_helmholtz27(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, const examg_expr_t *a,
+                                      double ksq, const int32_t *begin, const int32_t *end, examg_stream_t stream) {
   if (!lc || !cfield || !g || !begin || !end) { set_error("examg_init_helmholtz27: null argument"); return 1; }
+  if (!expr_ok(a)) return 1;
   if (lc->nd != 3) { set_error("examg_init_helmholtz27: 3-D only"); return 1; }
   const Box box = make_box(begin, end);
   if (box.count() == 0) return 0;
   if (!box_inside(lc, box, 0)) { set_error("examg_init_helmholtz27: box leaves the allocation"); return 1; }
-  hipLaunchKernelGGL(examg::k_init_helmholtz27, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(lc), cfield, make_geom(g), coef_fn, make_params(params), box);
+  hipLaunchKernelGGL(examg::k_init_helmholtz27, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(lc), cfield, make_geom(g), examg::ExprEval{*a}, ksq, box);
   EXAMG_CHECK_LAUNCH("k_init_helmholtz27");
   return 0;
 }

@@ -14,7 +14,10 @@ from typing import List, Optional, Sequence, Tuple
 from .layout import FieldLayout
 from .lib import StencilC
 
-# analytic function ids (include/examg.h)
+# Named point functions of the reference's programs (boundary values, right-hand sides, exact solutions, coefficient profiles).
+# They are HOST-side names only: the library knows expression programs (examg_expr_t) and nothing else -- FN_PROGRAMS below
+# spells each one as the postfix program of the expression tree written in the reference program (same tree as the oracle's
+# orc_eval_fn, hence the same bits up to libm).
 FN_ZERO, FN_POLY3D, FN_TRIG2D_SOL, FN_TRIG2D_RHS, FN_KAPPA_POLY, FN_KAPPA_RHS = 0, 1, 2, 3, 4, 5
 FN_KAPPA_EXPSOL, FN_KAPPA_COEF, FN_TRIG3D_SOL, FN_SIN3 = 6, 7, 8, 9
 FN_KAPPA_POLY2D, FN_KAPPA_RHS2D, FN_KAPPA_EXPSOL2D, FN_KAPPA_COEF2D = 10, 11, 12, 13
@@ -124,3 +127,77 @@ def stencil_field_offsets(nd: int) -> List[Tuple[int, int, int]]:
 def helmholtz27_offsets() -> List[Tuple[int, int, int]]:
     """Entry order of the 27-entry stencil field of examg_init_helmholtz27: centre first, then (dx,dy,dz) lexicographic."""
     return [(0, 0, 0)] + [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if (a, b, c) != (0, 0, 0)]
+
+
+def _fn_program(fn: int, p0: float):
+    """Postfix program [(op, const)] of named point function `fn`; p0 = kappa of the SISC / FMG programs' `Globals { Val kappa }`."""
+    import math
+
+    PI = math.pi
+    X, Y, Z = ("x", None), ("y", None), ("z", None)
+
+    def c(v):
+        return ("const", float(v))
+
+    def mul(a, b):
+        return a + b + [("*", None)]
+
+    def add(a, b):
+        return a + b + [("+", None)]
+
+    def sub_(a, b):
+        return a + b + [("-", None)]
+
+    def call(name, a):
+        return a + [(name, None)]
+
+    def bump(v):                       # (v - (v * v))
+        return sub_([v], mul([v], [v]))
+
+    xyz = mul(mul(bump(X), bump(Y)), bump(Z))               # ((x - x^2) * (y - y^2)) * (z - z^2)
+    xy = mul(bump(X), bump(Y))
+    table = {
+        FN_ZERO: lambda: [c(0.0)],
+        # ( x * x ) - ( ( 0.5 * y ) * y ) - ( ( 0.5 * z ) * z )                 Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:25
+        FN_POLY3D: lambda: sub_(sub_(mul([X], [X]), mul(mul([c(0.5)], [Y]), [Y])), mul(mul([c(0.5)], [Z]), [Z])),
+        # cos ( PI * x ) - sin ( ( 2.0 * PI ) * y )                              Examples/Poisson/2D_FD_Poisson_fromL4.exa4:26
+        FN_TRIG2D_SOL: lambda: sub_(call("cos", mul([c(PI)], [X])), call("sin", mul([c(2.0 * PI)], [Y]))),
+        # ( PI * PI ) * cos ( PI * x ) - ( ( 4.0 * ( PI * PI ) ) * sin ( ( 2.0 * PI ) * y ) )      ...exa4:233
+        FN_TRIG2D_RHS: lambda: sub_(mul([c(PI * PI)], call("cos", mul([c(PI)], [X]))),
+                                    mul([c(4.0 * (PI * PI))], call("sin", mul([c(2.0 * PI)], [Y])))),
+        FN_KAPPA_POLY: lambda: mul([c(p0)], xyz),                                                   # Testing/SISC/3D_ConstCoeff.exa4:43
+        FN_KAPPA_RHS: lambda: mul([c(2.0 * p0)], add(add(mul(bump(X), bump(Y)), mul(bump(X), bump(Z))), mul(bump(Y), bump(Z)))),
+        FN_KAPPA_EXPSOL: lambda: sub_([c(1.0)], call("exp", mul([c(-1.0 * p0)], xyz))),            # Testing/SISC/3D_VarCoeff.exa4:48
+        FN_KAPPA_COEF: lambda: call("exp", mul([c(p0)], xyz)),
+        # ( sin ( PI * x ) * sin ( PI * y ) ) * sinh ( ( sqrt ( 2.0 ) * PI ) * z )                 Testing/FMG/3D_Trigonometric.exa4:43
+        FN_TRIG3D_SOL: lambda: mul(mul(call("sin", mul([c(PI)], [X])), call("sin", mul([c(PI)], [Y]))),
+                                   call("sinh", mul([c(math.sqrt(2.0) * PI)], [Z]))),
+        FN_SIN3: lambda: mul(mul(call("sin", mul([c(PI)], [X])), call("sin", mul([c(PI)], [Y]))), call("sin", mul([c(PI)], [Z]))),
+        FN_KAPPA_POLY2D: lambda: mul([c(p0)], xy),
+        FN_KAPPA_RHS2D: lambda: mul([c(2.0 * p0)], add(bump(X), bump(Y))),
+        FN_KAPPA_EXPSOL2D: lambda: sub_([c(1.0)], call("exp", mul([c(-1.0 * p0)], xy))),
+        FN_KAPPA_COEF2D: lambda: call("exp", mul([c(p0)], xy)),
+        FN_POLY2D: lambda: sub_(mul([X], [X]), mul([Y], [Y])),                                      # Testing/BC/2D_Polynomial.exa4:43
+        FN_SINSINH2D: lambda: mul(call("sin", mul([c(PI)], [X])), call("sinh", mul([c(PI)], [Y]))),  # Testing/BC/2D_Trigonometric.exa4:43
+        FN_XSQ: lambda: mul([X], [X]),                                                               # Testing/BC/2D_Periodic.exa4:43
+    }
+    if fn not in table:
+        raise ValueError("unknown point function id %r" % (fn,))
+    return table[fn]()
+
+
+_FN_EXPR_CACHE = {}
+
+
+def fn_expr(fn, params=()):
+    """examg_expr_t of a named point function (or `fn` itself when it already is an expression program)."""
+    from .lib import ExprC
+
+    if not isinstance(fn, int):
+        return fn
+    p0 = float(params[0]) if len(params) else 0.0
+    key = (int(fn), p0)
+    e = _FN_EXPR_CACHE.get(key)
+    if e is None:
+        e = _FN_EXPR_CACHE[key] = ExprC.from_program(_fn_program(int(fn), p0))
+    return e

@@ -11,8 +11,8 @@ import ctypes as C
 from typing import Optional, Sequence
 
 from . import lib as _lib
-from .field import Stencil
-from .lib import ExamgError, check, dvec4, ivec
+from .field import Stencil, fn_expr
+from .lib import ExamgError, check, ivec
 
 
 class HipOps:
@@ -133,9 +133,7 @@ class HipOps:
 
     def max_err_fn(self, l, x, geom, fn: int, params: Sequence[float], begin, end, out=None):
         out = self.new_scalar() if out is None else out
-        check(self.L.examg_max_err_fn(C.byref(l), self.ptr(x), C.byref(geom), int(fn), dvec4(params), ivec(begin),
-                                      ivec(end), self.ptr(out), self.ptr(self._work), self._stream()), "examg_max_err_fn")
-        return out
+        return self.max_err_expr(l, x, geom, fn_expr(fn, params), begin, end, out)
 
     def max_err_expr(self, l, x, geom, expr, begin, end, out=None):
         out = self.new_scalar() if out is None else out
@@ -157,19 +155,18 @@ class HipOps:
 
     # -- boundary / init ----------------------------------------------------------------------------
     def fill_fn(self, l, x, geom, fn: int, params: Sequence[float], begin, end):
-        check(self.L.examg_fill_fn(C.byref(l), self.ptr(x), C.byref(geom), int(fn), dvec4(params), ivec(begin), ivec(end),
-                                   self._stream()), "examg_fill_fn")
+        self.fill_expr(l, x, geom, fn_expr(fn, params), begin, end)
 
     def apply_dirichlet(self, l, x, geom, fn: int, params: Sequence[float], face_mask: int):
-        check(self.L.examg_apply_dirichlet(C.byref(l), self.ptr(x), C.byref(geom), int(fn), dvec4(params), int(face_mask),
-                                           self._stream()), "examg_apply_dirichlet")
+        self.apply_dirichlet_expr(l, x, geom, fn_expr(fn, params), face_mask)
 
     def init_varcoeff7(self, lc, cf, geom, coef_fn: int, params: Sequence[float], begin, end):
-        check(self.L.examg_init_varcoeff7(C.byref(lc), self.ptr(cf), C.byref(geom), int(coef_fn), dvec4(params),
+        check(self.L.examg_init_varcoeff7(C.byref(lc), self.ptr(cf), C.byref(geom), C.byref(fn_expr(coef_fn, params)),
                                           ivec(begin), ivec(end), self._stream()), "examg_init_varcoeff7")
 
     def init_helmholtz27(self, lc, cf, geom, coef_fn: int, params: Sequence[float], begin, end):
-        check(self.L.examg_init_helmholtz27(C.byref(lc), self.ptr(cf), C.byref(geom), int(coef_fn), dvec4(params),
+        prm = list(params) + [0.0, 0.0]
+        check(self.L.examg_init_helmholtz27(C.byref(lc), self.ptr(cf), C.byref(geom), C.byref(fn_expr(coef_fn, params)), float(prm[1]),
                                             ivec(begin), ivec(end), self._stream()), "examg_init_helmholtz27")
 
     # -- halo ------------------------------------------------------------------------------------------

@@ -70,33 +70,8 @@ typedef struct examg_geom {
 
 typedef void *examg_stream_t; /* hipStream_t */
 
-/* `params` arguments below: HOST pointer to 4 doubles (params[0] = kappa of the SISC/FMG
- * programs' `Globals { Val kappa }`), or NULL for all-zero. */
-
 /* stencil loop kinds */
 enum { EXAMG_APPLY = 0, EXAMG_RESIDUAL = 1, EXAMG_SMOOTH = 2 };
-
-/* analytic functions of the reference programs (boundary values, RHS, exact solutions,
- * coefficient profiles); ids shared with oracle/examg_oracle.c */
-enum {
-  EXAMG_FN_ZERO = 0,
-  EXAMG_FN_POLY3D = 1,       /* x^2 - y^2/2 - z^2/2        Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:25 */
-  EXAMG_FN_TRIG2D_SOL = 2,   /* cos(pi x) - sin(2 pi y)     Examples/Poisson/2D_FD_Poisson_fromL4.exa4:26 */
-  EXAMG_FN_TRIG2D_RHS = 3,   /* pi^2 cos(pi x) - 4 pi^2 sin(2 pi y)   ...exa4:233 */
-  EXAMG_FN_KAPPA_POLY = 4,   /* kappa (x-x^2)(y-y^2)(z-z^2)           Testing/SISC/3D_ConstCoeff.exa4:43 */
-  EXAMG_FN_KAPPA_RHS = 5,    /* Testing/SISC/3D_VarCoeff.exa4 InitRHS */
-  EXAMG_FN_KAPPA_EXPSOL = 6, /* 1 - exp(-kappa (..))                  Testing/SISC/3D_VarCoeff.exa4:48 */
-  EXAMG_FN_KAPPA_COEF = 7,   /* exp(kappa (..))                       Testing/SISC/3D_VarCoeff.exa4 getCoefficient */
-  EXAMG_FN_TRIG3D_SOL = 8,   /* sin(pi x) sin(pi y) sinh(sqrt2 pi z)  Testing/FMG/3D_Trigonometric.exa4:43 */
-  EXAMG_FN_SIN3 = 9,
-  EXAMG_FN_KAPPA_POLY2D = 10,
-  EXAMG_FN_KAPPA_RHS2D = 11,
-  EXAMG_FN_KAPPA_EXPSOL2D = 12,
-  EXAMG_FN_KAPPA_COEF2D = 13,
-  EXAMG_FN_POLY2D = 14,      /* x*x - y*y                 (Testing/BC/2D_Polynomial.exa4:43) */
-  EXAMG_FN_SINSINH2D = 15,   /* sin(PI x) * sinh(PI y)    (Testing/BC/2D_Trigonometric.exa4:43) */
-  EXAMG_FN_XSQ = 16          /* x*x                       (Testing/BC/2D_Periodic.exa4:43) */
-};
 
 int examg_version(void);
 const char *examg_last_error(void);
@@ -215,10 +190,10 @@ int examg_axpby_dev(const examg_layout_t *lx, const double *x, const examg_layou
 size_t examg_reduce_work_bytes(void);
 int examg_dot(const examg_layout_t *lx, const double *x, const examg_layout_t *ly, const double *y,
               const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream);
-int examg_max_err_fn(const examg_layout_t *l, const double *x, const examg_geom_t *g, int fn, const double *params,
-                     const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream);
 
-/* ---- analytic expressions as stack programs ------------------------------------------------------------------------
+/* ---- analytic expressions as stack programs: the ONE mechanism for boundary values, right-hand sides, exact solutions and
+ * coefficient profiles (round 1 also had 17 built-in function ids of the reference's test programs; they are gone -- the same
+ * expression trees now travel as programs, exastencils_amd/field.py:FN_PROGRAMS) --------------------------------------- ------------------------------------------------------------------------
  * The generator inlines whatever expression a program gives for boundary values, right-hand sides and exact solutions
  * into the loop body (boundary/ir/IR_DirichletBC.scala:37-40; `loop over RHS { RHS = <expr> }`).  A library cannot be
  * recompiled per program, so an expression over the node position travels as a postfix program that a generic kernel
@@ -237,32 +212,29 @@ typedef struct {
   double c[EXAMG_MAX_EXPR];
 } examg_expr_t;
 
-/* As examg_fill_fn / examg_apply_dirichlet / examg_max_err_fn with the function given as an expression program. */
+/* x[box] = e(node position): InitRHS, SetFuncDir, `loop over F { F = <expr> }`. */
 int examg_fill_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, const examg_expr_t *e, const int32_t *begin,
                     const int32_t *end, examg_stream_t stream);
+/* All faces of `apply bc` in one launch (boundary/ir/IR_DirichletBC.scala:37-40 over the ranges of
+ * boundary/ir/IR_ApplyBCFunction.scala:53-83): face_mask bit (2*d + (side>0)) set => that face has no neighbour
+ * (IR_IV_NeighborIsValid false) and gets its duplicate plane, tangentially GLB..GRE, set to e(node position). */
 int examg_apply_dirichlet_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, const examg_expr_t *e,
                                uint32_t face_mask, examg_stream_t stream);
+/* max |x - e(node position)| over the box (`loop over F with reduction(max : err)`); result in device memory */
 int examg_max_err_expr(const examg_layout_t *l, const double *x, const examg_geom_t *g, const examg_expr_t *e,
                        const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream);
 
-/* ---- K8: x[box] = fn(node position): Dirichlet faces (boundary/ir/IR_DirichletBC.scala:37-40 over
- * the ranges of boundary/ir/IR_ApplyBCFunction.scala:53-83), InitRHS, SetFuncDir. */
-int examg_fill_fn(const examg_layout_t *l, double *x, const examg_geom_t *g, int fn, const double *params,
-                  const int32_t *begin, const int32_t *end, examg_stream_t stream);
-/* All faces of `apply bc` in one launch: face_mask bit (2*d + (side>0)) set => that face has no
- * neighbour (IR_IV_NeighborIsValid false) and gets its duplicate plane, tangentially GLB..GRE, set. */
-int examg_apply_dirichlet(const examg_layout_t *l, double *x, const examg_geom_t *g, int fn, const double *params,
-                          uint32_t face_mask, examg_stream_t stream);
-/* Stencil-field initialisation of Testing/SISC/3D_VarCoeff.exa4:206-217 (2*nd+1 entries). */
-int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,
-                         const double *params, const int32_t *begin, const int32_t *end, examg_stream_t stream);
+/* ---- stencil-field initialisation.  Testing/SISC/3D_VarCoeff.exa4:206-217 (2*nd+1 entries): -div(a grad u) with the
+ * coefficient expression `a` evaluated half a mesh width to either side of the node. */
+int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, const examg_expr_t *a,
+                         const int32_t *begin, const int32_t *end, examg_stream_t stream);
 
 /* 27-entry stencil field of -div(a grad u) - k^2 u (BASELINE.json config 4): trilinear elements with element-wise
- * constant a = coef_fn(element centre), lumped mass, scaled by 1/h^3; params[0] = kappa of the profile, params[1] = k^2.
+ * constant a = a(element centre) (expression program), lumped mass, scaled by 1/h^3; ksq = k^2.
  * Entry order: (0,0,0), then (dx,dy,dz) lexicographic with dx slowest.  The stencil-field mechanism is the reference's
  * (stencil/ir/IR_StencilConvolution.scala:73-95); the reference itself ships 2d+1-entry fields only. */
-int examg_init_helmholtz27(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, int coef_fn,
-                           const double *params, const int32_t *begin, const int32_t *end, examg_stream_t stream);
+int examg_init_helmholtz27(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, const examg_expr_t *a, double ksq,
+                           const int32_t *begin, const int32_t *end, examg_stream_t stream);
 
 /* ---- K9: halo pack / unpack (communication/ir/IR_NoInterpPacking.scala:53-83): box <-> contiguous
  * buffer, x fastest; ranges from IR_PackInfoDuplicate.scala:15-39 / IR_PackInfoGhost.scala:13-60. */

@@ -507,8 +507,13 @@ def _ulp_close(a, b, ulps=4):
     return np.all(np.abs(a - b) <= ulps * np.spacing(scale))
 
 
-@pytest.mark.parametrize("fn,nd,exact", [(FN_POLY3D, 3, True), (FN_TRIG2D_SOL, 2, False), (FN_KAPPA_RHS, 3, True),
-                                         (FN_KAPPA_EXPSOL, 3, False), (FN_TRIG3D_SOL, 3, False), (14, 2, True), (15, 2, False)])
+# All 17 named point functions of the reference's programs.  The library knows expression programs only (examg_expr_t;
+# exastencils_amd/field.py:FN_PROGRAMS spells each function as the postfix program of its expression tree); the oracle keeps
+# its own closed forms (orc_eval_fn).  Polynomial ones must agree bit for bit, those through libm within a few ulp.
+@pytest.mark.parametrize("fn,nd,exact", [(0, 3, True), (FN_POLY3D, 3, True), (FN_TRIG2D_SOL, 2, False), (3, 2, False), (4, 3, True),
+                                         (FN_KAPPA_RHS, 3, True), (FN_KAPPA_EXPSOL, 3, False), (7, 3, False), (FN_TRIG3D_SOL, 3, False),
+                                         (9, 3, False), (10, 2, True), (11, 2, True), (12, 2, False), (13, 2, False), (14, 2, True),
+                                         (15, 2, False), (16, 2, True)])
 def test_fill_fn_and_dirichlet(hip, orc, fn, nd, exact):
     n = 24
     shape = tuple(n if d < nd else 0 for d in range(3))
