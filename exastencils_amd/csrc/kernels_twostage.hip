@@ -289,7 +289,7 @@ static thread_local int g_ts_disable = 0;
 // (halo rows shared in its L2) while all XCDs stay in the same few planes (the z-halo planes a layer re-reads are still in the
 // Infinity Cache, DRAM sees one moving front); -1 = default (2).  tools/sweep_two_stage2.py on MI355X, red-black sweep, ms,
 // plain / per-XCD / layered at ~3072 workgroups: 256^3 0.122 / 0.095 / 0.095; 384^3 0.392 / 0.305 / 0.291; 448^3 0.495 / 0.481 / 0.417;
-// 512^3 0.714 / 0.737 / 0.698.  With the layered order more, shorter z chunks pay at 512^3 and above (16 planes per chunk):
+// 512^3 0.714 / 0.737 / 0.698.  Plain (cached) instead of non-temporal stores with the layered order: 0.703 against 0.670 ms.  With the layered order more, shorter z chunks pay at 512^3 and above (16 planes per chunk):
 // 3072 / 6144 / 8192 workgroups 0.697 / 0.668 / 0.667 (plain order: 0.733 / 0.780 / -); 256^3 prefers ~3072 (0.098 vs 0.106).
 static thread_local int g_ts_remap = -1;
 static thread_local int g_ts_minzc = 16;

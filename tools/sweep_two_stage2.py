@@ -12,7 +12,7 @@ from exastencils_amd.ops import HipOps
 ops = HipOps(0, lib.DBG_LIB_PATH)
 L = ops.L
 L.examg_debug_two_stage.argtypes = [C.c_int] * 4
-for n in (256, 512, 640):
+for n in (256, 512):
     lu, lf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0)
     u, un, f = ops.new_array(lu.size), ops.new_array(lu.size), ops.new_array(lf.size)
     ops.fill_random(u, 1); ops.fill_random(f, 2)
@@ -20,9 +20,9 @@ for n in (256, 512, 640):
     w = 0.8 / A.diag
     b, e = [1, 1, 1], [n, n, n]
     Ls, Fs = lu.c_struct(), lf.c_struct()
-    for blocks, minzc in ((3072, 16), (6144, 16), (8192, 16), (8192, 12), (8192, 8), (12288, 8), (16384, 8), (16384, 6), (32768, 4)):
+    for blocks, minzc in ((0, 16), (0, -1), (0, 16), (0, -1)):
         for remap in (2,):
-            L.examg_debug_two_stage(0, blocks, remap, minzc)
+            L.examg_debug_two_stage(0, blocks, -1, minzc)
             fn = lambda: ops.rbgs_sweep_fused(Ls, u, un, Fs, f, A, w, 0, b, e)
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
