@@ -279,6 +279,35 @@ class Communicator:
                 buf.copy_(wire)
             ops.unpack(f.lc, x, buf, box[0], box[1])
 
+    def c_pass(self, kind: str, S: Field, u_in, u_out, tmp, F: Field, A, w: float, first: int, begin, end, axis_only: bool, overlap: bool):
+        """One overlapped smoother pass on a block with neighbours as ONE library call (examg_jacobi2_blocks /
+        examg_rbgs_sweep_blocks: interior two-stage kernel on the launch stream, exchanges and shell launches on the
+        communicator's side stream).  Only with the C transport; True if the call was made."""
+        if self._c is None or not (S.layout.communicates_ghost and max(S.layout.ghost) > 0):
+            return False
+        import ctypes as C
+
+        from . import lib as _lib
+
+        ops, L = self.ops, self.ops.L
+        key = (S.layout,)
+        ws = self._ws.get(key)
+        nbytes = int(L.examg_exchange_workspace_bytes(C.byref(S.lc)))
+        if ws is None:
+            ws = self._ws[key] = ops.new_array(max(1, nbytes // 8))
+        flags = _lib.EXCH_CONCURRENT_AXES if (self.concurrent_ghost_axes and axis_only) else 0
+        sc = A.c_struct(ops.ptr)
+        if kind == "jacobi2":
+            rc = L.examg_jacobi2_blocks(self._c, C.byref(self._nb), C.byref(S.lc), ops.ptr(u_in), ops.ptr(u_out), ops.ptr(tmp), C.byref(F.lc),
+                                        ops.ptr(F.data()), C.byref(sc), float(w), _lib.ivec(begin), _lib.ivec(end), flags, ops.ptr(ws), nbytes,
+                                        1 if overlap else 0, ops._stream())
+        else:
+            rc = L.examg_rbgs_sweep_blocks(self._c, C.byref(self._nb), C.byref(S.lc), ops.ptr(u_in), ops.ptr(u_out), ops.ptr(tmp), C.byref(F.lc),
+                                           ops.ptr(F.data()), C.byref(sc), float(w), int(first), _lib.ivec(begin), _lib.ivec(end), flags,
+                                           ops.ptr(ws), nbytes, 1 if overlap else 0, ops._stream())
+        _lib.check(rc, "examg_%s_blocks" % ("jacobi2" if kind == "jacobi2" else "rbgs_sweep"))
+        return True
+
     # -- reductions across blocks -------------------------------------------------------------------
     def allreduce(self, t, op: str = "sum"):
         """MPI_Allreduce(MPI_IN_PLACE, &x, 1, MPI_DOUBLE, op) on a device scalar."""

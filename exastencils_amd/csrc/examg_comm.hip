@@ -84,6 +84,8 @@ struct examg_comm {
   ncclComm_t nccl = nullptr;   // null for a one-rank communicator created without RCCL
   int rank = 0, size = 1;
   bool self_via_rccl = false;  // periodic self-exchange through ncclSend/ncclRecv to the own rank (one-GPU test of the transport)
+  hipStream_t side = nullptr;  // second stream and fork / join events of the overlapped smoother passes (created on first use)
+  hipEvent_t fork = nullptr, join = nullptr;
 };
 
 static_assert(sizeof(ncclUniqueId) == EXAMG_COMM_ID_BYTES, "EXAMG_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
@@ -120,6 +122,9 @@ extern "C" int examg_comm_destroy(examg_comm_t *comm) {
   if (!comm) return 0;
   int rc = 0;
   if (comm->nccl) rc = check_nccl(g_rccl.CommDestroy(comm->nccl), "ncclCommDestroy");
+  if (comm->fork) (void)hipEventDestroy(comm->fork);
+  if (comm->join) (void)hipEventDestroy(comm->join);
+  if (comm->side) (void)hipStreamDestroy(comm->side);
   delete comm;
   return rc;
 }
@@ -365,4 +370,166 @@ extern "C" int examg_allgather(examg_comm_t *comm, const double *send, double *r
   }
   if (!comm->nccl) { set_error("examg_allgather: communicator has no RCCL handle"); return 1; }
   return check_nccl(g_rccl.AllGather(send, recv, (size_t)n, ncclDouble, comm->nccl, (hipStream_t)stream), "ncclAllGather");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Smoother passes on a block WITH neighbours, halo traffic overlapped with the interior kernel (the reference's core / boundary
+// split, baseExt/ir/IR_LoopOverPointsInOneFragment.scala:143-222, applied to a pair of dependent sweeps): one C call per pass.
+//
+//   launch stream   fused two-stage kernel on the loop's box shrunk by 1 (first stage) / 2 (second stage) at interior faces: reads
+//                   no ghost value, starts at once
+//   side stream     1. exchange ghost layers of u_in                            (as the smoother's `communicate` does)
+//                   2. first stage on the three planes next to every interior face, into tmp          (thin launches)
+//                   3. exchange ghost layers of tmp                             (the neighbours' first-stage values)
+//                   4. second stage on the two planes next to every interior face, into u_out         (thin launches)
+//   join            events; the launch stream continues when both are done
+//
+// Two exchanges per pass -- as many as the two plain loops have -- and results bit-identical to them.  tmp: scratch array of
+// u's layout.  Its duplicate planes on PHYSICAL faces are read tangentially by step 4 and written by nobody: they are copied
+// from u_in each time.  When the one-pass kernel is not eligible (examg_two_stage_eligible: other stencils or entry orders,
+// short rows) everything runs in sequence on the launch stream (the fallback uses tmp as its own scratch).
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// side stream and events live in the communicator (created on first use; a communicator belongs to one host thread and one device)
+typedef examg_comm Overlap;
+Overlap *overlap_of(examg_comm_t *c) {
+  if (!c->side) {
+    if (check_hip(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    if (check_hip(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming), "hipEventCreate")) return nullptr;
+    if (check_hip(hipEventCreateWithFlags(&c->join, hipEventDisableTiming), "hipEventCreate")) return nullptr;
+  }
+  return c;
+}
+
+struct Faces {
+  int n;
+  int d[6], side[6];
+};
+
+Faces interior_faces(const examg_layout_t *l, const examg_neighbors_t *nb) {
+  Faces f;
+  f.n = 0;
+  for (int d = 0; d < l->nd; ++d)
+    for (int s = 0; s < 2; ++s)
+      if (nb->rank[d][s] >= 0) { f.d[f.n] = d; f.side[f.n] = s ? +1 : -1; ++f.n; }
+  return f;
+}
+
+void shrunk(const Faces &f, const int32_t *b, const int32_t *e, int k, int32_t *bb, int32_t *ee) {
+  for (int d = 0; d < 3; ++d) { bb[d] = b[d]; ee[d] = e[d]; }
+  for (int i = 0; i < f.n; ++i) {
+    if (f.side[i] < 0) bb[f.d[i]] = b[f.d[i]] + k;
+    else ee[f.d[i]] = e[f.d[i]] - k;
+  }
+}
+
+void slab(const int32_t *b, const int32_t *e, int d, int side, int k, int32_t *sb, int32_t *se) {
+  for (int t = 0; t < 3; ++t) { sb[t] = b[t]; se[t] = e[t]; }
+  if (side < 0) se[d] = b[d] + k < e[d] ? b[d] + k : e[d];
+  else sb[d] = e[d] - k > b[d] ? e[d] - k : b[d];
+}
+
+// tmp's duplicate planes on physical faces <- u_in's
+int copy_physical_planes(const examg_layout_t *l, const examg_neighbors_t *nb, const double *src, double *tmp, hipStream_t s) {
+  for (int d = 0; d < l->nd; ++d)
+    for (int sd = 0; sd < 2; ++sd) {
+      if (nb->rank[d][sd] >= 0) continue;
+      int32_t pb[3] = {0, 0, 0}, pe[3] = {1, 1, 1};
+      for (int t = 0; t < l->nd; ++t) {
+        const Marks m = marks(l, t);
+        pb[t] = m.DLB;
+        pe[t] = m.DRE;
+      }
+      const Marks m = marks(l, d);
+      if (sd == 0) { pb[d] = m.DLB; pe[d] = m.DLE; }
+      else { pb[d] = m.DRB; pe[d] = m.DRE; }
+      if (examg_axpby(l, src, l, tmp, 1.0, 0.0, pb, pe, s)) return 1;
+    }
+  return 0;
+}
+
+template <bool COL>
+int pass_blocks(const char *who, examg_comm_t *comm, const examg_neighbors_t *nb, const examg_layout_t *lu, const double *u_in, double *u_out,
+                double *tmp, const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w, int first,
+                const int32_t *begin, const int32_t *end, int exchange_flags, void *workspace, size_t workspace_bytes, int overlap,
+                examg_stream_t stream) {
+  if (!comm || !nb || !lu || !u_in || !u_out || !tmp || !lf || !rhs || !st || !begin || !end) { set_error("%s: null argument", who); return 1; }
+  if (u_in == u_out || tmp == u_in || tmp == u_out) { set_error("%s: u_in, u_out and tmp must be three arrays", who); return 1; }
+  hipStream_t main = (hipStream_t)stream;
+  const Faces f = interior_faces(lu, nb);
+  const int what = EXAMG_EXCH_GHOST | (exchange_flags & EXAMG_EXCH_CONCURRENT_AXES);
+  if (f.n == 0) {   // no neighbours: the plain one-pass forms
+    if (COL) return examg_rbgs_sweep_fused(lu, u_in, u_out, lf, rhs, st, w, first, begin, end, stream);
+    return examg_jacobi2_boxes(lu, u_in, u_out, tmp, lf, rhs, st, w, begin, end, begin, end, stream);
+  }
+  int32_t b1[3], e1[3], b2[3], e2[3];
+  shrunk(f, begin, end, 1, b1, e1);
+  shrunk(f, begin, end, 2, b2, e2);
+  bool has_interior = true;
+  for (int d = 0; d < lu->nd; ++d) has_interior = has_interior && e2[d] > b2[d];
+  const bool fused = has_interior && examg_two_stage_eligible(lu, lf, st, b1, e1, b2, e2) == 1;
+
+  auto interior = [&](hipStream_t s) -> int {
+    if (!has_interior) return 0;
+    if (COL) return examg_rbgs_sweep_fused_boxes(lu, u_in, u_out, fused ? nullptr : tmp, lf, rhs, st, w, first, b1, e1, b2, e2, s);
+    return examg_jacobi2_boxes(lu, u_in, u_out, tmp, lf, rhs, st, w, b1, e1, b2, e2, s);
+  };
+  auto shell = [&](hipStream_t s) -> int {
+    if (examg_exchange(comm, lu, const_cast<double *>(u_in), nb, what, workspace, workspace_bytes, s)) return 1;
+    if (copy_physical_planes(lu, nb, u_in, tmp, s)) return 1;
+    int32_t sb[3], se[3];
+    for (int i = 0; i < f.n; ++i) {        // first stage on three planes
+      slab(begin, end, f.d[i], f.side[i], 3, sb, se);
+      if (COL) {                           // tmp = u_in on the slab, then the colour's points (reads u_in only)
+        if (examg_axpby(lu, u_in, lu, tmp, 1.0, 0.0, sb, se, s)) return 1;
+        if (examg_stencil_op(EXAMG_SMOOTH, lu, u_in, lf, rhs, lu, tmp, st, w, first, sb, se, s)) return 1;
+      } else if (examg_stencil_op(EXAMG_SMOOTH, lu, u_in, lf, rhs, lu, tmp, st, w, -1, sb, se, s)) {
+        return 1;
+      }
+    }
+    if (examg_exchange(comm, lu, tmp, nb, what, workspace, workspace_bytes, s)) return 1;
+    for (int i = 0; i < f.n; ++i) {        // second stage on two planes
+      slab(begin, end, f.d[i], f.side[i], 2, sb, se);
+      if (COL) {
+        if (examg_axpby(lu, tmp, lu, u_out, 1.0, 0.0, sb, se, s)) return 1;
+        if (examg_stencil_op(EXAMG_SMOOTH, lu, tmp, lf, rhs, lu, u_out, st, w, 1 - first, sb, se, s)) return 1;
+      } else if (examg_stencil_op(EXAMG_SMOOTH, lu, tmp, lf, rhs, lu, u_out, st, w, -1, sb, se, s)) {
+        return 1;
+      }
+    }
+    return 0;
+  };
+
+  if (!(overlap && fused)) {   // sequence on the launch stream: the fallback of the interior pass needs tmp first
+    if (interior(main)) return 1;
+    return shell(main);
+  }
+  Overlap *o = overlap_of(comm);
+  if (!o) return 1;
+  if (check_hip(hipEventRecord(o->fork, main), who)) return 1;              // what was issued so far (u_in, rhs) is visible to the side stream
+  if (check_hip(hipStreamWaitEvent(o->side, o->fork, 0), who)) return 1;
+  if (shell(o->side)) return 1;
+  if (interior(main)) return 1;
+  if (check_hip(hipEventRecord(o->join, o->side), who)) return 1;
+  return check_hip(hipStreamWaitEvent(main, o->join, 0), who);
+}
+
+}  // namespace
+
+extern "C" int examg_jacobi2_blocks(examg_comm_t *comm, const examg_neighbors_t *nb, const examg_layout_t *lu, const double *u_in,
+                                    double *u_out, double *tmp, const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st,
+                                    double w, const int32_t *begin, const int32_t *end, int exchange_flags, void *workspace,
+                                    size_t workspace_bytes, int overlap, examg_stream_t stream) {
+  return pass_blocks<false>("examg_jacobi2_blocks", comm, nb, lu, u_in, u_out, tmp, lf, rhs, st, w, 0, begin, end, exchange_flags, workspace,
+                            workspace_bytes, overlap, stream);
+}
+
+extern "C" int examg_rbgs_sweep_blocks(examg_comm_t *comm, const examg_neighbors_t *nb, const examg_layout_t *lu, const double *u_in,
+                                       double *u_out, double *tmp, const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st,
+                                       double w, int first, const int32_t *begin, const int32_t *end, int exchange_flags, void *workspace,
+                                       size_t workspace_bytes, int overlap, examg_stream_t stream) {
+  if (first != 0 && first != 1) { set_error("examg_rbgs_sweep_blocks: first colour must be 0 or 1"); return 1; }
+  return pass_blocks<true>("examg_rbgs_sweep_blocks", comm, nb, lu, u_in, u_out, tmp, lf, rhs, st, w, first, begin, end, exchange_flags, workspace,
+                           workspace_bytes, overlap, stream);
 }

@@ -74,6 +74,7 @@ SYMBOLS = [
     "examg_cg_coarse", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
     "examg_comm_unique_id", "examg_comm_create", "examg_comm_destroy", "examg_comm_rank", "examg_comm_size",
     "examg_exchange_workspace_bytes", "examg_exchange", "examg_allreduce", "examg_allgather",
+    "examg_jacobi2_blocks", "examg_rbgs_sweep_blocks",
 ]
 
 COMM_ID_BYTES = 128
@@ -143,6 +144,9 @@ def load(path=None):
     L.examg_exchange_workspace_bytes.restype = C.c_size_t
     L.examg_exchange.argtypes = [vp, lp, vp, C.POINTER(NeighborsC), C.c_int, vp, C.c_size_t, vp]
     L.examg_allreduce.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    nbp = C.POINTER(NeighborsC)
+    L.examg_jacobi2_blocks.argtypes = [vp, nbp, lp, vp, vp, vp, lp, vp, sp, C.c_double, ip, ip, C.c_int, vp, C.c_size_t, C.c_int, vp]
+    L.examg_rbgs_sweep_blocks.argtypes = [vp, nbp, lp, vp, vp, vp, lp, vp, sp, C.c_double, C.c_int, ip, ip, C.c_int, vp, C.c_size_t, C.c_int, vp]
     L.examg_allgather.argtypes = [vp, vp, vp, C.c_int64, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported

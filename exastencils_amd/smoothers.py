@@ -86,6 +86,12 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool =
         ops.jacobi2_boxes(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, b, e, b, e)
         S.advance()
         return
+    # product path on GPUs: the whole choreography below as ONE library call (csrc/examg_comm.hip: pass_blocks) -- the Python
+    # form that follows is the same sequence statement by statement; it serves the CPU kernel layer (gloo tests) and is what
+    # the library call is tested against (tests/test_gpu_transport.py)
+    if hasattr(comm, "c_pass") and comm.c_pass("jacobi2", S, S.data(src), S.data(dst), tmp_field.data(), F, A, w, 0, b, e, axis_only, overlap):
+        S.advance()
+        return
 
     # The fallback of examg_jacobi2_boxes (short rows on coarse levels, other stencils) uses tmp as scratch for its whole
     # first step: it must then finish before the shell work writes tmp -- sequential order, no overlap.
@@ -148,6 +154,9 @@ def rbgs_sweep(ops, comm, domain, S, F, A, w: float, alt, tmp_field, first: int 
             sb[d] = max(e[d] - k, b[d])
         return sb, se
 
+    if hasattr(comm, "c_pass") and comm.c_pass("rbgs", S, src, alt, tmp_field.data(), F, A, w, first, b, e, axis_only, overlap):
+        S.slots[S.active] = alt        # one library call did interior + shell (see jacobi_pair)
+        return src
     b1, e1 = shrunk(1)
     b2, e2 = shrunk(2)
     # eligibility of the one-pass kernel is the kernel layer's decision (examg_two_stage_eligible); without it the fallback

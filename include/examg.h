@@ -293,6 +293,25 @@ enum { EXAMG_EXCH_DUP = 1, EXAMG_EXCH_GHOST = 2, EXAMG_EXCH_ALL = 3, EXAMG_EXCH_
 size_t examg_exchange_workspace_bytes(const examg_layout_t *l);
 int examg_exchange(examg_comm_t *comm, const examg_layout_t *l, double *x, const examg_neighbors_t *nb, int what,
                    void *workspace, size_t workspace_bytes, examg_stream_t stream);
+/* Smoother passes on a block WITH neighbours, halo traffic overlapped with the interior kernel -- the reference's core / boundary
+ * split (baseExt/ir/IR_LoopOverPointsInOneFragment.scala:143-222) applied to a pair of dependent sweeps, as one call:
+ *   examg_jacobi2_blocks     two Jacobi steps  (`communicate ghost of u; loop; advance` twice, Testing/Smoothers/Jac.exa4:125-131)
+ *   examg_rbgs_sweep_blocks  one red-black sweep (`color with { .., communicate u; loop; .. }`, ...exa4:204-213), colour `first` first
+ * The loop's box [begin, end) shrunk by one point (first stage) and two (second stage) at interior faces runs as ONE two-stage kernel
+ * on `stream`; meanwhile a side stream owned by the communicator exchanges the ghost layers of u_in, evaluates the first stage on
+ * the three planes next to every interior face into `tmp`, exchanges tmp's ghost layers and evaluates the second stage on the two
+ * planes next to every interior face into u_out; events join the streams.  Two exchanges per pass, as the plain loops have;
+ * results bit-identical to them.  u_in, u_out, tmp: three arrays of layout lu (tmp: scratch; its duplicate planes on physical
+ * faces are refreshed from u_in).  exchange_flags: EXAMG_EXCH_CONCURRENT_AXES or 0.  overlap = 0, or a stencil / box for which
+ * the one-pass kernel is not eligible: the same steps in sequence on `stream`.  The caller swaps u_in / u_out afterwards. */
+int examg_jacobi2_blocks(examg_comm_t *comm, const examg_neighbors_t *nb, const examg_layout_t *lu, const double *u_in, double *u_out,
+                         double *tmp, const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w,
+                         const int32_t *begin, const int32_t *end, int exchange_flags, void *workspace, size_t workspace_bytes,
+                         int overlap, examg_stream_t stream);
+int examg_rbgs_sweep_blocks(examg_comm_t *comm, const examg_neighbors_t *nb, const examg_layout_t *lu, const double *u_in, double *u_out,
+                            double *tmp, const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w, int first,
+                            const int32_t *begin, const int32_t *end, int exchange_flags, void *workspace, size_t workspace_bytes,
+                            int overlap, examg_stream_t stream);
 /* MPI_Allreduce(MPI_IN_PLACE, x, n, MPI_DOUBLE, op): x is device memory; op 0 = sum, 1 = max, 2 = min */
 int examg_allreduce(examg_comm_t *comm, double *x, int n, int op, examg_stream_t stream);
 /* every rank's n doubles, in rank order (coarse-level agglomeration: fewer, larger collectives over xGMI) */

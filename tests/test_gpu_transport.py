@@ -106,3 +106,56 @@ def test_exchange_argument_errors(hip):
     assert L.examg_comm_create(C.byref(C.c_void_p()), None, 2, 0) != 0                                    # two ranks need the id
     lib.check(L.examg_comm_destroy(h), "examg_comm_destroy")
 
+
+
+@pytest.mark.parametrize("rccl", [False, True], ids=["direct", "rccl-to-self"])
+@pytest.mark.parametrize("kind", ["jacobi2", "rbgs"])
+@pytest.mark.parametrize("n,periodic", [(128, (True, True, True)), (128, (False, True, True)), (40, (True, True, True))])
+def test_overlapped_pass_in_c_equals_python_choreography(hip, monkeypatch, rccl, kind, n, periodic):
+    """examg_jacobi2_blocks / examg_rbgs_sweep_blocks (interior two-stage kernel on the launch stream, two ghost exchanges and
+    the shell launches on the communicator's side stream, one C call) against the statement-by-statement Python form of
+    exastencils_amd/smoothers.py and against the plain loops -- periodic self-neighbours put interior faces on every side of
+    the one block; 40^3 takes the in-sequence fallback (rows too short for the one-pass kernel)."""
+    from exastencils_amd.field import laplace_fd
+    from exastencils_amd.smoothers import jacobi_pair, rbgs_sweep
+
+    if rccl:
+        monkeypatch.setenv("EXAMG_COMM_SELF_RCCL", "1")
+    dom = RectDomain(3, (1, 1, 1), 0, (1, 1, 1), periodic=periodic)
+    lay, layf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0, True, False)
+    A = laplace_fd(3, dom.h(0))
+    w = 0.8 / A.diag
+    b, e = dom.loop_bounds(lay)
+    outs = []
+    for transport in ("c", "torch", "plain"):
+        comm = Communicator(dom, hip, concurrent_ghost_axes=True, transport="torch" if transport == "plain" else transport)
+        nslots = 2 if kind == "jacobi2" else 1
+        S, F, T = Field("S", 0, lay, hip, nslots, None), Field("F", 0, layf, hip, 1, None), Field("T", 0, lay, hip, 1, None)
+        hip.fill_random(S.data(0), 11)
+        if nslots == 2:
+            S.data(1).copy_(S.data(0))
+        T.data().copy_(S.data(0))
+        alt = S.data(0).clone()
+        hip.fill_random(F.data(), 12)
+        for _ in range(3):
+            if transport == "plain":
+                if kind == "jacobi2":
+                    for _k in range(2):
+                        comm.exchange(S, S.active, "ghost")
+                        hip.stencil_op(2, S.lc, S.data(S.active), F.lc, F.data(), S.lc, S.data(S.next), A, w, -1, b, e)
+                        S.advance()
+                else:
+                    for colour in (0, 1):
+                        comm.exchange(S, None, "ghost")
+                        hip.stencil_op(2, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, w, colour, b, e)
+            elif kind == "jacobi2":
+                jacobi_pair(hip, comm, dom, S, F, A, w, T)
+            else:
+                alt = rbgs_sweep(hip, comm, dom, S, F, A, w, alt, T, 0)
+        hip.synchronize()
+        v = hip.to_host(S.data()).reshape(lay.shape_zyx)
+        outs.append(v[1 + b[2]:1 + e[2], 1 + b[1]:1 + e[1], 1 + b[0]:1 + e[0]].copy())
+        assert (comm._c is not None) == (transport == "c")
+        comm.close()
+    assert np.array_equal(outs[0].view(np.uint64), outs[1].view(np.uint64))
+    assert np.array_equal(outs[0].view(np.uint64), outs[2].view(np.uint64))
