@@ -1,6 +1,6 @@
 """Parity at BASELINE.json's full per-GPU size (512^3 cells): the HIP path against residual histories and solution digests that
 this repository's CPU oracle produced at that size (tests/golden/own/*.json -- "own oracle" fixtures written by
-tools/make_own_goldens.py in the build container; NOT reference data: the reference has no golden at these sizes).
+tests/golden/make_own_goldens.py in the build container; NOT reference data: the reference has no golden at these sizes).
 
 Tolerance: 1e-10 relative per iterate (BASELINE.json north_star) plus the rounding floor of a residual evaluated in fp64,
 64 eps x the starting residual (1.4e-14 r0): the FMG solve reduces the residual by 1.4e9 in two iterations, where the norm of
