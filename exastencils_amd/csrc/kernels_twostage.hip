@@ -18,17 +18,28 @@
 // bit-identical to running the two loops one after the other.
 #include "examg_common.h"
 
+#include <type_traits>
+
 namespace examg {
 
 struct TSGeom {
   int ntx, nty, ntz, zc, nblocks, remap;
   int xs;                  // 1: windows start one point further left, which makes every 16-byte access aligned (padded layouts)
+  int ys, zs;              // PROL: row groups / z chunks start one point earlier (canonical parities, see the kernel)
   int first;               // COL: colour updated in stage 1
   Box box1;                // stage-1 box (contains the output box); points outside keep the input value
   int ax0, ax1, ay0, ay1, az0, az1;  // allocation of u in iterator coordinates, half open
 };
 
 constexpr int TS_OUT = 124;  // outputs per 128-point window
+
+// Prolongation + correction folded into the pass (PROL variants): the stages see u + P(uc) on `box` instead of u --
+// `Solution += Prolongation@coarser * Solution@coarser` followed by the first post-smoothing sweep
+// (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:240-247) in one pass, without the 16 B per point of the correction loop.
+struct TSProl {
+  LayoutDev lc;
+  const double *uc;
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // The NW waves of a workgroup share one 128-point x window and a stack of 2*NW stage-1 rows.  Every wave
@@ -41,15 +52,25 @@ constexpr int TS_OUT = 124;  // outputs per 128-point window
 #ifndef TS_SCALAR_WV
 #define TS_SCALAR_WV 1
 #endif
-template <int ORDER, bool COL, int NW, bool NT, int WPE>
+//
+// PROL: the coarse values a workgroup interpolates from -- (NI/2 + 1) rows x 65 columns per coarse plane -- pass through LDS
+// as well: two plane buffers CB[P & 1], filled from a one-plane register prefetch every second step.  The correction of
+// input plane q+1 is added at the start of step q (own rows and the outer halo row), before the plane is used or published,
+// with the terms and the summation order of k_prolong_add3_pairs (kernels_transfer.hip): bit-identical to the two loops.
+template <int ORDER, bool COL, int NW, bool NT, int WPE, bool PROL>
 __global__ void __launch_bounds__(64 * NW, WPE)
 k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs,
-                 double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g) {
+                 double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g, TSProl pr) {
   constexpr int NS = 2 * NW;        // stage-1 rows of the workgroup: s = 0 .. NS-1, global row rw0 - 1 + s
   constexpr int NI = NS + 2;        // input rows: i = 0 .. NI-1, global row rw0 - 2 + i (centre of stage-1 row s is i = s+1)
   constexpr int NO = NS - 2;        // output rows: stage-1 rows 1 .. NS-2
-  __shared__ d2 UB[2][NI][64];      // input plane p in UB[p & 1]
-  __shared__ d2 VB[2][NS][64];      // stage-1 plane p in VB[p & 1]
+  constexpr int NCR = NI / 2 + 1, CW = 66, CT = NCR * CW;   // coarse tile: rows, row pitch (65 columns used), doubles per plane
+  __shared__ d2 SM[2 * NI * 64 + 2 * NS * 64 + (PROL ? CT : 0)];
+  d2 *const UBp = SM;                   // input plane p, row i:    UB(p & 1, i)
+  d2 *const VBp = SM + 2 * NI * 64;     // stage-1 plane p, row s:  VB(p & 1, s)
+  double *const CBp = reinterpret_cast<double *>(SM + 2 * NI * 64 + 2 * NS * 64);   // coarse plane P: CBp + (P & 1) * CT
+#define UB(p, i) UBp[((p) * NI + (i)) * 64 + lane]
+#define VB(p, s) VBp[((p) * NS + (s)) * 64 + lane]
   // threadIdx.y is the same for all lanes of a wave: as a scalar it keeps row predicates and LDS row addresses on the SALU
   const int lane = threadIdx.x, wv = TS_SCALAR_WV ? __builtin_amdgcn_readfirstlane(threadIdx.y) : threadIdx.y;
   int t = blockIdx.x;
@@ -69,8 +90,9 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   const int xw = box.b0 - 2 - g.xs + TS_OUT * tx;   // first point of the window
   const int xa = xw + 2 * lane;
   const int xpar = xw & 1;                          // parity of xa, the same in every lane
-  const int rw0 = box.b1 + ty * NO;             // first output row of the workgroup
-  const int mb = box.b2 + tz * g.zc;
+  const int rw0 = box.b1 - g.ys + ty * NO;      // first output row of the workgroup
+  const int mb = box.b2 - g.zs + tz * g.zc;     // first output plane (PROL: the first chunk may start one plane before the box)
+  const int mlo = max(mb, box.b2);
   const int me = min(mb + g.zc, box.e2);
   const Box &box1 = g.box1;
   const bool inx_a = xa >= box.b0 && xa < box.e0, inx_b = xa + 1 >= box.b0 && xa + 1 < box.e0;
@@ -132,8 +154,6 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     Upf[r] = load_u(urow[r], mb + 1);
     Fq[r] = load_f(r, mb - 1);
     Fqn[r] = load_f(r, mb);
-    Vm[r] = Um[r];
-    Vc[r] = Um[r];
     Fm[r] = Fq[r];
   }
   d2 Ocur = {0.0, 0.0};
@@ -142,25 +162,123 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     Oc = load_u(uouter, mb);
     Opf = load_u(uouter, mb + 1);
   }
+
+  // ---- PROL: coarse tile bookkeeping and the correction of one pair ----
+  // The launcher shifts windows, row groups and z chunks so that every workgroup starts on the same parities: xw even,
+  // rw0 odd, mb even.  Lane l then holds an even-x point (coarse column cx0 + l, weight 1) and an odd-x point (columns
+  // cx0 + l + 1, then cx0 + l, weight 1/2); a wave's first row is even (coarse tile row wv + 1), its second row odd (tile rows
+  // wv + 2, then wv + 1); the outer row of wave 0 is odd (tile rows 1, 0), that of wave NW-1 even (tile row NW + 1); and a
+  // chunk's first plane is even.  Which terms a correction has is known at compile time but for the plane's parity.
+  const int cy0 = (rw0 - 3) >> 1;                // first coarse row of the tile
+  const int Pa = (mb - 2) >> 1;                  // coarse plane of the first input plane
+  long long cb0[2] = {0, 0};                     // this thread's (up to) two tile elements: global index on coarse plane 0
+  int cel[2] = {0, 0};
+  bool cv[2] = {false, false};
+  double Cpf[2] = {0.0, 0.0};                    // coarse plane in flight (the next one to enter LDS)
+  auto cload = [&](int kk, int P) {
+    long long i = cb0[kk] + pr.lc.s2 * (long long)P;
+    i = min(max(i, 0LL), pr.lc.size - 1);      // elements outside the coarse allocation are read by nobody
+    return pr.uc[i];
+  };
+  // v = input pair of a row on plane p, `on` = row and plane inside the box; Th / Tl = tiles of the coarse planes (p+1)/2 and
+  // (p-1)/2 of an odd plane (OP) or, twice, of plane p/2; rl = tile row of the row's first entry ((y+1)/2 resp. y/2): an odd row
+  // (OY) also reads tile row rl - 1.  Entry order and association of k_prolong_add (kernels_transfer.hip): an odd index i has
+  // the entries (i+1)/2, (i-1)/2 with weight 1/2; loops over x entries, then y, then z; weight ((wx * wy) * wz).
+  auto corr = [&](d2 v, bool on, const double *Th, const double *Tl, int rl, auto OYc, auto OPc) {
+    constexpr bool OY = decltype(OYc)::value, OP = decltype(OPc)::value;
+    constexpr double wr = OY ? 0.5 : 1.0, wq = OP ? 0.5 : 1.0;
+    constexpr double w1 = (1.0 * wr) * wq, w2 = (0.5 * wr) * wq;
+    const double *h0 = Th + rl * CW + lane, *l0 = Tl + rl * CW + lane;   // row slot 0 on plane slots 0 / 1
+    // c<column: 0 = cx0 + l, 1 = cx0 + l + 1><row slot><plane slot>
+    const double c000 = h0[0], c100 = h0[1];
+    double c001 = 0.0, c101 = 0.0, c010 = 0.0, c110 = 0.0, c011 = 0.0, c111 = 0.0;
+    if constexpr (OP) { c001 = l0[0]; c101 = l0[1]; }
+    if constexpr (OY) { c010 = h0[-CW]; c110 = h0[1 - CW]; }
+    if constexpr (OY && OP) { c011 = l0[-CW]; c111 = l0[1 - CW]; }
+    double acc1 = w1 == 1.0 ? c000 : w1 * c000;      // even-x point: its one column
+    if constexpr (OP) acc1 = acc1 + w1 * c001;
+    if constexpr (OY) acc1 = acc1 + w1 * c010;
+    if constexpr (OY && OP) acc1 = acc1 + w1 * c011;
+    double acc2 = w2 * c100;                          // odd-x point: column cx0 + l + 1, then cx0 + l
+    if constexpr (OP) acc2 = acc2 + w2 * c101;
+    if constexpr (OY) acc2 = acc2 + w2 * c110;
+    if constexpr (OY && OP) acc2 = acc2 + w2 * c111;
+    acc2 = acc2 + w2 * c000;
+    if constexpr (OP) acc2 = acc2 + w2 * c001;
+    if constexpr (OY) acc2 = acc2 + w2 * c010;
+    if constexpr (OY && OP) acc2 = acc2 + w2 * c011;
+    v.x = (inx_a && on) ? v.x + acc1 : v.x;
+    v.y = (inx_b && on) ? v.y + acc2 : v.y;
+    return v;
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  const bool rowon[2] = {grow[0] >= box.b1 && grow[0] < box.e1, grow[1] >= box.b1 && grow[1] < box.e1};
+  const int orow = rw0 - 2 + outer_i;
+  const bool orowon = orow >= box.b1 && orow < box.e1;
+  // corrections of one input plane: the wave's two rows and (waves 0, NW-1) its outer halo row
+  auto corr_plane = [&](d2 *U2, d2 &O, int p, const double *Th, const double *Tl, auto OPc) {
+    const bool pon = p >= box.b2 && p < box.e2;
+    U2[0] = corr(U2[0], pon && rowon[0], Th, Tl, wv + 1, F_{}, OPc);
+    U2[1] = corr(U2[1], pon && rowon[1], Th, Tl, wv + 2, T_{}, OPc);
+    if (wv == 0) O = corr(O, pon && orowon, Th, Tl, 1, T_{}, OPc);
+    else if (wv == NW - 1) O = corr(O, pon && orowon, Th, Tl, NW + 1, F_{}, OPc);
+  };
+  if constexpr (PROL) {
+    const int cx0 = xw >> 1;
+    const int tid = wv * 64 + lane;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int e = tid + kk * 64 * NW;
+      const int row = e / CW, col = e - row * CW;
+      cel[kk] = e;
+      cv[kk] = e < CT;
+      cb0[kk] = pr.lc.origin + (long long)(cx0 + col) + pr.lc.s1 * (long long)(cy0 + row);
+    }
+    // coarse planes Pa, Pa + 1 cover the input planes mb-2 .. mb; plane Pa + 2 is in flight
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (!cv[kk]) continue;
+      const double a0 = cload(kk, Pa), a1 = cload(kk, Pa + 1);
+      Cpf[kk] = cload(kk, Pa + 2);
+      CBp[(Pa & 1) * CT + cel[kk]] = a0;
+      CBp[((Pa + 1) & 1) * CT + cel[kk]] = a1;
+    }
+    __syncthreads();
+    const double *Ta = CBp + (Pa & 1) * CT, *Tb = CBp + ((Pa + 1) & 1) * CT;
+    d2 dummy = {0.0, 0.0};
+    corr_plane(Um, dummy, mb - 2, Ta, Ta, F_{});     // even plane: coarse plane Pa
+    corr_plane(Uc, Ocur, mb - 1, Tb, Ta, T_{});      // odd plane: coarse planes Pa + 1, then Pa
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    Vm[r] = Um[r];
+    Vc[r] = Um[r];
+  }
   // publish input plane q0 = mb-1
   {
     const int pb = (mb - 1) & 1;
-    UB[pb][s0 + 1][lane] = Uc[0];
-    UB[pb][s0 + 2][lane] = Uc[1];
-    if (has_outer) UB[pb][outer_i][lane] = Ocur;
+    UB(pb, s0 + 1) = Uc[0];
+    UB(pb, s0 + 2) = Uc[1];
+    if (has_outer) UB(pb, outer_i) = Ocur;
   }
   __syncthreads();
 
   for (int q = mb - 1; q <= me; ++q) {
     const int m = q - 1;
     const int ub = q & 1, vb = m & 1;
+    if constexpr (PROL) {   // input plane q+1 enters the pipeline here: add its correction first
+      const int P = (q + 1) >> 1;
+      if ((q + 1) & 1) corr_plane(Up, Oc, q + 1, CBp + ((P + 1) & 1) * CT, CBp + (P & 1) * CT, T_{});
+      else corr_plane(Up, Oc, q + 1, CBp + (P & 1) * CT, CBp + (P & 1) * CT, F_{});
+    }
     // y-neighbour rows of this step from LDS
-    const d2 ulo = UB[ub][s0][lane];          // input row below the first own row
-    const d2 uhi = UB[ub][s0 + 3][lane];      // input row above the second own row
+    const d2 ulo = UB(ub, s0);          // input row below the first own row
+    const d2 uhi = UB(ub, s0 + 3);      // input row above the second own row
     d2 vlo = {0.0, 0.0}, vhi = {0.0, 0.0};
-    if (m >= mb) {
-      if (s0 >= 1) vlo = VB[vb][s0 - 1][lane];
-      if (s0 + 2 <= NS - 1) vhi = VB[vb][s0 + 2][lane];
+    if (m >= mlo) {
+      if (s0 >= 1) vlo = VB(vb, s0 - 1);
+      if (s0 + 2 <= NS - 1) vhi = VB(vb, s0 + 2);
     }
     // prefetch: input plane q+3 of the own rows is not needed yet; plane q+2 is in flight (Upf), rhs q+1 in flight (Fqn)
     // ---- stage 1 on plane q, own rows ----
@@ -200,7 +318,7 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
       Vn[r] = v;
     }
     // ---- stage 2 on plane m = q-1, own rows that are output rows ----
-    if (m >= mb) {
+    if (m >= mlo) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         if (!row_out[r]) continue;   // wave-uniform
@@ -252,11 +370,24 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     // ---- publish input plane q+1 and stage-1 plane q; rotate; issue the next loads ----
     if (q < me) {
       const int nb = (q + 1) & 1;
-      UB[nb][s0 + 1][lane] = Up[0];
-      UB[nb][s0 + 2][lane] = Up[1];
-      if (has_outer) UB[nb][outer_i][lane] = Oc;
-      VB[q & 1][s0][lane] = Vn[0];
-      VB[q & 1][s0 + 1][lane] = Vn[1];
+      UB(nb, s0 + 1) = Up[0];
+      UB(nb, s0 + 2) = Up[1];
+      if (has_outer) UB(nb, outer_i) = Oc;
+      VB(q & 1, s0) = Vn[0];
+      VB(q & 1, s0 + 1) = Vn[1];
+      if constexpr (PROL) {
+        // even input plane q+1: coarse plane (q+3)/2 is first needed by input plane q+2 (corrected after this step's
+        // barrier); its buffer held plane (q-1)/2, last read for input plane q at the start of step q-1
+        if (!((q + 1) & 1)) {
+          const int Pn = (q + 3) >> 1;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+            if (cv[kk]) {
+              CBp[(Pn & 1) * CT + cel[kk]] = Cpf[kk];
+              Cpf[kk] = cload(kk, Pn + 1);
+            }
+        }
+      }
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -279,6 +410,8 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     }
     __syncthreads();
   }
+#undef UB
+#undef VB
 }
 
 // launch knobs (debug build: examg_debug_two_stage*; per host thread): workgroup count target, tile order
@@ -299,35 +432,45 @@ static thread_local int g_ts_minzc = 16;
 //   256^3: LDS-5 0.138, LDS-8 0.119-0.124;  128^3: LDS-5 0.028, LDS-8 0.031
 // ~120 VGPRs -> 4 waves per SIMD = 16 per CU: two 8-wave workgroups fill a CU (a 9-wave workgroup runs alone)
 static thread_local int g_ts_lds = -2;
+static thread_local int g_ts_prol_wpe = 4;     // PROL variants: 4 = capped at 128 VGPRs (4 waves per SIMD), 1 = uncapped (160 VGPRs, 3 waves)
 
 template <bool COL, int NW, int WPE = 1>
 static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
                                 double *out, const examg_stencil_t *st, double w, int first, const Box &box, const Box &box1,
-                                hipStream_t s) {
+                                hipStream_t s, const TSProl *prol = nullptr) {
   constexpr int NO = 2 * NW - 2;
   const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
   TSGeom g;
   // padded layouts (even strides): start the windows so that every 16-byte access is aligned (kernels_stencil.hip: launch_zmarch)
   const bool even = !(lu.s1 & 1) && !(lu.s2 & 1) && !(lf.s1 & 1) && !(lf.s2 & 1);
   g.xs = (even && ((lu.origin + box.b0) & 1) && ((lf.origin + box.b0) & 1)) ? 1 : 0;
+  g.ys = g.zs = 0;
+  if (prol) {   // canonical parities (see the kernel): window start even, first output row odd, first output plane even
+    g.xs = box.b0 & 1;
+    g.ys = (box.b1 & 1) ? 0 : 1;
+    g.zs = box.b2 & 1;
+  }
   g.ntx = (box.n0() + g.xs + TS_OUT - 1) / TS_OUT;
-  g.nty = (box.n1() + NO - 1) / NO;
+  g.nty = (box.n1() + g.ys + NO - 1) / NO;
   const int xy = g.ntx * g.nty;
-  const int blocks_target = g_ts_blocks > 0 ? g_ts_blocks : (box.count() >= 50000000LL ? 8192 : 3072);
+  // (with the correction folded in, a step costs more and longer chunks pay: 512^3, 3072 / 8192 workgroups: 0.87 / 0.92 ms)
+  const int blocks_target = g_ts_blocks > 0 ? g_ts_blocks : (box.count() >= 50000000LL && !prol ? 8192 : 3072);
   int ntz = (blocks_target + xy - 1) / xy;
   if (ntz < 1) ntz = 1;
-  int zc = (box.n2() + ntz - 1) / ntz;
+  const int n2 = box.n2() + g.zs;
+  int zc = (n2 + ntz - 1) / ntz;
   if (zc < g_ts_minzc) zc = g_ts_minzc;
+  if (prol) zc += zc & 1;
   // the kernel addresses a workgroup's window with 32-bit element offsets: plane stride x (chunk + halo planes) must fit
   {
     const LayoutDev lbig = lu.s2 > lf.s2 ? lu : lf;
     const long long zmax = (2147483000LL - lbig.s1 * (2 * NW + 6) - 512) / lbig.s2 - 8;
     if (zmax < 16) { set_error("examg two-stage kernel: plane too large for 32-bit window offsets"); return 1; }
-    if (zc > zmax) zc = (int)zmax;
+    if (zc > zmax) zc = (int)zmax & ~1;
   }
-  if (zc > box.n2()) zc = box.n2();
+  if (zc > n2) zc = n2 + (prol ? (n2 & 1) : 0);
   g.zc = zc;
-  g.ntz = (box.n2() + zc - 1) / zc;
+  g.ntz = (n2 + zc - 1) / zc;
   g.nblocks = xy * g.ntz;
   g.remap = g_ts_remap >= 0 ? g_ts_remap : 2;
   g.first = first;
@@ -339,8 +482,20 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
   const int ord = canonical_order7(st);
   dim3 block(64, NW, 1), grid(g.nblocks, 1, 1);
-  if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, WPE>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
-  else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, WPE>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g);
+  TSProl pr;
+  pr.lc = lu;
+  pr.uc = nullptr;
+  if (prol) {
+    pr = *prol;
+    if (g_ts_prol_wpe == 4) {
+      if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, (NW == 6 ? 1 : 4), true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+      else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, (NW == 6 ? 1 : 4), true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+    } else {
+      if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, 1, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+      else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, 1, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+    }
+  } else if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, WPE, false>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+  else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, WPE, false>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
   EXAMG_CHECK_LAUNCH("k_two_stage7_lds");
   return 0;
 }
@@ -348,11 +503,20 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
 template <bool COL>
 static int launch_two_stage(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
                             double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s,
-                            const Box *box1 = nullptr) {
+                            const Box *box1 = nullptr, const TSProl *prol = nullptr) {
   const Box &b1 = box1 ? *box1 : box;
   const int impl = g_ts_lds == -2 ? (box.n1() >= 192 ? 8 : 5) : g_ts_lds;
-  if (impl == 8) return launch_two_stage_lds<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
-  return launch_two_stage_lds<COL, 5>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s);
+  if (impl == 8) return launch_two_stage_lds<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol);
+  if (impl == 6) return launch_two_stage_lds<COL, 6>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol);
+  return launch_two_stage_lds<COL, 5>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol);
+}
+
+// The coarse footprint of the correction loop on `box` (examg_prolong_add's checks)
+static bool prolong_args_ok(const char *who, const examg_layout_t *lc, const Box &box) {
+  if (box.b0 < 0 || box.b1 < 0 || box.b2 < 0) { set_error("%s: negative fine index", who); return false; }
+  int32_t cb[3] = {box.b0 / 2, box.b1 / 2, box.b2 / 2}, ce[3] = {box.e0 / 2 + 1, box.e1 / 2 + 1, box.e2 / 2 + 1};
+  if (lc->nd != 3 || !box_inside(lc, make_box(cb, ce), 0)) { set_error("%s: coarse footprint leaves the coarse allocation", who); return false; }
+  return true;
 }
 
 static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
@@ -367,6 +531,11 @@ using namespace examg;
 #ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_two_stage_lds(int nw) {
   g_ts_lds = nw < 0 ? -2 : nw;
+  return 0;
+}
+
+extern "C" int examg_debug_two_stage_prol(int wpe) {
+  g_ts_prol_wpe = wpe == 1 ? 1 : 4;
   return 0;
 }
 
@@ -416,6 +585,41 @@ extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_
     e2[d] = end[d] + (on ? reach : 0);
   }
   int rc = examg_axpby(lu, u_in, lu, u_out, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_rbgs_colour(lu, u_out, lf, rhs, st, w, first, begin, end, stream);
+  if (rc) return rc;
+  return examg_rbgs_colour(lu, u_out, lf, rhs, st, w, 1 - first, begin, end, stream);
+}
+
+// `u += Prolongation * uc` on [begin,end) followed by one full red-black sweep on the same box, out of place: u_out receives
+// the swept values on the box (every point of which the sweep rewrites); u_in is not modified.
+extern "C" int examg_rbgs_sweep_fused_prolong(const examg_layout_t *lu, const double *u_in, double *u_out,
+                                              const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w,
+                                              int first, const int32_t *begin, const int32_t *end, const examg_layout_t *lc,
+                                              const double *uc, examg_stream_t stream) {
+  if (!lu || !u_in || !u_out || !lf || !rhs || !st || !begin || !end || !lc || !uc) { set_error("examg_rbgs_sweep_fused_prolong: null argument"); return 1; }
+  if (u_in == u_out) { set_error("examg_rbgs_sweep_fused_prolong: out of place only"); return 1; }
+  if (first != 0 && first != 1) { set_error("examg_rbgs_sweep_fused_prolong: first colour must be 0 or 1"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (two_stage_ok(lu, lf, st, box)) {
+    if (!prolong_args_ok("examg_rbgs_sweep_fused_prolong", lc, box)) return 1;
+    TSProl pr;
+    pr.lc = make_layout(lc);
+    pr.uc = uc;
+    return launch_two_stage<true>(lu, u_in, lf, rhs, u_out, st, w, first, box, (hipStream_t)stream, nullptr, &pr);
+  }
+  // general stencils / small boxes: the three loops one after the other on a copy (box + one-stencil-reach shell)
+  const int reach = stencil_reach(st);
+  int32_t b2[3], e2[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool on = d < lu->nd;
+    b2[d] = begin[d] - (on ? reach : 0);
+    e2[d] = end[d] + (on ? reach : 0);
+  }
+  int rc = examg_axpby(lu, u_in, lu, u_out, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_prolong_add(lc, uc, lu, u_out, begin, end, stream);
   if (rc) return rc;
   rc = examg_rbgs_colour(lu, u_out, lf, rhs, st, w, first, begin, end, stream);
   if (rc) return rc;
@@ -487,6 +691,43 @@ extern "C" int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in,
   rc = examg_jacobi(lu, u_in, tmp, lf, rhs, st, w, begin1, end1, stream);
   if (rc) return rc;
   return examg_jacobi(lu, tmp, u_out, lf, rhs, st, w, begin2, end2, stream);
+}
+
+// `u += Prolongation * uc` on [begin,end) followed by two Jacobi steps on the same box: u_out receives the result on the box,
+// u_in is not modified; `tmp` (a distinct array) is only used by the fallback.
+extern "C" int examg_jacobi2_prolong(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp,
+                                     const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w,
+                                     const int32_t *begin, const int32_t *end, const examg_layout_t *lc, const double *uc,
+                                     examg_stream_t stream) {
+  if (!lu || !u_in || !u_out || !lf || !rhs || !st || !begin || !end || !lc || !uc) { set_error("examg_jacobi2_prolong: null argument"); return 1; }
+  if (u_in == u_out) { set_error("examg_jacobi2_prolong: out of place only"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (two_stage_ok(lu, lf, st, box)) {
+    if (!prolong_args_ok("examg_jacobi2_prolong", lc, box)) return 1;
+    TSProl pr;
+    pr.lc = make_layout(lc);
+    pr.uc = uc;
+    return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box, (hipStream_t)stream, nullptr, &pr);
+  }
+  if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2_prolong: fallback needs a distinct tmp array"); return 1; }
+  const int reach = stencil_reach(st);
+  int32_t b2[3], e2[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool on = d < lu->nd;
+    b2[d] = begin[d] - (on ? reach : 0);
+    e2[d] = end[d] + (on ? reach : 0);
+  }
+  // u_out holds the corrected field for the first step, tmp (with the box's shell) the intermediate one
+  int rc = examg_axpby(lu, u_in, lu, u_out, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_axpby(lu, u_in, lu, tmp, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_prolong_add(lc, uc, lu, u_out, begin, end, stream);
+  if (rc) return rc;
+  rc = examg_jacobi(lu, u_out, tmp, lf, rhs, st, w, begin, end, stream);
+  if (rc) return rc;
+  return examg_jacobi(lu, tmp, u_out, lf, rhs, st, w, begin, end, stream);
 }
 
 // Two Jacobi steps, u_in -> (u_in's values after two sweeps) in u_out; `tmp` is only used by the fallback

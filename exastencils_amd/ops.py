@@ -91,6 +91,18 @@ class HipOps:
                                          C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin1), ivec(end1),
                                          ivec(begin2), ivec(end2), self._stream()), "examg_jacobi2_boxes")
 
+    def rbgs_sweep_fused_prolong(self, lu, u_in, u_out, lf, rhs, st: Stencil, w: float, first: int, begin, end, lc, uc):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_rbgs_sweep_fused_prolong(C.byref(lu), self.ptr(u_in), self.ptr(u_out), C.byref(lf), self.ptr(rhs), C.byref(sc),
+                                                    float(w), int(first), ivec(begin), ivec(end), C.byref(lc), self.ptr(uc), self._stream()),
+              "examg_rbgs_sweep_fused_prolong")
+
+    def jacobi2_prolong(self, lu, u_in, u_out, tmp, lf, rhs, st: Stencil, w: float, begin, end, lc, uc):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_jacobi2_prolong(C.byref(lu), self.ptr(u_in), self.ptr(u_out), self.ptr(tmp) if tmp is not None else None,
+                                           C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin), ivec(end), C.byref(lc),
+                                           self.ptr(uc), self._stream()), "examg_jacobi2_prolong")
+
     def two_stage_eligible(self, lu, lf, st: Stencil, begin1, end1, begin2, end2) -> bool:
         """Will jacobi2_boxes / rbgs_sweep_fused_boxes run their one-pass kernel (True) or the fallback that writes `tmp`?"""
         sc = st.c_struct(self.ptr)

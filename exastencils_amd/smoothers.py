@@ -24,11 +24,12 @@ from __future__ import annotations
 SMOOTH = 2
 
 
-def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool = True):
+def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool = True, correction_from=None):
     """Two applications of `Smoother@current` (Testing/Smoothers/Jac.exa4:125-131) on field S (2 slots):
     reads slot <active>, leaves the result in the slot two `advance`s would make active (the same one),
     reached through one advance of the out-of-place pass.  tmp_field: scratch field of S's layout whose
-    Dirichlet shell holds S's boundary values."""
+    Dirichlet shell holds S's boundary values.  correction_from (single block only): the coarser Solution field whose
+    prolongation `Correction@current` adds to S just before the pair -- folded into the pass (examg_jacobi2_prolong)."""
     nd = domain.nd
     b, e = domain.loop_bounds(S.layout)
     src, dst = S.active, S.next
@@ -83,9 +84,14 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool =
 
     if not faces:
         comm.exchange(S, src, "ghost", axis_only)      # empty on a single block
-        ops.jacobi2_boxes(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, b, e, b, e)
+        if correction_from is not None:
+            Sc = correction_from
+            ops.jacobi2_prolong(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, b, e, Sc.lc, Sc.data())
+        else:
+            ops.jacobi2_boxes(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, b, e, b, e)
         S.advance()
         return
+    assert correction_from is None, "the folded correction needs a block without neighbours"
     # product path on GPUs: the whole choreography below as ONE library call (csrc/examg_comm.hip: pass_blocks) -- the Python
     # form that follows is the same sequence statement by statement; it serves the CPU kernel layer (gloo tests) and is what
     # the library call is tested against (tests/test_gpu_transport.py)

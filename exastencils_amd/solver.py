@@ -117,6 +117,10 @@ class ConfigL4:
     fused_coarse: bool = True     # single block: mgCycle@coarsest as one persistent kernel
     fused_rbgs: bool = False      # one-pass red-black sweep (out of place, pointer swap)
     fused_residual_restrict: bool = False   # single block: `Residual = ...` + restriction as one pass, fine residual not stored
+    # single block + fused_rbgs: the correction loop is folded into the first post-smoothing sweep on levels with at least this
+    # many points (0 = never).  MI355X: 512^3 1.16 -> 0.87 ms; below ~5*10^7 points the fields sit in the Infinity Cache, the
+    # separate correction loop is cheap and the fold does not pay (256^3: 0.141 -> 0.150 ms)
+    fused_prolong_min_points: int = 0
     overlap_transfers: bool = True            # blocks > 1: residual / restriction as interior + shell around their halo exchange
     agglomerate_level: Optional[int] = None   # blocks > 1: levels <= this are solved redundantly on every rank (see _agg_cycle)
     agglomerate_extra_levels: int = 0         # the gathered hierarchy coarsens this many levels below min_level
@@ -292,7 +296,20 @@ class SolverFromL4(_Program):
         return curIt
 
     # repeat 3 times { color with { (i0+i1+i2) % 2, communicate; loop over Solution {...}; apply bc } }  (:204-213)
-    def _smooth(self, l: int):
+    def _folds_prolongation(self, l: int) -> bool:
+        """Is `Solution@l += Prolongation * Solution@(l-1)` folded into the first post-smoothing sweep of level l?"""
+        cfg = self.cfg
+        if not (cfg.fused_prolong_min_points > 0 and cfg.fused_rbgs and self._single_block() and cfg.n_smooth >= 1):
+            return False
+        S = self.Solution[l]
+        b, e = self.bounds(S)
+        if (e[0] - b[0]) * (e[1] - b[1]) * (e[2] - b[2]) < cfg.fused_prolong_min_points:
+            return False
+        # the kernel layer decides whether its one-pass kernel takes these arguments; without it the entry point runs the plain
+        # loops on a copy, which costs more than the separate calls
+        return not hasattr(self.ops, "two_stage_eligible") or self.ops.two_stage_eligible(S.lc, self.RHS[l].lc, self.Laplace[l], b, e, b, e)
+
+    def _smooth(self, l: int, correction_from: Optional[Field] = None):
         S, F, A = self.Solution[l], self.RHS[l], self.Laplace[l]
         w = self.cfg.omega / A.diag           # `0.8 / diag(Laplace)`, folded to a literal by the generator
         b, e = self.bounds(S)
@@ -301,11 +318,17 @@ class SolverFromL4(_Program):
             # `apply bc` would re-write the same position-only Dirichlet values each time: both arrays get their
             # shell once, the per-colour `apply bc` calls become no-ops and are dropped -- no bit changes
             # (_init_alt_shells, called from setup())
-            for _ in range(self.cfg.n_smooth):
+            for it in range(self.cfg.n_smooth):
                 alt = self._sol_alt[l]
-                self.ops.rbgs_sweep_fused(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e)
+                if it == 0 and correction_from is not None:
+                    # the correction loop, whose box is the sweep's box, rides along (examg_rbgs_sweep_fused_prolong)
+                    Sc = correction_from
+                    self.ops.rbgs_sweep_fused_prolong(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e, Sc.lc, Sc.data())
+                else:
+                    self.ops.rbgs_sweep_fused(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e)
                 self._sol_alt[l], S.slots[0] = S.slots[0], alt
             return
+        assert correction_from is None
         if self.cfg.fused_rbgs:
             # blocks with neighbours: fused deep interior + two-point shell with its two exchanges on a side stream
             # (exastencils_amd/smoothers.py: rbgs_sweep); the three arrays carry the Dirichlet planes of the physical faces
@@ -358,6 +381,11 @@ class SolverFromL4(_Program):
         self.apply_bc(Sc)
         self.mgCycle(l - 1)
         b, e = self.bounds(S)
+        if self._folds_prolongation(l):
+            # `communicate Solution@coarser` and `apply bc Solution` are empty / re-write the same values on a single block
+            self.communicate(Sc)
+            self._smooth(l, correction_from=Sc)
+            return
         side = ops.side_stream() if (self.cfg.overlap_transfers and not self._single_block() and hasattr(ops, "side_stream")) else None
         if side is not None:
             # `communicate Solution@coarser`: the interpolation of node values reads duplicate and inner points of the coarse
@@ -481,6 +509,7 @@ class ConfigL3:
     temporal_blocking: bool = False   # pairs of Jacobi steps in one pass (exastencils_amd/smoothers.py)
     fused_residual_restrict: bool = False   # single block: UpResidual + Restriction as one pass (fine residual not stored)
     fused_rbgs: bool = False          # red-black sweeps as one out-of-place pass (with neighbours: fused interior + shell)
+    fused_prolong_min_points: int = 0 # single block + temporal_blocking: Correction folded into the first pair of post-smoothing steps (ConfigL4)
     ksq: float = 0.0                  # stencil 'helmholtz27': shift k^2 of  -div(a grad u) - k^2 u  (config 4)
     rhs_from_solution: bool = False   # RHS = A * sol_fn (discrete manufactured solution)
 
@@ -582,9 +611,22 @@ class SolverFromL3(_Program):
                 self.ops.stencil_op(SMOOTH, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, self._w(l), colour, b, e)
 
     # `repeat n times { Smoother@current ( ) }`
-    def Smoothers(self, l: int, n: int):
+    def _folds_prolongation(self, l: int) -> bool:
+        """Is Correction@l folded into the first pair of post-smoothing Jacobi steps?"""
+        cfg = self.cfg
+        if not (cfg.fused_prolong_min_points > 0 and cfg.temporal_blocking and cfg.smoother == "jacobi" and cfg.n_smooth >= 2
+                and self._single_block() and self.nd == 3 and self.Laplace[l].cfield is None):
+            return False
+        S = self.Solution[l]
+        b, e = self.bounds(S)
+        if (e[0] - b[0]) * (e[1] - b[1]) * (e[2] - b[2]) < cfg.fused_prolong_min_points:
+            return False
+        return not hasattr(self.ops, "two_stage_eligible") or self.ops.two_stage_eligible(S.lc, self.RHS[l].lc, self.Laplace[l], b, e, b, e)
+
+    def Smoothers(self, l: int, n: int, correction_from: Optional[Field] = None):
         cfg = self.cfg
         if not (cfg.temporal_blocking and cfg.smoother == "jacobi"):
+            assert correction_from is None
             for _ in range(n):
                 self.Smoother(l)
             return
@@ -600,7 +642,9 @@ class SolverFromL3(_Program):
             self.apply_bc(tmp)
         k = n
         while k >= 2:
-            jacobi_pair(self.ops, self.comm, self.domain, S, self.RHS[l], self.Laplace[l], self._w(l), tmp)
+            jacobi_pair(self.ops, self.comm, self.domain, S, self.RHS[l], self.Laplace[l], self._w(l), tmp,
+                        correction_from=correction_from)
+            correction_from = None
             k -= 2
         if k:
             self.Smoother(l)
@@ -641,8 +685,13 @@ class SolverFromL3(_Program):
             self.Restriction(l)
         self.SetSolution(l - 1, 0.0)
         self.VCycle(l - 1)
-        self.Correction(l)
-        self.Smoothers(l, self.cfg.n_smooth)
+        if self._folds_prolongation(l):
+            Sc = self.Solution[l - 1]
+            self.communicate(Sc, Sc.active, "ghost")      # Correction@current's exchange (empty on a single block)
+            self.Smoothers(l, self.cfg.n_smooth, correction_from=Sc)
+        else:
+            self.Correction(l)
+            self.Smoothers(l, self.cfg.n_smooth)
 
     # Function VCycle_0@coarsest (Testing/Smoothers/Jac.exa4:75-109)
     def VCycle_0(self, l: int):

@@ -139,6 +139,20 @@ int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in, double *u_
                         const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin1, const int32_t *end1,
                         const int32_t *begin2, const int32_t *end2, examg_stream_t stream);
 
+/* `Solution += Prolongation@coarser * Solution@coarser` on [begin,end) followed by the first post-smoothing pass on the same box
+ * (mgCycle, Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:240-247: correction loop, `apply bc`, smoother) in ONE pass: the
+ * one-pass kernels interpolate the coarse values (1/8 of the points, staged through LDS) while they load u_in, instead of a
+ * separate read-modify-write loop over the fine field (16 B per point).  u_in is not modified; u_out receives on the box
+ * exactly (bit for bit) what examg_prolong_add on u_in followed by examg_rbgs_sweep_fused / examg_jacobi2 would put there.
+ * Single block only (the correction's `communicate` and the halo exchanges of the smoother must be empty).  Arguments that the
+ * one-pass kernel does not take (examg_two_stage_eligible with both boxes = [begin,end)) run copy + the plain loops. */
+int examg_rbgs_sweep_fused_prolong(const examg_layout_t *lu, const double *u_in, double *u_out, const examg_layout_t *lf,
+                                   const double *rhs, const examg_stencil_t *st, double w, int first, const int32_t *begin,
+                                   const int32_t *end, const examg_layout_t *lc, const double *uc, examg_stream_t stream);
+int examg_jacobi2_prolong(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp, const examg_layout_t *lf,
+                          const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end,
+                          const examg_layout_t *lc, const double *uc, examg_stream_t stream);
+
 /* 1 if examg_jacobi2_boxes / examg_rbgs_sweep_fused_boxes will run their one-pass kernel for these arguments, 0 if they will
  * take the fallback that writes `tmp` on the launch stream (other stencils or entry orders, short rows, boxes at the edge of
  * the allocation).  A caller that overlaps the pass with work on `tmp` on another stream must ask here first. */

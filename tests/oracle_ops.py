@@ -98,6 +98,19 @@ class OracleOps:
         self.stencil_op(2, lu, u_in, lf, rhs, lu, tmp, st, w, -1, begin1, end1)
         self.stencil_op(2, lu, tmp, lf, rhs, lu, u_out, st, w, -1, begin2, end2)
 
+    def rbgs_sweep_fused_prolong(self, lu, u_in, u_out, lf, rhs, st, w, first, begin, end, lc, uc):
+        u_out.copy_(u_in)
+        self.prolong_add(lc, uc, lu, u_out, begin, end)
+        for c in (first, 1 - first):
+            self.stencil_op(2, lu, u_out, lf, rhs, lu, u_out, st, w, c, begin, end)
+
+    def jacobi2_prolong(self, lu, u_in, u_out, tmp, lf, rhs, st, w, begin, end, lc, uc):
+        u_out.copy_(u_in)
+        tmp.copy_(u_in)
+        self.prolong_add(lc, uc, lu, u_out, begin, end)
+        self.stencil_op(2, lu, u_out, lf, rhs, lu, tmp, st, w, -1, begin, end)
+        self.stencil_op(2, lu, tmp, lf, rhs, lu, u_out, st, w, -1, begin, end)
+
     def restrict(self, lfine, rf, lc, fc, scale, begin, end):
         self.L.orc_restrict(_lp(lfine), self.ptr(rf), _lp(lc), self.ptr(fc), float(scale), _iv(begin), _iv(end))
 

@@ -225,6 +225,65 @@ def test_two_stage_interior_faces_anisotropic(orc, two_stage_variant, kind):
     assert_same([hip.to_host(t) for t in g], c, "two-stage faces " + kind)
 
 
+def _prolong_fold_case(ops, fused, kind, shape, st, b, e, first=0, align=0):
+    """`u += P uc` on the box, then one red-black sweep / two Jacobi steps: one call (fused) or the separate loops."""
+    lu, lf = FieldLayout.node(3, shape, 1, True, True, align), FieldLayout.node(3, shape, 0, True, False, align)
+    lc = FieldLayout.node(3, tuple(s // 2 for s in shape), 1, True, True, align)
+    u, f, out, tmp, uc = (ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size),
+                          ops.new_array(lc.size))
+    ops.fill_random(u, 12345)
+    ops.fill_random(f, 4711)
+    ops.fill_random(out, 5)
+    ops.fill_random(uc, 99)
+    w = 0.8 / st.diag
+    L, Fl, Lc = lu.c_struct(), lf.c_struct(), lc.c_struct()
+    if fused:
+        if kind == "rbgs":
+            ops.rbgs_sweep_fused_prolong(L, u, out, Fl, f, st, w, first, b, e, Lc, uc)
+        else:
+            ops.jacobi2_prolong(L, u, out, tmp, Fl, f, st, w, b, e, Lc, uc)
+        return [out, u]
+    work = u.clone()
+    ops.prolong_add(Lc, uc, L, work, b, e)
+    if kind == "rbgs":
+        for c in (first, 1 - first):
+            ops.stencil_op(SMOOTH, L, work, Fl, f, L, work, st, w, c, b, e)
+    else:
+        tmp.copy_(work)
+        ops.stencil_op(SMOOTH, L, work, Fl, f, L, tmp, st, w, -1, b, e)
+        ops.stencil_op(SMOOTH, L, tmp, Fl, f, L, work, st, w, -1, b, e)
+    ops.axpby(L, work, L, out, 1.0, 0.0, b, e)      # box only
+    return [out, u]
+
+
+@pytest.mark.parametrize("kind", ["rbgs", "jacobi2"])
+@pytest.mark.parametrize("shape,b,e,first,align", [
+    ((66, 66, 66), None, None, 0, 0),
+    ((130, 130, 130), None, None, 1, 0),
+    ((200, 200, 200), None, None, 0, 0),
+    ((256, 256, 64), None, None, 0, 16),                     # padded layout: aligned windows start one point further left
+    ((150, 36, 20), [0, 1, 0], [151, 36, 21], 0, 0),         # loop over duplicate planes: even window / row / plane starts
+    ((128, 40, 38), [1, 2, 3], [126, 39, 37], 1, 0),         # box inside the inner points, mixed parities
+    ((40, 20, 20), None, None, 0, 0),                        # short rows: the copy + plain loops path
+])
+def test_prolongation_folded_into_the_pass_bit_exact(orc, two_stage_variant, kind, shape, b, e, first, align):
+    """examg_rbgs_sweep_fused_prolong / examg_jacobi2_prolong == correction loop + the smoother loops one after the other on
+    the CPU, bit for bit (same interpolation terms in the same order); u_in untouched, u_out untouched outside the box."""
+    hip = two_stage_variant
+    st = laplace_fd(3, tuple(1.0 / s for s in shape))
+    if b is None:
+        b, e = [1, 1, 1], list(shape)
+    g = _prolong_fold_case(hip, True, kind, shape, st, b, e, first, align)
+    hip.synchronize()
+    c = _prolong_fold_case(orc, False, kind, shape, st, b, e, first, align)
+    got, want = [hip.to_host(t) for t in g], [orc.to_host(t) for t in c]
+    if shape[0] < 64:     # the copy path also brings u_in's values to the box's one-point shell (include/examg.h): compare the box
+        lu = FieldLayout.node(3, shape, 1, True, True, align)
+        sl = tuple(slice(b[d] + 1, e[d] + 1) for d in (2, 1, 0))
+        got[0], want[0] = got[0].reshape(lu.shape_zyx)[sl], want[0].reshape(lu.shape_zyx)[sl]
+    assert_same(got, want, "prolongation fold " + kind)
+
+
 @pytest.mark.parametrize("shape,b,e,b2,e2", [
     ((150, 36, 40), [0, 1, 0], [151, 36, 41], [1, 1, 1], [150, 36, 40]),     # neighbours in x and z: both dup planes excluded
     ((130, 70, 33), [1, 0, 1], [130, 71, 33], [1, 1, 1], [130, 71, 33]),     # lower y neighbour only

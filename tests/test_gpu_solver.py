@@ -340,6 +340,39 @@ def test_lds_resident_coarse_cg_equals_global_memory_solver():
         assert np.array_equal(hist[0][1], hist[1][1])
 
 
+def test_folded_prolongation_changes_no_bit(hip):
+    """V-cycles with the correction loop folded into the first post-smoothing sweep (examg_rbgs_sweep_fused_prolong on every
+    level with rows of 64 points or more) leave the same residual history and the same solution, bit for bit."""
+    from exastencils_amd.solver import ConfigL4, SolverFromL4
+
+    hist, sols, folds = [], [], []
+    for min_points in (0, 1):
+        P = SolverFromL4(ConfigL4(nd=3, min_level=2, max_level=7, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True,
+                                  fused_prolong_min_points=min_points), hip)
+        P.setup()
+        P.Solve()
+        hist.append(P.res_history)
+        sols.append(hip.to_host(P.Solution[7].data()).copy())
+        folds.append([P._folds_prolongation(l) for l in range(3, 8)])
+    assert folds == [[False] * 5, [False, False, False, False, True]]       # 128^3 has rows of 127 points, 64^3 of 63
+    assert hist[0] == hist[1] and len(hist[0]) > 4
+    assert np.array_equal(sols[0].view(np.uint64), sols[1].view(np.uint64))
+    from exastencils_amd.solver import ConfigL3, SolverFromL3
+
+    hist, sols = [], []
+    for min_points in (0, 1):        # slotted Jacobi program: Correction folded into the first pair of post-smoothing steps
+        P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=7, temporal_blocking=True, fused_residual_restrict=True,
+                                  fused_prolong_min_points=min_points), hip)
+        P.setup()
+        P.Solve()
+        assert P._folds_prolongation(7) == bool(min_points) and not P._folds_prolongation(6)
+        hist.append(P.res_history)
+        S = P.Solution[7]
+        sols.append(hip.to_host(S.data(S.active)).copy())
+    assert hist[0] == hist[1] and len(hist[0]) > 4
+    assert np.array_equal(sols[0].view(np.uint64), sols[1].view(np.uint64))
+
+
 def test_fused_residual_restrict_changes_no_bit(hip):
     """V-cycles with residual + restriction as one pass (fine residual never stored) print the same history, bit for bit."""
     from exastencils_amd.solver import ConfigL4, SolverFromL4

@@ -40,6 +40,28 @@ def test_host_driver_reproduces_goldens(name):
     assert P.err_history == O.err_history
 
 
+def test_folded_prolongation_in_the_host_driver():
+    """mgCycle with the correction loop folded into the first post-smoothing sweep (one kernel-layer call instead of
+    prolong_add + sweep; here the oracle's loops stand in): same history as the statement-by-statement cycle."""
+    hist = []
+    for min_points in (0, 1):
+        P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, tol=1e-8, fused_coarse=False, fused_rbgs=True,
+                                  fused_prolong_min_points=min_points), OracleOps())
+        P.setup()
+        P.Solve()
+        assert P._folds_prolongation(4) == bool(min_points)
+        hist.append(P.res_history)
+    assert hist[0] == hist[1] and len(hist[0]) > 3
+    hist = []
+    for min_points in (0, 1):        # the slotted Jacobi program with pairs of steps: Correction rides on the first pair
+        P = SolverFromL3(ConfigL3(nd=3, min_level=1, max_level=4, temporal_blocking=True, fused_prolong_min_points=min_points), OracleOps())
+        P.setup()
+        P.Solve()
+        assert P._folds_prolongation(4) == bool(min_points)
+        hist.append(P.res_history)
+    assert hist[0] == hist[1] and len(hist[0]) > 3
+
+
 def test_layout_matches_reference_sizes():
     # SURVEY.md section 8: 512^3 NodeWithComm => TOT = 2^L + 3 = 515 per dim, NodeNoGhost => 513
     l = FieldLayout.node(3, (512, 512, 512), 1)
