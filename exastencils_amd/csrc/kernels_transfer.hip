@@ -321,6 +321,9 @@ k_prolong_add3_pairs(LayoutDev lc, const double *__restrict__ uc, LayoutDev lfin
 }
 
 static thread_local int g_restrict_wide = 1;
+// residual_restrict: wave count target, minimum coarse planes per wave.  MI355X, 512^3 -> 256^3 (tools/sweep_rr.py), ms by target:
+// 4096: 0.560, 9216: 0.511, 18432: 0.486, 24576: 0.479, 36864: 0.481 -- many short waves keep the tail of the launch short
+static thread_local int g_rr_waves = 24576, g_rr_minzc = 8;
 static thread_local int g_prolong_zb = 2;    // planes per workgroup of the pair prolongation (examg_debug_prolong)   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
 
 static inline dim3 grid_for(long long total) {
@@ -335,6 +338,12 @@ static inline dim3 grid_for(long long total) {
 using namespace examg;
 
 #ifdef EXAMG_DEBUG_HOOKS
+extern "C" int examg_debug_residual_restrict(int waves, int minzc) {
+  if (waves > 0) examg::g_rr_waves = waves;
+  if (minzc > 0) examg::g_rr_minzc = minzc;
+  return 0;
+}
+
 extern "C" int examg_debug_prolong(int zb) {
   examg::g_prolong_zb = zb > 0 ? zb : 8;
   return 0;
@@ -402,10 +411,10 @@ extern "C" int examg_residual_restrict(const examg_layout_t *lu_, const double *
     for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
     const int ntx = (cb.n0() + 62) / 63;
     const long long cols = (long long)ntx * cb.n1();
-    int ntz = (int)((4096 + cols - 1) / cols);
+    int ntz = (int)((g_rr_waves + cols - 1) / cols);
     if (ntz < 1) ntz = 1;
     int zc = (cb.n2() + ntz - 1) / ntz;
-    if (zc < 8) zc = 8;
+    if (zc < g_rr_minzc) zc = g_rr_minzc;
     if (zc > cb.n2()) zc = cb.n2();
     ntz = (cb.n2() + zc - 1) / zc;
     const long long nwaves = cols * ntz;

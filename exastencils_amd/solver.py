@@ -242,7 +242,8 @@ class SolverFromL4(_Program):
             f = self.RHS[hi]
             b, e = self.bounds(f)
             self.ops.fill_fn(f.lc, f.data(), self.domain.geom(hi), cfg.rhs_fn, (), b, e)
-        self.apply_bc(self.Solution[hi])
+        for l in self.levels:           # finest: the program's `apply bc`; coarser: homogeneous values the cycle relies on (mgCycle: static_bc)
+            self.apply_bc(self.Solution[l])
         self._init_alt_shells()
 
     def _init_alt_shells(self):
@@ -296,6 +297,17 @@ class SolverFromL4(_Program):
         return curIt
 
     # repeat 3 times { color with { (i0+i1+i2) % 2, communicate; loop over Solution {...}; apply bc } }  (:204-213)
+    def _one_pass_sweep(self, l: int) -> bool:
+        """Does the kernel layer run the red-black sweep of level l as one pass (examg_two_stage_eligible)?"""
+        if not hasattr(self, "_one_pass"):
+            self._one_pass = {}
+        if l not in self._one_pass:
+            S = self.Solution[l]
+            b, e = self.bounds(S)
+            self._one_pass[l] = not hasattr(self.ops, "two_stage_eligible") or \
+                self.ops.two_stage_eligible(S.lc, self.RHS[l].lc, self.Laplace[l], b, e, b, e)
+        return self._one_pass[l]
+
     def _folds_prolongation(self, l: int) -> bool:
         """Is `Solution@l += Prolongation * Solution@(l-1)` folded into the first post-smoothing sweep of level l?"""
         cfg = self.cfg
@@ -307,7 +319,7 @@ class SolverFromL4(_Program):
             return False
         # the kernel layer decides whether its one-pass kernel takes these arguments; without it the entry point runs the plain
         # loops on a copy, which costs more than the separate calls
-        return not hasattr(self.ops, "two_stage_eligible") or self.ops.two_stage_eligible(S.lc, self.RHS[l].lc, self.Laplace[l], b, e, b, e)
+        return self._one_pass_sweep(l)
 
     def _smooth(self, l: int, correction_from: Optional[Field] = None):
         S, F, A = self.Solution[l], self.RHS[l], self.Laplace[l]
@@ -318,6 +330,13 @@ class SolverFromL4(_Program):
             # `apply bc` would re-write the same position-only Dirichlet values each time: both arrays get their
             # shell once, the per-colour `apply bc` calls become no-ops and are dropped -- no bit changes
             # (_init_alt_shells, called from setup())
+            if correction_from is None and not self._one_pass_sweep(l):
+                # short rows (coarse levels): the entry point would copy the field and run the two colour loops on the copy --
+                # the loops in place are the same statements with one launch less per sweep (launch-bound levels)
+                for _ in range(self.cfg.n_smooth):
+                    for colour in (0, 1):
+                        self.ops.stencil_op(SMOOTH, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, w, colour, b, e)
+                return
             for it in range(self.cfg.n_smooth):
                 alt = self._sol_alt[l]
                 if it == 0 and correction_from is not None:
@@ -378,7 +397,11 @@ class SolverFromL4(_Program):
         Sc, S = self.Solution[l - 1], self.Solution[l]
         b, e = self.bounds(Sc)
         ops.set(Sc.lc, Sc.data(), 0.0, b, e)
-        self.apply_bc(Sc)
+        # single block with the one-pass sweeps: every loop of the cycle writes inner points only and the Dirichlet values are
+        # functions of the position, written once by setup() -- `apply bc` would re-write the same bits (as in _smooth)
+        static_bc = self.cfg.fused_rbgs and self._single_block()
+        if not static_bc:
+            self.apply_bc(Sc)
         self.mgCycle(l - 1)
         b, e = self.bounds(S)
         if self._folds_prolongation(l):
@@ -402,7 +425,8 @@ class SolverFromL4(_Program):
         else:
             self.communicate(Sc)
             ops.prolong_add(Sc.lc, Sc.data(), S.lc, S.data(), b, e)
-        self.apply_bc(S)
+        if not static_bc:
+            self.apply_bc(S)
         self._smooth(l)
 
     # Function mgCycle@coarsest (...exa4:152-201)
