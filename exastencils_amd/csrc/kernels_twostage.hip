@@ -425,7 +425,7 @@ static thread_local int g_ts_disable = 0;
 // 512^3 0.714 / 0.737 / 0.698.  Plain (cached) instead of non-temporal stores with the layered order: 0.703 against 0.670 ms.  With the layered order more, shorter z chunks pay at 512^3 and above (16 planes per chunk):
 // 3072 / 6144 / 8192 workgroups 0.697 / 0.668 / 0.667 (plain order: 0.733 / 0.780 / -); 256^3 prefers ~3072 (0.098 vs 0.106).
 static thread_local int g_ts_remap = -1;
-static thread_local int g_ts_minzc = 16;
+static thread_local int g_ts_minzc = -1;     // minimum planes per z chunk; -1: 16, 8 on small boxes
 // Which implementation: 5 / 8 = that many waves per workgroup; -2 = by size.
 // tools/tune_two_stage.py on MI355X, ms for a Jacobi pair / a red-black sweep (all variants bit-identical):
 //   512^3: registers 0.97 / 0.93, LDS-5 0.79 / 0.77, LDS-8 0.717 / 0.716 (3072 workgroups), LDS-9 0.87 / 0.85
@@ -459,7 +459,11 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   if (ntz < 1) ntz = 1;
   const int n2 = box.n2() + g.zs;
   int zc = (n2 + ntz - 1) / ntz;
-  if (zc < g_ts_minzc) zc = g_ts_minzc;
+  // at least 16 planes per chunk (4 halo planes each); 8 on small boxes that would leave most of the chip idle otherwise
+  // (tools/sweep_two_stage3.py, 5-wave workgroups, 16 / 8 / 4 planes: 128^3 0.0243 / 0.0186 / 0.0300 ms, 96^3 0.0235 / 0.0149 / 0.0129)
+  int minzc = g_ts_minzc;
+  if (minzc < 0) minzc = (long long)xy * ((n2 + 15) / 16) < 512 ? 8 : 16;
+  if (zc < minzc) zc = minzc;
   if (prol) zc += zc & 1;
   // the kernel addresses a workgroup's window with 32-bit element offsets: plane stride x (chunk + halo planes) must fit
   {
@@ -543,7 +547,7 @@ extern "C" int examg_debug_two_stage(int disable, int blocks, int remap, int wy)
   g_ts_disable = disable;
   if (blocks > 0) g_ts_blocks = blocks;
   if (remap >= 0) g_ts_remap = remap;
-  if (wy > 0) g_ts_minzc = wy;      // 4th argument: minimum planes per z chunk
+  g_ts_minzc = wy > 0 ? wy : -1;    // 4th argument: minimum planes per z chunk (<= 0: default rule)
   return 0;
 }
 #endif
