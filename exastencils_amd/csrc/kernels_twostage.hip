@@ -57,10 +57,14 @@ struct TSProl {
 // as well: two plane buffers CB[P & 1], filled from a one-plane register prefetch every second step.  The correction of
 // input plane q+1 is added at the start of step q (own rows and the outer halo row), before the plane is used or published,
 // with the terms and the summation order of k_prolong_add3_pairs (kernels_transfer.hip): bit-identical to the two loops.
-template <int ORDER, bool COL, int NW, bool NT, int WPE, bool PROL>
+//
+// VAR: 0 = as described; 1 = PROL; 2 = the input field is zero everywhere (a coarse level's first pre-smoothing pass after
+// `Solution = 0`): nothing is loaded for it, the arithmetic is the same expression on the constant 0.0.
+template <int ORDER, bool COL, int NW, bool NT, int WPE, int VAR>
 __global__ void __launch_bounds__(64 * NW, WPE)
 k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs,
                  double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g, TSProl pr) {
+  constexpr bool PROL = VAR == 1, ZIN = VAR == 2;
   constexpr int NS = 2 * NW;        // stage-1 rows of the workgroup: s = 0 .. NS-1, global row rw0 - 1 + s
   constexpr int NI = NS + 2;        // input rows: i = 0 .. NI-1, global row rw0 - 2 + i (centre of stage-1 row s is i = s+1)
   constexpr int NO = NS - 2;        // output rows: stage-1 rows 1 .. NS-2
@@ -133,6 +137,7 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   const int uouter = lane_u + s1u * outer_i;
 
   auto load_u = [&](int rowoff, int p) {
+    if constexpr (ZIN) return d2{0.0, 0.0};
     const int rel = min(max(rowoff + s2u * (p - mb + 2), 0), hi_u);
     return load2(ub + rel);
   };
@@ -437,7 +442,7 @@ static thread_local int g_ts_prol_wpe = 4;     // PROL variants: 4 = capped at 1
 template <bool COL, int NW, int WPE = 1>
 static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
                                 double *out, const examg_stencil_t *st, double w, int first, const Box &box, const Box &box1,
-                                hipStream_t s, const TSProl *prol = nullptr) {
+                                hipStream_t s, const TSProl *prol = nullptr, bool zero_in = false) {
   constexpr int NO = 2 * NW - 2;
   const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
   TSGeom g;
@@ -492,14 +497,22 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   if (prol) {
     pr = *prol;
     if (g_ts_prol_wpe == 4) {
-      if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, (NW == 6 ? 1 : 4), true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
-      else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, (NW == 6 ? 1 : 4), true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+      if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, (NW == 6 ? 1 : 4), 1>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+      else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, (NW == 6 ? 1 : 4), 1>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
     } else {
-      if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, 1, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
-      else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, 1, true>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+      if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, 1, 1>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+      else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, 1, 1>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
     }
-  } else if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, WPE, false>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
-  else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, WPE, false>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+  } else if (zero_in) {
+    if constexpr (COL && NW != 6) {
+      if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, WPE, 2>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+      else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, WPE, 2>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+    } else {
+      set_error("examg two-stage kernel: no zero-input variant of this form");
+      return 1;
+    }
+  } else if (ord == 0) hipLaunchKernelGGL((k_two_stage7_lds<0, COL, NW, true, WPE, 0>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
+  else hipLaunchKernelGGL((k_two_stage7_lds<1, COL, NW, true, WPE, 0>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);
   EXAMG_CHECK_LAUNCH("k_two_stage7_lds");
   return 0;
 }
@@ -507,12 +520,13 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
 template <bool COL>
 static int launch_two_stage(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
                             double *out, const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s,
-                            const Box *box1 = nullptr, const TSProl *prol = nullptr) {
+                            const Box *box1 = nullptr, const TSProl *prol = nullptr, bool zero_in = false) {
   const Box &b1 = box1 ? *box1 : box;
-  const int impl = g_ts_lds == -2 ? (box.n1() >= 192 ? 8 : 5) : g_ts_lds;
-  if (impl == 8) return launch_two_stage_lds<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol);
-  if (impl == 6) return launch_two_stage_lds<COL, 6>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol);
-  return launch_two_stage_lds<COL, 5>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol);
+  int impl = g_ts_lds == -2 ? (box.n1() >= 192 ? 8 : 5) : g_ts_lds;
+  if (zero_in && impl == 6) impl = 5;
+  if (impl == 8) return launch_two_stage_lds<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol, zero_in);
+  if (impl == 6) return launch_two_stage_lds<COL, 6>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol, zero_in);
+  return launch_two_stage_lds<COL, 5>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol, zero_in);
 }
 
 // The coarse footprint of the correction loop on `box` (examg_prolong_add's checks)
@@ -589,6 +603,32 @@ extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_
     e2[d] = end[d] + (on ? reach : 0);
   }
   int rc = examg_axpby(lu, u_in, lu, u_out, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_rbgs_colour(lu, u_out, lf, rhs, st, w, first, begin, end, stream);
+  if (rc) return rc;
+  return examg_rbgs_colour(lu, u_out, lf, rhs, st, w, 1 - first, begin, end, stream);
+}
+
+// One full red-black sweep of the ZERO field (every value of u, boundary planes included, is 0.0): u_out receives on the box
+// what examg_rbgs_sweep_fused would write for such a u_in, which is never read.
+extern "C" int examg_rbgs_sweep_fused_zero(const examg_layout_t *lu, double *u_out, const examg_layout_t *lf, const double *rhs,
+                                           const examg_stencil_t *st, double w, int first, const int32_t *begin,
+                                           const int32_t *end, examg_stream_t stream) {
+  if (!lu || !u_out || !lf || !rhs || !st || !begin || !end) { set_error("examg_rbgs_sweep_fused_zero: null argument"); return 1; }
+  if (first != 0 && first != 1) { set_error("examg_rbgs_sweep_fused_zero: first colour must be 0 or 1"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (two_stage_ok(lu, lf, st, box))
+    return launch_two_stage<true>(lu, u_out, lf, rhs, u_out, st, w, first, box, (hipStream_t)stream, nullptr, nullptr, true);
+  // general stencils / small boxes: zero the box and its one-stencil-reach shell, then the two half sweeps in place
+  const int reach = stencil_reach(st);
+  int32_t b2[3], e2[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool on = d < lu->nd;
+    b2[d] = begin[d] - (on ? reach : 0);
+    e2[d] = end[d] + (on ? reach : 0);
+  }
+  int rc = examg_set(lu, u_out, 0.0, b2, e2, stream);
   if (rc) return rc;
   rc = examg_rbgs_colour(lu, u_out, lf, rhs, st, w, first, begin, end, stream);
   if (rc) return rc;

@@ -97,6 +97,11 @@ class HipOps:
                                                     float(w), int(first), ivec(begin), ivec(end), C.byref(lc), self.ptr(uc), self._stream()),
               "examg_rbgs_sweep_fused_prolong")
 
+    def rbgs_sweep_fused_zero(self, lu, u_out, lf, rhs, st: Stencil, w: float, first: int, begin, end):
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_rbgs_sweep_fused_zero(C.byref(lu), self.ptr(u_out), C.byref(lf), self.ptr(rhs), C.byref(sc), float(w),
+                                                 int(first), ivec(begin), ivec(end), self._stream()), "examg_rbgs_sweep_fused_zero")
+
     def jacobi2_prolong(self, lu, u_in, u_out, tmp, lf, rhs, st: Stencil, w: float, begin, end, lc, uc):
         sc = st.c_struct(self.ptr)
         check(self.L.examg_jacobi2_prolong(C.byref(lu), self.ptr(u_in), self.ptr(u_out), self.ptr(tmp) if tmp is not None else None,

@@ -121,6 +121,9 @@ class ConfigL4:
     # many points (0 = never).  MI355X: 512^3 1.16 -> 0.87 ms; below ~5*10^7 points the fields sit in the Infinity Cache, the
     # separate correction loop is cheap and the fold does not pay (256^3: 0.141 -> 0.150 ms)
     fused_prolong_min_points: int = 0
+    # single block + fused_rbgs: `Solution@coarser = 0` is not executed where the first pre-smoothing sweep of that level is a
+    # one-pass sweep: it takes the zero field as a constant (examg_rbgs_sweep_fused_zero: no zeroing loop, 16 instead of 24 B per point)
+    fused_zero_start: bool = False
     overlap_transfers: bool = True            # blocks > 1: residual / restriction as interior + shell around their halo exchange
     agglomerate_level: Optional[int] = None   # blocks > 1: levels <= this are solved redundantly on every rank (see _agg_cycle)
     agglomerate_extra_levels: int = 0         # the gathered hierarchy coarsens this many levels below min_level
@@ -321,7 +324,7 @@ class SolverFromL4(_Program):
         # loops on a copy, which costs more than the separate calls
         return self._one_pass_sweep(l)
 
-    def _smooth(self, l: int, correction_from: Optional[Field] = None):
+    def _smooth(self, l: int, correction_from: Optional[Field] = None, zero_input: bool = False):
         S, F, A = self.Solution[l], self.RHS[l], self.Laplace[l]
         w = self.cfg.omega / A.diag           # `0.8 / diag(Laplace)`, folded to a literal by the generator
         b, e = self.bounds(S)
@@ -343,11 +346,13 @@ class SolverFromL4(_Program):
                     # the correction loop, whose box is the sweep's box, rides along (examg_rbgs_sweep_fused_prolong)
                     Sc = correction_from
                     self.ops.rbgs_sweep_fused_prolong(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e, Sc.lc, Sc.data())
+                elif it == 0 and zero_input:
+                    self.ops.rbgs_sweep_fused_zero(S.lc, alt, F.lc, F.data(), A, w, 0, b, e)
                 else:
                     self.ops.rbgs_sweep_fused(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e)
                 self._sol_alt[l], S.slots[0] = S.slots[0], alt
             return
-        assert correction_from is None
+        assert correction_from is None and not zero_input
         if self.cfg.fused_rbgs:
             # blocks with neighbours: fused deep interior + two-point shell with its two exchanges on a side stream
             # (exastencils_amd/smoothers.py: rbgs_sweep); the three arrays carry the Dirichlet planes of the physical faces
@@ -366,13 +371,13 @@ class SolverFromL4(_Program):
                 self.apply_bc(S)
 
     # Function mgCycle@(all but coarsest) (...exa4:203-249)
-    def mgCycle(self, l: int):
+    def mgCycle(self, l: int, solution_is_zero: bool = False):
         if self._agg is not None and l == self.cfg.agglomerate_level:
             return self._agg_cycle(l)
         if l == self.cfg.min_level:
             return self.mgCycle_coarsest(l)
         ops = self.ops
-        self._smooth(l)
+        self._smooth(l, zero_input=solution_is_zero)
         R, Fc = self.Residual[l], self.RHS[l - 1]
         if self.cfg.fused_residual_restrict and self._single_block():
             # nothing reads Residual@l between here and its next update: residual and restriction in one pass, bit-identical
@@ -396,13 +401,18 @@ class SolverFromL4(_Program):
                 ops.restrict(R.lc, R.data(), Fc.lc, Fc.data(), 1.0, b, e)
         Sc, S = self.Solution[l - 1], self.Solution[l]
         b, e = self.bounds(Sc)
-        ops.set(Sc.lc, Sc.data(), 0.0, b, e)
         # single block with the one-pass sweeps: every loop of the cycle writes inner points only and the Dirichlet values are
         # functions of the position, written once by setup() -- `apply bc` would re-write the same bits (as in _smooth)
         static_bc = self.cfg.fused_rbgs and self._single_block()
+        # ... and a coarser level that starts with a one-pass sweep reads its zero Solution as a constant (its boundary values are 0)
+        zero_start = (self.cfg.fused_zero_start and static_bc and l - 1 != self.cfg.min_level and self.cfg.n_smooth >= 1 and
+                      Sc.bc_fn == FN_ZERO and not (self._agg is not None and l - 1 == self.cfg.agglomerate_level) and
+                      self._one_pass_sweep(l - 1))
+        if not zero_start:
+            ops.set(Sc.lc, Sc.data(), 0.0, b, e)
         if not static_bc:
             self.apply_bc(Sc)
-        self.mgCycle(l - 1)
+        self.mgCycle(l - 1, solution_is_zero=zero_start)
         b, e = self.bounds(S)
         if self._folds_prolongation(l):
             # `communicate Solution@coarser` and `apply bc Solution` are empty / re-write the same values on a single block

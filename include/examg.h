@@ -139,6 +139,14 @@ int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in, double *u_
                         const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin1, const int32_t *end1,
                         const int32_t *begin2, const int32_t *end2, examg_stream_t stream);
 
+/* examg_rbgs_sweep_fused for a u_in that is 0.0 everywhere, boundary planes included -- a coarse level's first pre-smoothing
+ * sweep after `Solution@coarser = 0` (mgCycle, Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:225-229 followed by :204-213): u_in is
+ * not passed and not read (16 B per point instead of 24, and the zeroing loop need not run), the arithmetic is the same
+ * expression evaluated on the constant 0.0: bit-identical.  The shell of u_out is not written (fallback path: zeroed). */
+int examg_rbgs_sweep_fused_zero(const examg_layout_t *lu, double *u_out, const examg_layout_t *lf, const double *rhs,
+                                const examg_stencil_t *st, double w, int first, const int32_t *begin, const int32_t *end,
+                                examg_stream_t stream);
+
 /* `Solution += Prolongation@coarser * Solution@coarser` on [begin,end) followed by the first post-smoothing pass on the same box
  * (mgCycle, Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:240-247: correction loop, `apply bc`, smoother) in ONE pass: the
  * one-pass kernels interpolate the coarse values (1/8 of the points, staged through LDS) while they load u_in, instead of a

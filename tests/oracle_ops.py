@@ -104,6 +104,11 @@ class OracleOps:
         for c in (first, 1 - first):
             self.stencil_op(2, lu, u_out, lf, rhs, lu, u_out, st, w, c, begin, end)
 
+    def rbgs_sweep_fused_zero(self, lu, u_out, lf, rhs, st, w, first, begin, end):
+        u_out.zero_()
+        for c in (first, 1 - first):
+            self.stencil_op(2, lu, u_out, lf, rhs, lu, u_out, st, w, c, begin, end)
+
     def jacobi2_prolong(self, lu, u_in, u_out, tmp, lf, rhs, st, w, begin, end, lc, uc):
         u_out.copy_(u_in)
         tmp.copy_(u_in)

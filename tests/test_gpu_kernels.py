@@ -284,6 +284,32 @@ def test_prolongation_folded_into_the_pass_bit_exact(orc, two_stage_variant, kin
     assert_same(got, want, "prolongation fold " + kind)
 
 
+@pytest.mark.parametrize("n,first,order", [(66, 0, "mp"), (130, 1, "pm"), (200, 0, "mp"), (40, 0, "mp")])
+def test_sweep_of_the_zero_field_bit_exact(orc, two_stage_variant, n, first, order):
+    """examg_rbgs_sweep_fused_zero (the input field is the constant 0.0, nothing is loaded for it) == the two colour loops on a
+    zeroed array; 40^3 takes the zero + plain loops path."""
+    hip = two_stage_variant
+    st = laplace_fd(3, (1.0 / n,) * 3, order)
+    b, e = box(3, n)
+    lu, lf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0, True, False)
+    w = 0.8 / st.diag
+
+    def run(ops, fused):
+        f, out = ops.new_array(lf.size), ops.new_array(lu.size)
+        ops.fill_random(f, 4711)
+        if fused:
+            ops.rbgs_sweep_fused_zero(lu.c_struct(), out, lf.c_struct(), f, st, w, first, b, e)
+        else:
+            for c in (first, 1 - first):
+                ops.stencil_op(SMOOTH, lu.c_struct(), out, lf.c_struct(), f, lu.c_struct(), out, st, w, c, b, e)
+        return [out]
+
+    g = run(hip, True)
+    hip.synchronize()
+    c = run(orc, False)
+    assert_same([hip.to_host(t) for t in g], [orc.to_host(t) for t in c], "sweep of the zero field")
+
+
 @pytest.mark.parametrize("shape,b,e,b2,e2", [
     ((150, 36, 40), [0, 1, 0], [151, 36, 41], [1, 1, 1], [150, 36, 40]),     # neighbours in x and z: both dup planes excluded
     ((130, 70, 33), [1, 0, 1], [130, 71, 33], [1, 1, 1], [130, 71, 33]),     # lower y neighbour only

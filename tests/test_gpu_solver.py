@@ -346,15 +346,15 @@ def test_folded_prolongation_changes_no_bit(hip):
     from exastencils_amd.solver import ConfigL4, SolverFromL4
 
     hist, sols, folds = [], [], []
-    for min_points in (0, 1):
-        P = SolverFromL4(ConfigL4(nd=3, min_level=2, max_level=7, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True,
-                                  fused_prolong_min_points=min_points), hip)
+    for min_points in (0, 1):       # ... and (second run) `Solution@coarser = 0` left to the first sweep of the coarser level
+        P = SolverFromL4(ConfigL4(nd=3, min_level=2, max_level=8, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True,
+                                  fused_prolong_min_points=min_points, fused_zero_start=bool(min_points)), hip)
         P.setup()
         P.Solve()
         hist.append(P.res_history)
-        sols.append(hip.to_host(P.Solution[7].data()).copy())
-        folds.append([P._folds_prolongation(l) for l in range(3, 8)])
-    assert folds == [[False] * 5, [False, False, False, False, True]]       # 128^3 has rows of 127 points, 64^3 of 63
+        sols.append(hip.to_host(P.Solution[8].data()).copy())
+        folds.append([P._folds_prolongation(l) for l in range(3, 9)])
+    assert folds == [[False] * 6, [False, False, False, False, True, True]]       # 128^3 has rows of 127 points, 64^3 of 63
     assert hist[0] == hist[1] and len(hist[0]) > 4
     assert np.array_equal(sols[0].view(np.uint64), sols[1].view(np.uint64))
     from exastencils_amd.solver import ConfigL3, SolverFromL3
