@@ -537,16 +537,20 @@ def vcycle(ops, dom, comm, L, world, align=0):
     its = Q.Solve(use_graph=use_graph)
     torch.cuda.synchronize()
     solve_s = time.perf_counter() - t0
-    # compulsory bytes of one cycle with the fused kernels, per level above the coarsest: 6 sweeps x 24 B per point, residual +
-    # restriction (16 B per point + 8 B per coarse point), zeroing the coarse solution (8 B per coarse point), prolongation +
-    # correction (16 B per point + 8 B per coarse point)
+    # compulsory bytes of one cycle as the driver runs it, per level above the coarsest: 6 sweeps x 24 B per point (16 B for a first
+    # sweep that takes the zero field as a constant), residual + restriction (16 B per point + 8 B per coarse point), zeroing the
+    # coarse solution (8 B per coarse point, unless left to that sweep), prolongation + correction (16 B per point + 8 B per coarse
+    # point; folded into the first post-smoothing sweep: the 8 B per coarse point only)
     comp = 0.0
     for l in range(L - 4, L + 1):
         lb, le = dom.loop_bounds(P.Solution[l].layout)
         lcb, lce = dom.loop_bounds(P.Solution[l - 1].layout)
         p = float((le[0] - lb[0]) * (le[1] - lb[1]) * (le[2] - lb[2]))
         c = float((lce[0] - lcb[0]) * (lce[1] - lcb[1]) * (lce[2] - lcb[2]))
-        comp += 6 * 24.0 * p + 16.0 * p + 8.0 * c + 8.0 * c + 16.0 * p + 8.0 * c
+        comp += 6 * 24.0 * p - (8.0 * p if P._starts_from_zero(l) else 0.0)
+        comp += 16.0 * p + 8.0 * c
+        comp += 0.0 if P._starts_from_zero(l - 1) else 8.0 * c
+        comp += 8.0 * c if P._folds_prolongation(l) else 16.0 * p + 8.0 * c
     npts = 1
     b, e = dom.loop_bounds(P.Solution[L].layout)
     for d in range(3):

@@ -311,6 +311,13 @@ class SolverFromL4(_Program):
                 self.ops.two_stage_eligible(S.lc, self.RHS[l].lc, self.Laplace[l], b, e, b, e)
         return self._one_pass[l]
 
+    def _starts_from_zero(self, l: int) -> bool:
+        """Is `Solution@l = 0` (in mgCycle@(l+1)) left to the first pre-smoothing sweep of level l?"""
+        cfg = self.cfg
+        return bool(cfg.fused_zero_start and cfg.fused_rbgs and self._single_block() and l != cfg.min_level and l < cfg.max_level and
+                    cfg.n_smooth >= 1 and self.Solution[l].bc_fn == FN_ZERO and
+                    not (self._agg is not None and l == cfg.agglomerate_level) and self._one_pass_sweep(l))
+
     def _folds_prolongation(self, l: int) -> bool:
         """Is `Solution@l += Prolongation * Solution@(l-1)` folded into the first post-smoothing sweep of level l?"""
         cfg = self.cfg
@@ -405,9 +412,7 @@ class SolverFromL4(_Program):
         # functions of the position, written once by setup() -- `apply bc` would re-write the same bits (as in _smooth)
         static_bc = self.cfg.fused_rbgs and self._single_block()
         # ... and a coarser level that starts with a one-pass sweep reads its zero Solution as a constant (its boundary values are 0)
-        zero_start = (self.cfg.fused_zero_start and static_bc and l - 1 != self.cfg.min_level and self.cfg.n_smooth >= 1 and
-                      Sc.bc_fn == FN_ZERO and not (self._agg is not None and l - 1 == self.cfg.agglomerate_level) and
-                      self._one_pass_sweep(l - 1))
+        zero_start = self._starts_from_zero(l - 1)
         if not zero_start:
             ops.set(Sc.lc, Sc.data(), 0.0, b, e)
         if not static_bc:

@@ -44,8 +44,11 @@ def cases(ops, level, with27=True, align=0):
         ("jacobi_1step", lambda: ops.stencil_op(2, L, u, F, f, L, un, A, w, -1, b, e), "k_stencil7_zmarch<2", 24 * pts, pts),
         ("residual", lambda: ops.stencil_op(1, L, u, F, f, L, r, A, 0.0, -1, b, e), "k_stencil7_zmarch<1", 24 * pts, pts),
         ("rbgs_half_sweep", lambda: ops.stencil_op(2, L, u, F, f, L, u, A, w, 0, b, e), "k_stencil7_zmarch<2", 24 * pts, pts // 2),
-        ("jacobi_2step", lambda: ops.jacobi2(L, u, un, None, F, f, A, w, b, e), "k_two_stage7_lds<0, false", 24 * pts, 2 * pts),
-        ("rbgs_fused_sweep", lambda: ops.rbgs_sweep_fused(L, u, un, F, f, A, w, 0, b, e), "k_two_stage7_lds<0, true", 24 * pts, pts),
+        ("jacobi_2step", lambda: ops.jacobi2(L, u, un, None, F, f, A, w, b, e), "k_two_stage7_lds<0, false, 8, true, 1, 0", 24 * pts, 2 * pts),
+        ("rbgs_fused_sweep", lambda: ops.rbgs_sweep_fused(L, u, un, F, f, A, w, 0, b, e), "k_two_stage7_lds<0, true, 8, true, 1, 0", 24 * pts, pts),
+        ("rbgs_fused_sweep_prolong", lambda: ops.rbgs_sweep_fused_prolong(L, u, un, F, f, A, w, 0, b, e, Lc, uc), "k_two_stage7_lds<0, true, 8, true, 4, 1",
+         24 * pts + 8 * cpts, pts),
+        ("rbgs_fused_sweep_zero", lambda: ops.rbgs_sweep_fused_zero(L, un, F, f, A, w, 0, b, e), "k_two_stage7_lds<0, true, 8, true, 1, 2", 16 * pts, pts),
         ("residual_restrict", lambda: ops.residual_restrict(L, u, F, f, L, r, A, Fc, fc, 1.0, b, e, bc, ec), "k_residual_restrict3",
          16 * pts + 8 * cpts, pts),
         ("restrict", lambda: ops.restrict(L, r, Fc, fc, 1.0, bc, ec), "k_restrict3_wide", 8 * pts + 8 * cpts, cpts),

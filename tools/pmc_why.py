@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Memory-side and wave-state counters of the hot kernels: what the time of the streaming kernels goes to.
 
-    for S in A B C D; do rocprofv3 --pmc <set S> --output-format csv -d gpurun_out/pmcY_${S}${TAG} -- python3 tools/pmc_kernels.py --no27 [--align 16]; done
+    for S in A B C D; do rocprofv3 --pmc <set S> --output-format csv -d gpurun_out/pmcY_${S}${TAG} -- python3 tools/pmc_kernels.py [--align 16]; done
     python3 tools/pmc_why.py [--tag _a16] -> profiles/r02_pmc_why[_align16].json
 
 Counter sets (TCC has 4 slots per pass, SQ 8; MI355X_MICROARCH.md, rocprofv3 PMC slots):
@@ -49,7 +49,6 @@ def main():
     args = ap.parse_args()
     go = os.path.join(ROOT, "gpurun_out")
     cases = json.load(open(os.path.join(go, "pmcK_times_L%d%s.json" % (args.level, args.tag))))
-    cases = [c for c in cases if "27entry" not in c["case"]]
     res = {c["case"]: {"ms": c["ms"], "compulsory_bytes": c["compulsory_bytes"]} for c in cases}
     for sname in SETS:
         per_counter = rows_of(os.path.join(go, "pmcY_%s%s" % (sname, args.tag)))
