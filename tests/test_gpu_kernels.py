@@ -484,20 +484,25 @@ def test_restrict_and_prolong_bit_exact(hip, orc, nd, n, scale):
 
 
 @pytest.mark.parametrize("order", ["mp", "pm"])
-@pytest.mark.parametrize("n", [64, 130, 200])
-def test_residual_restrict_fused_bit_exact(hip, orc, n, order):
+@pytest.mark.parametrize("shape,scale,align", [((64, 64, 64), 1.0, 0), ((130, 130, 130), 1.0, 0), ((200, 200, 200), 4.0, 0),
+                                               ((256, 72, 44), 1.0, 16), ((140, 396, 36), 1.0, 0)])
+def test_residual_restrict_fused_bit_exact(hip, orc, shape, scale, align, order):
     """`Residual = RHS - A * Solution` + restriction in one pass (fine residual never stored) against the oracle's two loops;
-    n = 64: short coarse rows, the two-kernel path through the residual array."""
-    st = laplace_fd(3, (1.0 / n,) * 3, order)
+    64^3: short coarse rows, the two-kernel path through the residual array; anisotropic blocks, a padded layout, the
+    restriction scaled by 4 (the generated-from-L3 programs)."""
+    st = laplace_fd(3, tuple(1.0 / s for s in shape), order)
 
     def f(ops):
-        lu, lf, lc = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0), FieldLayout.node(3, (n // 2,) * 3, 0)
+        cs = tuple(s // 2 for s in shape)
+        lu, lf, lc = (FieldLayout.node(3, shape, 1, True, True, align), FieldLayout.node(3, shape, 0, True, False, align),
+                      FieldLayout.node(3, cs, 0, True, False, align))
         u, fr, r, fc = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lc.size)
         ops.fill_random(u, 21)
         ops.fill_random(fr, 22)
-        fb, fe = box(3, n)
-        cb, ce = box(3, n // 2)
-        ops.residual_restrict(lu.c_struct(), u, lf.c_struct(), fr, lu.c_struct(), r, st, lc.c_struct(), fc, 1.0, fb, fe, cb, ce)
+        ops.fill_random(fc, 23)          # the coarse array outside the restriction's box must survive
+        fb, fe = [1, 1, 1], list(shape)
+        cb, ce = [1, 1, 1], list(cs)
+        ops.residual_restrict(lu.c_struct(), u, lf.c_struct(), fr, lu.c_struct(), r, st, lc.c_struct(), fc, scale, fb, fe, cb, ce)
         return [fc]
 
     g, c = both(hip, orc, f)
