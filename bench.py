@@ -506,7 +506,7 @@ def vcycle(ops, dom, comm, L, world, align=0):
     # the gathered coarsest level grows with the blocks (16 x 32 x 64 points on 8 GPUs, 5 ms for a single-workgroup CG): it
     # coarsens log2(max blocks per dimension) levels further, back to a few hundred points
     extra = max(dom.num_blocks).bit_length() - 1 if world > 1 else 0
-    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True, agglomerate_level=agg, fused_prolong_min_points=50_000_000, fused_zero_start=True,
+    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True, agglomerate_level=agg, fused_prolong_min_points=50_000_000, fused_zero_start=True, fused_residual_norm=True,
                    agglomerate_extra_levels=extra, align=align)
     P = SolverFromL4(cfg, ops, dom, comm)
     P.setup()

@@ -353,7 +353,18 @@ extern "C" int examg_axpby_dev(const examg_layout_t *lx, const double *x, const 
   return axpby_impl(lx, x, ly, y, a, b, which + 1, sign, num, den, begin, end, stream);
 }
 
-extern "C" size_t examg_reduce_work_bytes(void) { return (size_t)RED_MAX_BLOCKS * sizeof(double); }
+constexpr int RED_WORK_DOUBLES = 8192;   // >= RED_MAX_BLOCKS; kernels that write one partial sum per wave need more than the dot kernels
+extern "C" size_t examg_reduce_work_bytes(void) { return (size_t)RED_WORK_DOUBLES * sizeof(double); }
+
+namespace examg {
+// for kernels that write their own partial sums (kernels_stencil.hip: examg_residual_norm2)
+size_t reduce_work_doubles() { return (size_t)RED_WORK_DOUBLES; }
+int launch_reduce_sum(const double *part, int n, double *result, hipStream_t s) {
+  hipLaunchKernelGGL((k_reduce_final<false>), dim3(1), dim3(RED_BLOCK), 0, s, part, n, result);
+  EXAMG_CHECK_LAUNCH("k_reduce_final");
+  return 0;
+}
+}  // namespace examg
 
 static int red_blocks(long long total) {
   long long nb = (total + RED_BLOCK * 4 - 1) / (RED_BLOCK * 4);

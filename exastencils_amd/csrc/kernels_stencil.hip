@@ -111,11 +111,20 @@ k_stencilfield_unrolled(LayoutDev lu, const double *__restrict__ u, LayoutDev lf
 // ---------------------------------------------------------------------------------------------
 // 3-D 7-point constant-coefficient z-marching kernel
 // ---------------------------------------------------------------------------------------------
+// kernel-internal mode: the residual's squares are summed instead of the residual being stored (examg_residual_norm2)
+constexpr int ZM_RESNORM = 3;
+
 template <int MODE>
 __device__ __forceinline__ double finish(double u, double acc, double f, double w) {
   if (MODE == EXAMG_APPLY) return acc;
-  if (MODE == EXAMG_RESIDUAL) return f - acc;
+  if (MODE == EXAMG_RESIDUAL || MODE == ZM_RESNORM) return f - acc;
   return u + w * (f - acc);
+}
+
+__device__ __forceinline__ double zm_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = v + __shfl_down(v, o);
+  return v;
 }
 
 struct ZMarchGeom {
@@ -153,7 +162,12 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
   const int rw = box.b1 + (ty * WY + wv) * RY;  // first row of this wave
   const int mb = box.b2 + tz * g.zc;
   const int me = min(mb + g.zc, box.e2);
-  if (rw >= box.e1) return;  // wave-uniform
+  // ZM_RESNORM: `dst` is the array of partial sums, one per wave of the grid (fixed geometry: reproducible run to run)
+  double ssum = 0.0;
+  if (rw >= box.e1) {        // wave-uniform
+    if (MODE == ZM_RESNORM && lane == 0) dst[blockIdx.x * WY + wv] = 0.0;
+    return;
+  }
   const bool va = x >= box.b0 && x < box.e0, vb = x + 1 < box.e0;   // x + 1 >= b0 always
   // right neighbour of b comes from lane+1 unless that lane is past the box
   const bool rload = vb && (lane == 63 || x + 2 >= box.e0);
@@ -168,7 +182,7 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
     const int row = min(rw + r, box.e1);  // clamped rows re-read the upper halo row
     ur[r] = u + lu.origin + xs + lu.s1 * row;
     fr[r] = rhs + lf.origin + xs + lf.s1 * row;
-    dr[r] = dst + ld.origin + xs + ld.s1 * row;
+    dr[r] = MODE == ZM_RESNORM ? dst : dst + ld.origin + xs + ld.s1 * row;
   }
   const double *uhm = u + lu.origin + xs + lu.s1 * (rw - 1);
   const double *uhp = u + lu.origin + xs + lu.s1 * min(rw + RY, box.e1);
@@ -232,7 +246,12 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
         o.x = finish<MODE>(uc[r].x, acc_a, st.f[r].x, w);
         o.y = finish<MODE>(uc[r].y, acc_b, st.f[r].y, w);
       }
-      if (rw + r < box.e1) {
+      if (MODE == ZM_RESNORM) {
+        if (rw + r < box.e1) {
+          if (va) ssum = ssum + o.x * o.x;
+          if (vb) ssum = ssum + o.y * o.y;
+        }
+      } else if (rw + r < box.e1) {
         double *q = dr[r] + ld.s2 * m;
         if (va && vb) store2_nt(q, o);
         else if (va) q[0] = o.x;
@@ -259,6 +278,10 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
       }
     }
   }
+  if (MODE == ZM_RESNORM) {
+    ssum = zm_wave_sum(ssum);
+    if (lane == 0) dst[blockIdx.x * WY + wv] = ssum;
+  }
 }
 
 static thread_local int g_force_generic = 0;  // test hook (debug build only): examg_debug_force_generic
@@ -275,9 +298,10 @@ int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const L
 
 constexpr int ZM_RY = 2, ZM_WY = 4, ZM_BLOCKS = 512, ZM_BLOCKS_COL = 1024, ZM_MINCHUNK = 16;   // half sweeps: 0.68 ms at 512 workgroups, 0.64 at 1024
 
+// returns the number of waves of the grid (ZM_RESNORM: the number of partial sums written to dst)
 template <int MODE, int ORDER>
-static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
+static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
+                         double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
   ZMarchGeom g;
   // Padded layouts (`align`, field/ir/IR_AddPaddingToFieldLayouts.scala:36-41) have even row lengths and put the lower duplicate
   // point on an even index: starting the windows one point to the left of an odd box makes every 16-byte load and store of
@@ -303,10 +327,15 @@ static void launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev 
   if (colour >= 0) {
     if (MODE == EXAMG_SMOOTH)
       hipLaunchKernelGGL((k_stencil7_zmarch<EXAMG_SMOOTH, ORDER, ZM_RY, ZM_WY, true>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
-    return;
+    return (int)grid.x * ZM_WY;
   }
   hipLaunchKernelGGL((k_stencil7_zmarch<MODE, ORDER, ZM_RY, ZM_WY, false>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  return (int)grid.x * ZM_WY;
 }
+
+// kernels_blas.hip
+int launch_reduce_sum(const double *part, int n, double *result, hipStream_t s);
+size_t reduce_work_doubles();
 
 }  // namespace examg
 
@@ -420,6 +449,32 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
     hipLaunchKernelGGL((k_stencil_generic<EXAMG_SMOOTH>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, lc, sd, w, colour, box, row_w);
   EXAMG_CHECK_LAUNCH("k_stencil_generic");
   return 0;
+}
+
+// sum over [begin,end) of (rhs - A u)^2: the residual loop and the reduction loop of the norm as one pass, residual not stored
+extern "C" int examg_residual_norm2(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
+                                    const examg_stencil_t *st, const int32_t *begin, const int32_t *end, const examg_layout_t *lr_,
+                                    double *res, double *result, void *work, examg_stream_t stream) {
+  if (!lu_ || !u || !lf_ || !rhs || !st || !begin || !end || !result || !work) { set_error("examg_residual_norm2: null argument"); return 1; }
+  const Box box = make_box(begin, end);
+  hipStream_t s = (hipStream_t)stream;
+  if (box.count() == 0) return check_hip(hipMemsetAsync(result, 0, sizeof(double), s), "examg_residual_norm2 memset");
+  const int ord = canonical_order7(st);
+  if (!g_force_generic && lu_->nd == 3 && ord >= 0 && box.n0() >= 64 && box_inside(lu_, box, 1) && box_inside(lf_, box, 0)) {
+    const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
+    Coef7 k;
+    for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
+    int n;
+    if (ord == 0) n = launch_zmarch<ZM_RESNORM, 0>(lu, u, lf, rhs, lu, (double *)work, k, 0.0, box, s);
+    else n = launch_zmarch<ZM_RESNORM, 1>(lu, u, lf, rhs, lu, (double *)work, k, 0.0, box, s);
+    EXAMG_CHECK_LAUNCH("k_stencil7_zmarch (residual norm)");
+    if ((size_t)n > reduce_work_doubles()) { set_error("examg_residual_norm2: work buffer too small for %d partial sums", n); return 1; }
+    return launch_reduce_sum((const double *)work, n, result, s);
+  }
+  if (!lr_ || !res) { set_error("examg_residual_norm2: this stencil / box needs the residual array"); return 1; }
+  int rc = examg_stencil_op(EXAMG_RESIDUAL, lu_, u, lf_, rhs, lr_, res, st, 0.0, -1, begin, end, stream);
+  if (rc) return rc;
+  return examg_dot(lr_, res, lr_, res, begin, end, result, work, stream);
 }
 
 extern "C" int examg_jacobi(const examg_layout_t *lu, const double *u, double *u_next, const examg_layout_t *lf,

@@ -148,6 +148,15 @@ class HipOps:
                                self.ptr(self._work), self._stream()), "examg_dot")
         return out
 
+    def residual_norm2(self, lu, u, lf, rhs, st: Stencil, begin, end, lr=None, res=None, out=None):
+        """sum over the box of (rhs - A u)^2 on the device, the residual not stored (examg_residual_norm2)"""
+        out = self.new_scalar() if out is None else out
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_residual_norm2(C.byref(lu), self.ptr(u), C.byref(lf), self.ptr(rhs), C.byref(sc), ivec(begin), ivec(end),
+                                          C.byref(lr) if lr is not None else None, self.ptr(res) if res is not None else None,
+                                          self.ptr(out), self.ptr(self._work), self._stream()), "examg_residual_norm2")
+        return out
+
     def max_err_fn(self, l, x, geom, fn: int, params: Sequence[float], begin, end, out=None):
         out = self.new_scalar() if out is None else out
         return self.max_err_expr(l, x, geom, fn_expr(fn, params), begin, end, out)

@@ -124,6 +124,9 @@ class ConfigL4:
     # single block + fused_rbgs: `Solution@coarser = 0` is not executed where the first pre-smoothing sweep of that level is a
     # one-pass sweep: it takes the zero field as a constant (examg_rbgs_sweep_fused_zero: no zeroing loop, 16 instead of 24 B per point)
     fused_zero_start: bool = False
+    # Solve@finest: `Residual = RHS - A * Solution` + ResNorm as one pass that does not store the residual (nothing reads
+    # Residual@finest between two of the loop's updates when the cycle runs residual + restriction as one pass)
+    fused_residual_norm: bool = False
     overlap_transfers: bool = True            # blocks > 1: residual / restriction as interior + shell around their halo exchange
     agglomerate_level: Optional[int] = None   # blocks > 1: levels <= this are solved redundantly on every rank (see _agg_cycle)
     agglomerate_extra_levels: int = 0         # the gathered hierarchy coarsens this many levels below min_level
@@ -219,6 +222,18 @@ class SolverFromL4(_Program):
     def ResNorm(self, l: int) -> float:
         return math.sqrt(self._dot_host(self.Residual[l], self.Residual[l], self.Residual[l]))
 
+    def _residual_and_norm(self, l: int) -> float:
+        """`Residual = RHS - A * Solution` (statement of Solve@finest) followed by ResNorm()."""
+        cfg = self.cfg
+        if not (cfg.fused_residual_norm and cfg.fused_residual_restrict and self._single_block()):
+            self._update_residual(l)
+            return self.ResNorm(l)
+        S, R, A = self.Solution[l], self.Residual[l], self.Laplace[l]
+        self.communicate(S, axis_only=self._faces_only(A))
+        b, e = self.bounds(R, reduction=True)
+        t = self.ops.residual_norm2(S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), A, b, e, R.lc, R.data())
+        return math.sqrt(self.ops.scalar_value(self.comm.allreduce(t, "sum")))
+
     def _update_residual(self, l: int):
         S, R = self.Solution[l], self.Residual[l]
         b, e = self.bounds(R)
@@ -273,8 +288,7 @@ class SolverFromL4(_Program):
     # Function Solve@finest (...exa4:121-150)
     def Solve(self, use_graph: bool = False) -> int:
         cfg, hi = self.cfg, self.cfg.max_level
-        self._update_residual(hi)
-        initRes = self.ResNorm(hi)
+        initRes = self._residual_and_norm(hi)
         curRes = initRes
         self.res_history.append(initRes)
         self.log.append(reduced_prec(initRes))
@@ -292,8 +306,7 @@ class SolverFromL4(_Program):
                 err = self.ops.scalar_value(self.comm.allreduce(t, "max"))
                 self.err_history.append(err)
                 self.log.append(reduced_prec(err))
-            self._update_residual(hi)
-            curRes = self.ResNorm(hi)
+            curRes = self._residual_and_norm(hi)
             self.res_history.append(curRes)
             self.log.append(reduced_prec(curRes))
         self.iterations = curIt

@@ -213,6 +213,16 @@ size_t examg_reduce_work_bytes(void);
 int examg_dot(const examg_layout_t *lx, const double *x, const examg_layout_t *ly, const double *y,
               const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream);
 
+/* `Residual = RHS - A * Solution` followed by the norm's reduction loop (`ResNorm`, Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:113-119
+ * after :215-219) as ONE pass when nothing else reads the residual: *result (device) = sum over [begin,end) of (rhs - A u)^2, the
+ * residual is not stored (16 B per point instead of 24 + 8).  [begin,end) is the reduction loop's box (the residual is only needed
+ * there).  3-D 7-point constant stencils on long rows take the one-pass kernel and never touch `res` / `lr` (may be NULL); everything
+ * else runs examg_residual + examg_dot through `res`.  Same partial sums every run; their order differs from examg_dot's (1e-15
+ * relative).  `work`: examg_reduce_work_bytes() bytes. */
+int examg_residual_norm2(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs,
+                         const examg_stencil_t *st, const int32_t *begin, const int32_t *end, const examg_layout_t *lr, double *res,
+                         double *result, void *work, examg_stream_t stream);
+
 /* ---- analytic expressions as stack programs: the ONE mechanism for boundary values, right-hand sides, exact solutions and
  * coefficient profiles (round 1 also had 17 built-in function ids of the reference's test programs; they are gone -- the same
  * expression trees now travel as programs, exastencils_amd/field.py:FN_PROGRAMS) --------------------------------------- ------------------------------------------------------------------------

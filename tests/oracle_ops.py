@@ -137,6 +137,16 @@ class OracleOps:
         out[0] = self.L.orc_dot(_lp(lx), self.ptr(x), _lp(ly), self.ptr(y), _iv(begin), _iv(end))
         return out
 
+    def residual_norm2(self, lu, u, lf, rhs, st, begin, end, lr=None, res=None, out=None):
+        import torch
+
+        n = 1
+        for d in range(3):
+            n *= sum(getattr(lu, k)[d] for k in ("pad_l", "ghost_l", "dup_l", "inner", "dup_r", "ghost_r", "pad_r"))
+        tmp = torch.zeros(n, dtype=torch.float64)
+        self.stencil_op(1, lu, u, lf, rhs, lu, tmp, st, 0.0, -1, begin, end)
+        return self.dot(lu, tmp, lu, tmp, begin, end, out)
+
     def cg_coarse(self, lu, sol, lf, rhs, lr, res, lp, p, lq, ap, st, geom, face_mask, max_it, rel_tol, begin, end, info):
         """The statements examg_cg_coarse fuses (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:152-201), one oracle loop each."""
         import math

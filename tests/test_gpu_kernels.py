@@ -509,6 +509,30 @@ def test_residual_restrict_fused_bit_exact(hip, orc, shape, scale, align, order)
     assert_same(g, c, "residual_restrict")
 
 
+@pytest.mark.parametrize("shape,order", [((130, 130, 130), "mp"), ((200, 72, 44), "pm"), ((256, 256, 64), "mp"), ((40, 40, 40), "mp")])
+def test_residual_norm_in_one_pass(hip, orc, shape, order):
+    """examg_residual_norm2 (the residual's squares summed where the residual loop would store it) against the oracle's
+    residual loop + reduction loop: 1e-13 relative (summation order), the same bits on a second call; 40^3 takes the
+    two-kernel path through the residual array; the box leaves out the upper planes like a reduction box with neighbours."""
+    st = laplace_fd(3, tuple(1.0 / s for s in shape), order)
+    lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0, True, False)
+    b, e = [1, 1, 1], [shape[0], shape[1] - 1, shape[2]]
+
+    def f(ops):
+        u, fr, r = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size)
+        ops.fill_random(u, 31)
+        ops.fill_random(fr, 32)
+        return u, fr, r
+
+    u, fr, r = f(hip)
+    got = [hip.scalar_value(hip.residual_norm2(lu.c_struct(), u, lf.c_struct(), fr, st, b, e, lu.c_struct(), r)) for _ in range(2)]
+    u, fr, r = f(orc)
+    orc.stencil_op(RESIDUAL, lu.c_struct(), u, lf.c_struct(), fr, lu.c_struct(), r, st, 0.0, -1, b, e)
+    want = orc.scalar_value(orc.dot(lu.c_struct(), r, lu.c_struct(), r, b, e))
+    assert got[0] == got[1]
+    assert abs(got[0] - want) <= 1e-13 * want, (got, want)
+
+
 def test_restrict_on_a_block_with_interior_faces(hip, orc):
     """Coarse loop bounds of a block with neighbours (iteration offsets 0): the fine footprint reaches the ghost layers;
     long rows take the wide kernel, a partial last tile included."""

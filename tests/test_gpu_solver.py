@@ -373,6 +373,25 @@ def test_folded_prolongation_changes_no_bit(hip):
     assert np.array_equal(sols[0].view(np.uint64), sols[1].view(np.uint64))
 
 
+def test_residual_norm_in_one_pass_keeps_the_history(hip):
+    """Solve@finest with `Residual = ...` + ResNorm() as one pass that never stores the residual: same iteration count, every
+    norm within 1e-13 (summation order of the reduction), same solution bits (the cycle never reads Residual@finest)."""
+    from exastencils_amd.solver import ConfigL4, SolverFromL4
+
+    hist, sols = [], []
+    for fused in (False, True):
+        P = SolverFromL4(ConfigL4(nd=3, min_level=2, max_level=7, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True,
+                                  fused_residual_norm=fused), hip)
+        P.setup()
+        P.Solve()
+        hist.append(P.res_history)
+        sols.append(hip.to_host(P.Solution[7].data()).copy())
+    assert len(hist[0]) == len(hist[1]) > 4
+    for a, b in zip(*hist):
+        assert abs(a - b) <= 1e-13 * a, (a, b)
+    assert np.array_equal(sols[0].view(np.uint64), sols[1].view(np.uint64))
+
+
 def test_fused_residual_restrict_changes_no_bit(hip):
     """V-cycles with residual + restriction as one pass (fine residual never stored) print the same history, bit for bit."""
     from exastencils_amd.solver import ConfigL4, SolverFromL4

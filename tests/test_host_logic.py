@@ -46,7 +46,8 @@ def test_folded_prolongation_in_the_host_driver():
     hist = []
     for min_points in (0, 1):
         P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, tol=1e-8, fused_coarse=False, fused_rbgs=True,
-                                  fused_prolong_min_points=min_points, fused_zero_start=bool(min_points)), OracleOps())
+                                  fused_prolong_min_points=min_points, fused_zero_start=bool(min_points), fused_residual_restrict=True,
+                                  fused_residual_norm=bool(min_points)), OracleOps())
         P.setup()
         P.Solve()
         assert P._folds_prolongation(4) == bool(min_points)

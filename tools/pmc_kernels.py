@@ -53,6 +53,7 @@ def cases(ops, level, with27=True, align=0):
          16 * pts + 8 * cpts, pts),
         ("restrict", lambda: ops.restrict(L, r, Fc, fc, 1.0, bc, ec), "k_restrict3_wide", 8 * pts + 8 * cpts, cpts),
         ("prolong_add", lambda: ops.prolong_add(Lc, uc, L, u, b, e), "k_prolong_add3_pairs", 16 * pts + 8 * cpts, pts),
+        ("residual_norm", lambda: ops.residual_norm2(L, u, F, f, A, b, e, out=out), "k_stencil7_zmarch<3", 16 * pts, pts),
         ("dot_norm", lambda: ops.dot(L, r, L, r, b, e, out), "k_dot_rows", 8 * pts, pts),
     ]
     if with27:
