@@ -54,6 +54,7 @@ def parse():
                     help="row padding of the field layouts in doubles (IR_AddPaddingToFieldLayouts); 0 = the verbatim reference layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true")
+    ap.add_argument("--preflight-timeout", type=float, default=180.0, help="N > 1: seconds the first exchange + pass may take")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-temporal-blocking", action="store_true", help="one kernel launch per smoother step")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
@@ -264,9 +265,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # communicator set-up (RCCL connects peers lazily at the first point-to-point batch) is not part of any step
+    # communicator set-up (RCCL connects peers lazily at the first point-to-point batch) is not part of any step.  At N > 1 a
+    # transport that never completes its first exchange must not look like a slow benchmark: a watchdog ends the process with a
+    # diagnosis (exit code 4; EXAMG_TRANSPORT=torch keeps the messages on torch.distributed)
+    preflight_done = None
+    if world > 1:
+        import threading
+
+        preflight_done = threading.Event()
+
+        def preflight_watchdog():
+            if not preflight_done.wait(args.preflight_timeout):
+                sys.stderr.write("bench.py rank %d: first halo exchange / barrier did not complete within %g s (transport %r); "
+                                 "EXAMG_TRANSPORT=torch selects the torch.distributed point-to-point path\n"
+                                 % (rank, args.preflight_timeout, getattr(comm, "transport", None)))
+                sys.stderr.flush()
+                os._exit(4)
+
+        threading.Thread(target=preflight_watchdog, daemon=True).start()
     comm.exchange(Solution, Solution.active, "ghost", axis_only=True)
     barrier()
+    if world > 1:
+        steps(2)               # one overlapped pass with its exchanges on the side stream
+        barrier()
+        preflight_done.set()
     steps(args.warmup)
     barrier()
     t0 = time.perf_counter()

@@ -65,7 +65,10 @@ class Communicator:
         # transport selection: the C transport whenever the kernel layer is libexamg on a GPU and messages need no host staging
         on_gpu = hasattr(ops, "L") and hasattr(ops.L, "examg_exchange") and getattr(getattr(ops, "device", None), "type", "cpu") != "cpu"
         if transport == "auto":
-            transport = "c" if (on_gpu and not self._stage) else "torch"
+            import os
+
+            forced = os.environ.get("EXAMG_TRANSPORT", "")       # "torch": keep every message on torch.distributed (diagnosis)
+            transport = forced if forced in ("c", "torch") else ("c" if (on_gpu and not self._stage) else "torch")
         if transport == "c" and not on_gpu:
             raise RuntimeError("the C transport needs the HIP kernel layer (HipOps)")
         self.transport = transport
