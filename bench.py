@@ -54,6 +54,7 @@ def parse():
                     help="row padding of the field layouts in doubles (IR_AddPaddingToFieldLayouts); 0 = the verbatim reference layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true")
+    ap.add_argument("--settle-steps", type=int, default=150, help="untimed smoother steps before the warm-up (device clocks reach their steady state)")
     ap.add_argument("--preflight-timeout", type=float, default=180.0, help="N > 1: seconds the first exchange + pass may take")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-temporal-blocking", action="store_true", help="one kernel launch per smoother step")
@@ -289,6 +290,12 @@ def main():
         steps(2)               # one overlapped pass with its exchanges on the side stream
         barrier()
         preflight_done.set()
+    # Clock settle (untimed, before the W warm-up steps): when load arrives on an idle device the power management overshoots
+    # for the first ~30 ms -- passes of 0.67 ms rise to 0.90 ms and come back to 0.66-0.69 ms (tools/pass_times.py) -- so the
+    # first ten passes after an idle period run ~20 % below the steady state every longer run sees (1000 steps: 0.329 ms per step,
+    # 20 steps from idle: 0.395).  The same smoother steps are run for --settle-steps steps first; the timed region is unchanged.
+    steps(2 * (args.settle_steps // 2))
+    barrier()
     steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -355,6 +362,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": 2 * (args.settle_steps // 2),
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
@@ -541,7 +549,9 @@ def vcycle(ops, dom, comm, L, world, align=0):
     else:
         P.mgCycle(L)
         run = lambda: P.mgCycle(L)
-    n = 5
+    for _ in range(8):     # ~50 ms of cycles first: the clock transient of a device that was idle (see main) is over
+        run()
+    n = 10
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
