@@ -1,3 +1,4 @@
+# gpurun -- "bash tools/gpu_bench_steps.sh": the headline at 20 / 50 / 200 timed steps (they agree once the clock-settle phase has run)
 for K in 20 50 200; do
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-kernel-table --steps $K --warmup 5 2>/dev/null | python -c "
 import json,sys

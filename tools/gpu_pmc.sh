@@ -1,3 +1,5 @@
+# gpurun -- "bash tools/gpu_pmc.sh": timing pass, FETCH_SIZE / WRITE_SIZE passes and the four why-counter sets of tools/pmc_kernels.py for the verbatim and
+# the align=16 layout; afterwards, locally: cp gpurun_out/r02_pmc_kernels*.json profiles/ (see the file names in the script); python3 tools/pmc_why.py [--tag _a16]
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out; rm -rf gpurun_out/pmcK_FETCH* gpurun_out/pmcK_WRITE* gpurun_out/pmcY_*
 for AL in 0 16; do
 TAG=""; [ $AL -ne 0 ] && TAG="_a$AL"

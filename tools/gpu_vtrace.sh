@@ -1,3 +1,4 @@
+# gpurun -- "bash tools/gpu_vtrace.sh": kernel timeline of one V(3,3) cycle at 512^3 (rocprofv3 --kernel-trace) -> gpurun_out/vtrace.txt
 set -o pipefail
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
