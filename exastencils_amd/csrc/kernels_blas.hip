@@ -353,7 +353,7 @@ extern "C" int examg_axpby_dev(const examg_layout_t *lx, const double *x, const 
   return axpby_impl(lx, x, ly, y, a, b, which + 1, sign, num, den, begin, end, stream);
 }
 
-constexpr int RED_WORK_DOUBLES = 8192;   // >= RED_MAX_BLOCKS; kernels that write one partial sum per wave need more than the dot kernels
+constexpr int RED_WORK_DOUBLES = 32768;   // >= RED_MAX_BLOCKS; kernels that write one partial sum per wave need more than the dot kernels
 extern "C" size_t examg_reduce_work_bytes(void) { return (size_t)RED_WORK_DOUBLES * sizeof(double); }
 
 namespace examg {

@@ -301,7 +301,7 @@ constexpr int ZM_RY = 2, ZM_WY = 4, ZM_BLOCKS = 512, ZM_BLOCKS_COL = 1024, ZM_MI
 // returns the number of waves of the grid (ZM_RESNORM: the number of partial sums written to dst)
 template <int MODE, int ORDER>
 static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
-                         double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1) {
+                         double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1, int max_waves = 0) {
   ZMarchGeom g;
   // Padded layouts (`align`, field/ir/IR_AddPaddingToFieldLayouts.scala:36-41) have even row lengths and put the lower duplicate
   // point on an even index: starting the windows one point to the left of an odd box makes every 16-byte load and store of
@@ -324,6 +324,7 @@ static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &
   g.ntz = (box.n2() + zc - 1) / zc;
   g.colour = colour;
   dim3 block(64, ZM_WY, 1), grid(g.ntx * g.nty * g.ntz, 1, 1);
+  if (max_waves > 0 && (long long)grid.x * ZM_WY > max_waves) return -1;     // nothing launched
   if (colour >= 0) {
     if (MODE == EXAMG_SMOOTH)
       hipLaunchKernelGGL((k_stencil7_zmarch<EXAMG_SMOOTH, ORDER, ZM_RY, ZM_WY, true>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
@@ -464,12 +465,14 @@ extern "C" int examg_residual_norm2(const examg_layout_t *lu_, const double *u, 
     const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
     Coef7 k;
     for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
-    int n;
-    if (ord == 0) n = launch_zmarch<ZM_RESNORM, 0>(lu, u, lf, rhs, lu, (double *)work, k, 0.0, box, s);
-    else n = launch_zmarch<ZM_RESNORM, 1>(lu, u, lf, rhs, lu, (double *)work, k, 0.0, box, s);
-    EXAMG_CHECK_LAUNCH("k_stencil7_zmarch (residual norm)");
-    if ((size_t)n > reduce_work_doubles()) { set_error("examg_residual_norm2: work buffer too small for %d partial sums", n); return 1; }
-    return launch_reduce_sum((const double *)work, n, result, s);
+    int n;      // one partial sum per wave of the grid; a box with more waves than the work buffer holds takes the two-kernel path
+    const int cap = (int)reduce_work_doubles();
+    if (ord == 0) n = launch_zmarch<ZM_RESNORM, 0>(lu, u, lf, rhs, lu, (double *)work, k, 0.0, box, s, -1, cap);
+    else n = launch_zmarch<ZM_RESNORM, 1>(lu, u, lf, rhs, lu, (double *)work, k, 0.0, box, s, -1, cap);
+    if (n > 0) {
+      EXAMG_CHECK_LAUNCH("k_stencil7_zmarch (residual norm)");
+      return launch_reduce_sum((const double *)work, n, result, s);
+    }
   }
   if (!lr_ || !res) { set_error("examg_residual_norm2: this stencil / box needs the residual array"); return 1; }
   int rc = examg_stencil_op(EXAMG_RESIDUAL, lu_, u, lf_, rhs, lr_, res, st, 0.0, -1, begin, end, stream);

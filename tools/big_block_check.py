@@ -60,6 +60,28 @@ ops.restrict(L, u, Lc, fc2, 1.0, bc, ec)
 ops.L.examg_debug_restrict(1)
 out["restrict_wide_equals_plain"] = bool(torch.equal(fc1, fc2))
 out["restrict_ms"] = timed(lambda: ops.restrict(L, u, Lc, fc1, 1.0, bc, ec))
+# correction + sweep in one pass vs correction loop, then the fused sweep; sweep of the zero field vs zeroing + fused sweep
+lcu = FieldLayout.node(3, (n // 2,) * 3, 1)
+uc = ops.new_array(lcu.size)
+ops.fill_random(uc, 3)
+Lcu = lcu.c_struct()
+a.copy_(u)
+ops.prolong_add(Lcu, uc, L, a, b, e)
+t.copy_(u)
+ops.rbgs_sweep_fused(L, a, t, F, f, A, w, 0, b, e)
+b_.copy_(u)
+ops.rbgs_sweep_fused_prolong(L, u, b_, F, f, A, w, 0, b, e, Lcu, uc)
+out["sweep_with_folded_correction_equals_two_launches"] = bool(torch.equal(t, b_))
+out["sweep_with_folded_correction_ms"] = timed(lambda: ops.rbgs_sweep_fused_prolong(L, u, b_, F, f, A, w, 0, b, e, Lcu, uc))
+a.zero_(); t.zero_(); b_.zero_()
+ops.rbgs_sweep_fused(L, a, t, F, f, A, w, 0, b, e)
+ops.rbgs_sweep_fused_zero(L, b_, F, f, A, w, 0, b, e)
+out["zero_field_sweep_equals_sweep_of_zeros"] = bool(torch.equal(t, b_))
+# residual + norm in one pass vs residual loop + reduction
+ops.stencil_op(1, L, u, F, f, L, a, A, 0.0, -1, b, e)
+want = ops.scalar_value(ops.dot(L, a, L, a, b, e))
+got = ops.scalar_value(ops.residual_norm2(L, u, F, f, A, b, e))
+out["residual_norm2_rel_diff"] = abs(got - want) / want
 pts = (n - 1) ** 3
 out["jacobi2_lups"] = 2 * pts / (out["jacobi2_ms"] * 1e-3)
 out["jacobi2_algorithmic_gbs"] = 48.0 * pts / (out["jacobi2_ms"] * 1e-3) / 1e9
