@@ -453,6 +453,27 @@ def test_cpp_host_program_matches_oracle():
     assert mg.compare_with_golden(printed, "\n".join(O.log)) == []
 
 
+@pytest.mark.parametrize("fold_min_points", [1, 50_000_000])
+def test_cpp_fast_host_program_matches_oracle(fold_min_points):
+    """examples/poisson3d_fast_host.cpp: the same program on the one-pass entry points (fused sweeps, residual + restriction,
+    zero-field first sweep, correction folded into the first post-smoothing sweep, residual + norm) with the cycle replayed
+    from a hipGraph, all from C++: the oracle's history within 1e-10, the same iteration count."""
+    import subprocess
+
+    import __graft_entry__ as ge
+
+    exe = ge.build_example(name="poisson3d_fast_host")
+    out = subprocess.run([exe, "7", "2", str(fold_min_points)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    hist = [float(l[2:]) for l in out.stdout.splitlines() if l.startswith("# ")]
+    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=2, max_level=7, tol=1e-6))
+    O.setup()
+    O.Solve()
+    _close(hist, O.res_history)
+    assert "iterations %d" % O.iterations in out.stdout
+    assert any(l.startswith("vcycle_ms") for l in out.stdout.splitlines())
+
+
 def test_config3_512_properties(hip):
     """Config 3 (512^3, levels 4..9) at full size, through size-independent properties: the V-cycle contracts
     the residual by the factor the oracle shows at 128^3 (multigrid convergence is h-independent), the history
