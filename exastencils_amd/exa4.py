@@ -1176,6 +1176,9 @@ class Exa4Program:
             return self._exec_reduction(f, boxes, reduction, body, fr)
         if body and all(st[0] == "assign" and st[2][0] == "sentry" for st in body):
             return self._exec_stencil_field_init(body, boxes, fr)
+        if (len(body) == 1 and body[0][0] == "assign" and body[0][1] == "=" and body[0][2][0] == "fld" and colour is None
+                and self._is_std_rand(body[0][3])):
+            return self._exec_rand_fill(body[0][2], boxes, fr)
         for st in body:
             if st[0] != "assign":
                 raise Exa4Unsupported("statement %r inside a loop body" % st[0])
@@ -1185,6 +1188,54 @@ class Exa4Program:
                 self._bc_valid -= {(tf.name, tf.level, sl) for sl in range(tf.num_slots)}
             for b, e in boxes:
                 self._exec_point_assign(st, b, e, colour, fr)
+
+    # `loop over F sequentially { F = native("((double)std::rand()/RAND_MAX)") }` (Testing/Opts/base.exa4:161-165): the generated
+    # loop nest calls the C library's rand() once per point, x fastest.  The reference's results files were produced with glibc,
+    # whose rand() is the TYPE_3 additive feedback generator (r[i] = r[i-3] + r[i-31], 310 values discarded, seed 1, result >> 1):
+    # restated here on the host; the values are uploaded into the field.  One generator per program run, as in a process.
+    @staticmethod
+    def _is_std_rand(e) -> bool:
+        return (e[0] == "call" and e[1] == "native" and len(e[3]) == 1 and e[3][0][0] == "str"
+                and e[3][0][1].replace(" ", "") == "((double)std::rand()/RAND_MAX)")
+
+    def _glibc_rand(self, n: int):
+        import numpy as np
+
+        st = getattr(self, "_rand_state", None)
+        if st is None:
+            r = [1]
+            for i in range(1, 31):
+                hi, lo = divmod(r[i - 1], 127773)
+                w = 16807 * lo - 2836 * hi
+                r.append(w + 2147483647 if w < 0 else w)
+            for i in range(31, 34):
+                r.append(r[i - 31])
+            for i in range(34, 344):
+                r.append((r[i - 31] + r[i - 3]) & 0xFFFFFFFF)
+            st = self._rand_state = r[-31:]
+        out = np.empty(n, dtype=np.float64)
+        for i in range(n):
+            v = (st[-31] + st[-3]) & 0xFFFFFFFF
+            st.append(v)
+            del st[0]
+            out[i] = (v >> 1) / 2147483647.0
+        return out
+
+    def _exec_rand_fill(self, target, boxes, fr: _Frame):
+        f, slot = self._field(target, fr)
+        lay = f.layout
+        host = self.ops.to_host(f.data(slot)).copy().reshape(lay.shape_zyx)
+        for b, e in boxes:
+            n = 1
+            for d in range(3):
+                n *= max(0, e[d] - b[d])
+            if n == 0:
+                continue
+            vals = self._glibc_rand(n).reshape(e[2] - b[2], e[1] - b[1], e[0] - b[0])
+            sl = tuple(slice(lay.ref(d) + b[d], lay.ref(d) + e[d]) for d in (2, 1, 0))
+            host[sl] = vals
+        f.data(slot).copy_(self.ops.from_host(host.reshape(-1)))
+        self.launches += 1
 
     # pattern helpers ---------------------------------------------------------------------------------------------------
     def _is_scalar(self, e) -> bool:

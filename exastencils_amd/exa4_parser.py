@@ -183,11 +183,40 @@ class Parser:
                 self._stencil_field()
             elif t.text == "Globals":
                 self._globals()
+            elif t.text == "LayoutTransformations":
+                self._layout_transformations()
             elif t.text in ("Function", "Func", "Def", "noinline"):
                 self._function()
             else:
                 raise Exa4SyntaxError("line %d: unexpected %r at top level" % (t.line, t.text))
         return self
+
+    def _layout_transformations(self):
+        """`LayoutTransformations { transform F@lvls with [x, y, z] => [...] | concat @lvls A, B into M | rename F@lvl to N }`
+        (layoutTransformation/l4/L4_LayoutSection.scala; Testing/LayoutTrafo/rbgs.exa4:1-6): directives about where the values of
+        a field live in memory -- they change no value a program computes or prints (the reference checks these programs against
+        the .results files of the untransformed ones, .gitlab-ci.yml:760-767).  Recorded, not applied: fields stay in the
+        reference layout, which is the library's contract with its callers."""
+        self.expect("LayoutTransformations")
+        self.expect("{")
+        depth, cur, line = 1, [], self.peek().line
+        self.layout_transformations = getattr(self, "layout_transformations", [])
+        while depth:
+            t = self.next()
+            if t.kind == "eof":
+                raise Exa4SyntaxError("line %d: LayoutTransformations block is not closed" % line)
+            if t.text == "{":
+                depth += 1
+            elif t.text == "}":
+                depth -= 1
+                if depth == 0:
+                    break
+            if t.text in ("transform", "concat", "rename") and depth == 1 and cur:
+                self.layout_transformations.append(" ".join(cur))
+                cur = []
+            cur.append(t.text)
+        if cur:
+            self.layout_transformations.append(" ".join(cur))
 
     def _const_list(self) -> list:
         self.expect("[")
@@ -514,7 +543,10 @@ class Parser:
             self.expect("on")
             self.expect("boundary")
             only = (region, direction)
-        if self.at("starting") or self.at("ending") or self.at("stepping") or self.at("sequentially"):
+        # `sequentially` (baseExt/l4/L4_LoopOverField.scala: no OpenMP/SIMD for this loop) concerns the reference's CPU code
+        # generation only; the statements of a `loop over` are independent per point either way
+        self.accept("sequentially")
+        if self.at("starting") or self.at("ending") or self.at("stepping"):
             raise Exa4Unsupported("line %d: loop modifier %r" % (self.peek().line, self.peek().text))
         where = self.expr() if self.accept("where") else None
         reduction = None

@@ -66,6 +66,61 @@ def test_more_reference_tests_reproduce_their_results_files(name):
     assert mg.compare_with_golden(out, want) == []      # Testing/run_test.py:12-42
 
 
+# programs whose expected output lives under another test's name (the reference's CI pairs them the same way, .gitlab-ci.yml:760-767):
+# the generator-optimisation tests (one program, many knowledge files, one results file) and the layout-transformation tests
+SHARED_RESULTS = [
+    ("Testing/Opts/base.exa4", "Testing/Opts/seq_naive.knowledge", "Testing/Opts/seq.results"),
+    ("Testing/Opts/base.exa4", "Testing/Opts/seq_all.knowledge", "Testing/Opts/seq.results"),
+    ("Testing/LayoutTrafo/opts.exa4", "Testing/LayoutTrafo/seq_naive.knowledge", "Testing/Opts/seq.results"),
+]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("prog,know,res", SHARED_RESULTS)
+def test_opts_and_layout_transformation_programs(prog, know, res):
+    """Testing/Opts: `Solution = native("((double)std::rand()/RAND_MAX)")` in a `sequentially` loop -- the C library's generator,
+    restated (glibc TYPE_3) -- and every optimisation switch of the generator in the knowledge file (none changes a result);
+    Testing/LayoutTrafo: the same program with a `LayoutTransformations` block (storage directives: recorded, not applied)."""
+    from oracle import mg
+
+    if not os.path.exists(os.path.join(REF, know)):
+        pytest.skip("knowledge file not in this checkout")
+    k = knowledge.parse_file(os.path.join(REF, know))
+    k["testing_enabled"] = True
+    with open(os.path.join(REF, prog)) as f:
+        P = exa4.Exa4Program(f.read(), k, ops=OracleOps())
+    out = P.run()
+    with open(os.path.join(REF, res)) as f:
+        assert mg.compare_with_golden(out, f.read()) == []
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_layout_transformed_smoother_program_equals_the_plain_one():
+    """Testing/LayoutTrafo/rbgs.exa4 (transform / concat / rename directives on Solution, RHS, Residual) prints what
+    Testing/Smoothers/RBGS.exa4 prints -- the reference compares it with Smoothers/RBGS.results; here on one 64^3 block
+    (EXAMG_SLOW=1: the 576^3 decomposition of the knowledge file against that results file)."""
+    from oracle import mg
+
+    outs = []
+    for prog in ("Testing/LayoutTrafo/rbgs.exa4", "Testing/Smoothers/RBGS.exa4"):
+        k = knowledge.parse_file(os.path.join(REF, "Testing/LayoutTrafo/RBGS.knowledge"))
+        k["testing_enabled"] = True
+        if not os.environ.get("EXAMG_SLOW"):
+            for a in "xyz":
+                k["domain_rect_numBlocks_" + a] = 1
+                k["domain_rect_numFragsPerBlock_" + a] = 1
+            k["domain_numBlocks"] = k["domain_numFragmentsPerBlock"] = 1
+        with open(os.path.join(REF, prog)) as f:
+            P = exa4.Exa4Program(f.read(), k, ops=OracleOps())
+        outs.append(P.run())
+        if prog.startswith("Testing/LayoutTrafo"):
+            assert len(P.ast.layout_transformations) == 4
+    assert outs[0] == outs[1] and len(outs[0]) > 3
+    if os.environ.get("EXAMG_SLOW"):
+        with open(os.path.join(REF, "Testing/Smoothers/RBGS.results")) as f:
+            assert mg.compare_with_golden(outs[0], f.read()) == []
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
 @pytest.mark.parametrize("name", sorted(REFERENCE_PROGRAMS))
 def test_reference_program_reproduces_its_results_file(name):
