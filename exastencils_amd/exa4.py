@@ -150,10 +150,13 @@ class Exa4Program:
         if self.ast.domain:
             lo = tuple(float(_const_value(e)) for e in self.ast.domain[1]) + (0.0,) * (3 - self.nd)
             hi = tuple(float(_const_value(e)) for e in self.ast.domain[2]) + (1.0,) * (3 - self.nd)
+        self._merged_blocks = None
         if domain is None:
             # one process: the reference's blocks x fragments become one fragment of the same global grid
             flen = tuple(d["frags_total"][i] * d["frag_len"][i] for i in range(3))
             domain = RectDomain(self.nd, (1, 1, 1), 0, flen, lo[:3], hi[:3], d["periodic"])
+            if d["num_blocks"] != (1, 1, 1) and d["frags_per_block"] == (1, 1, 1):
+                self._merged_blocks = (d["num_blocks"], d["frag_len"])      # what a per-process std::rand() needs to know (_exec_rand_fill)
         self.domain = domain
         self.comm = comm or Communicator(domain, ops)
         self.echo = echo
@@ -1198,12 +1201,12 @@ class Exa4Program:
         return (e[0] == "call" and e[1] == "native" and len(e[3]) == 1 and e[3][0][0] == "str"
                 and e[3][0][1].replace(" ", "") == "((double)std::rand()/RAND_MAX)")
 
-    def _glibc_rand(self, n: int):
+    def _glibc_rand(self, n: int, seed: int = 1):
         import numpy as np
 
         st = getattr(self, "_rand_state", None)
         if st is None:
-            r = [1]
+            r = [seed if seed != 0 else 1]        # srand(0) seeds with 1
             for i in range(1, 31):
                 hi, lo = divmod(r[i - 1], 127773)
                 w = 16807 * lo - 2836 * hi
@@ -1225,13 +1228,37 @@ class Exa4Program:
         f, slot = self._field(target, fr)
         lay = f.layout
         host = self.ops.to_host(f.data(slot)).copy().reshape(lay.shape_zyx)
+        if self._merged_blocks is not None:
+            # The knowledge file describes several blocks = processes of the reference, merged into one fragment here.  Every
+            # process of the reference draws from its OWN generator (seeded with its rank) over its own loop box, and the duplicate planes
+            # two processes share end up with the value of the lower one (`communicate`: upper duplicate plane -> the upper
+            # neighbour's lower one, axis by axis): the boxes are filled block by block, highest rank first.
+            nb, flen = self._merged_blocks
+            ranks = nb[0] * nb[1] * nb[2]
+            saved = getattr(self, "_rand_states", None) or [None] * ranks
+            for r in reversed(range(ranks)):
+                sub = RectDomain(self.nd, nb, r, flen)
+                nc = sub.ncells(f.level)
+                sb, se = sub.loop_bounds(FieldLayout.node(self.nd, nc, lay.ghost[0]))
+                gb = [sub.pos[d] * nc[d] + sb[d] if d < self.nd else 0 for d in range(3)]
+                ge = [sub.pos[d] * nc[d] + se[d] if d < self.nd else 1 for d in range(3)]
+                self._rand_state = saved[r]
+                # the generated main() of an MPI program calls std::srand(mpiRank) (parallelization/api/mpi/MPI_IVs.scala:41-45)
+                vals = self._glibc_rand((ge[0] - gb[0]) * (ge[1] - gb[1]) * (ge[2] - gb[2]), seed=r).reshape(ge[2] - gb[2], ge[1] - gb[1], ge[0] - gb[0])
+                saved[r] = self._rand_state
+                host[tuple(slice(lay.ref(d) + gb[d], lay.ref(d) + ge[d]) for d in (2, 1, 0))] = vals
+            self._rand_states, self._rand_state = saved, None
+            f.data(slot).copy_(self.ops.from_host(host.reshape(-1)))
+            self.launches += 1
+            return
         for b, e in boxes:
             n = 1
             for d in range(3):
                 n *= max(0, e[d] - b[d])
             if n == 0:
                 continue
-            vals = self._glibc_rand(n).reshape(e[2] - b[2], e[1] - b[1], e[0] - b[0])
+            # one process of several: the generated main() seeded its generator with the rank (MPI_IVs.scala:41-45)
+            vals = self._glibc_rand(n, seed=self.domain.rank if self.domain.world_size > 1 else 1).reshape(e[2] - b[2], e[1] - b[1], e[0] - b[0])
             sl = tuple(slice(lay.ref(d) + b[d], lay.ref(d) + e[d]) for d in (2, 1, 0))
             host[sl] = vals
         f.data(slot).copy_(self.ops.from_host(host.reshape(-1)))

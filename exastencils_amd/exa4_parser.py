@@ -114,7 +114,8 @@ _SLOT_WORDS = {"active", "activeSlot", "current", "currentSlot", "next", "nextSl
 _LEVEL_WORDS = {"current", "coarser", "finer", "finest", "coarsest", "all"}
 _MATH = {"sqrt": math.sqrt, "fabs": abs, "abs": abs, "sin": math.sin, "cos": math.cos, "tan": math.tan, "exp": math.exp,
          "sinh": math.sinh, "cosh": math.cosh, "tanh": math.tanh, "log": math.log, "pow": math.pow, "max": max, "min": min,
-         "floor": math.floor, "ceil": math.ceil}
+         "floor": math.floor, "ceil": math.ceil, "ldexp": lambda x, e: math.ldexp(float(x), int(e)), "fmod": math.fmod,
+         "asin": math.asin, "acos": math.acos, "atan": math.atan, "atan2": math.atan2, "log10": math.log10}
 _COORD = re.compile(r"^vf_(nodePosition|nodePos|boundaryCoord|boundaryPosition|boundaryPos)_([xyz])$")
 _GRIDW = re.compile(r"^vf_gridWidth_([xyz])$")
 
@@ -190,6 +191,10 @@ class Parser:
             else:
                 raise Exa4SyntaxError("line %d: unexpected %r at top level" % (t.line, t.text))
         return self
+
+    def _bad_comm(self):
+        t = self.peek()
+        raise Exa4SyntaxError("line %d: communicate: expected all / dup / ghost, found %r" % (t.line, t.text))
 
     def _layout_transformations(self):
         """`LayoutTransformations { transform F@lvls with [x, y, z] => [...] | concat @lvls A, B into M | rename F@lvl to N }`
@@ -455,6 +460,19 @@ class Parser:
                 if (self.at("ghost") or self.at("dup") or self.at("all")) and self.at("of", 1):
                     what = self.next().text
                     self.next()
+                elif self.at("ghost") or self.at("dup") or self.at("all"):
+                    # `communicate dup ghost [0, 0, 0] of F` (Testing/Misc/inlining.exa4:157; communication/l4/L4_Communicate.scala):
+                    # a list of layer kinds, each with an optional index range `[b] [to [e]]` of the layers meant.  The kinds are
+                    # honoured; an index range is widened to all layers of its kind -- more layers exchanged, the same values in them
+                    kinds = set()
+                    while not self.at("of"):
+                        kinds.add(self.expect(self.peek().text).text if self.peek().text in ("ghost", "dup", "all") else self._bad_comm())
+                        if self.at("["):
+                            self._const_list()
+                            if self.accept("to"):
+                                self._const_list()
+                    self.next()
+                    what = "all" if ("all" in kinds or kinds >= {"dup", "ghost"}) else kinds.pop()
                 target = self.postfix()
                 if self.accept("where"):      # conditional exchange (Testing/Smoothers/RBGS.exa4:126): same values, full exchange
                     self.expr()
@@ -532,8 +550,11 @@ class Parser:
         self.expect("over")
         if self.at("fragments"):          # `loop over fragments { ... }`: one fragment per process here
             self.next()
-            if self.at("with"):
-                raise Exa4Unsupported("line %d: loop over fragments with reduction" % self.peek().line)
+            if self.accept("with"):       # `with reduction ( + : res )`: the loop over the field inside carries the same clause and
+                self.expect("reduction")  # does the reduction (and the all-reduce across blocks); one fragment per process
+                self.expect("(")
+                while not self.accept(")"):
+                    self.next()
             return ("if", ("num", True), self.block(), [])
         target = self.postfix()
         only = None

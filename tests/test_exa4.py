@@ -41,7 +41,7 @@ SLOW = {"Smoothers_RBGS", "Smoothers_Jac"}      # 576^3 on the CPU
 
 # Further tests of the reference's suite inside the subset: program, knowledge and expected output are all read from the
 # reference checkout (Testing/<name>.{exa4,knowledge,results}); compared under the harness' own rule.
-MORE_REFERENCE_TESTS = ["BC/2D_Polynomial", "BC/2D_Trigonometric", "BC/3D_Polynomial", "BC/3D_Trigonometric", "CommBasic/2D",
+MORE_REFERENCE_TESTS = ["Misc/MathFunctionEvaluation", "Misc/inlining", "BC/2D_Polynomial", "BC/2D_Trigonometric", "BC/3D_Polynomial", "BC/3D_Trigonometric", "CommBasic/2D",
                         "CommBasic/PureOMP", "FMG/2D_ConstCoeff", "FMG/2D_Polynomial", "SISC/2D_ConstCoeff", "SISC/2D_VarCoeff",
                         "CUDA/2D_VarCoeff", "BC/2D_Periodic", "BC/3D_Periodic", "CommBasic/Hybrid", "CommBasic/Strategy26",
                         "CommBasic/Summarize"]
@@ -72,7 +72,11 @@ SHARED_RESULTS = [
     ("Testing/Opts/base.exa4", "Testing/Opts/seq_naive.knowledge", "Testing/Opts/seq.results"),
     ("Testing/Opts/base.exa4", "Testing/Opts/seq_all.knowledge", "Testing/Opts/seq.results"),
     ("Testing/LayoutTrafo/opts.exa4", "Testing/LayoutTrafo/seq_naive.knowledge", "Testing/Opts/seq.results"),
+    # 2 x 2 x 2 processes of 256^3 cells, each with std::srand(mpiRank): run as one merged block, one generator per former process
+    ("Testing/Opts/base_par.exa4", "Testing/Opts/par_naive.knowledge", "Testing/Opts/par.results"),
+    ("Testing/LayoutTrafo/opts.exa4", "Testing/LayoutTrafo/par_all.knowledge", "Testing/Opts/par.results"),
 ]
+SHARED_SLOW = {"Testing/Opts/par_naive.knowledge", "Testing/LayoutTrafo/par_all.knowledge"}      # 512^3 on the CPU, ~1 min each
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
@@ -85,6 +89,8 @@ def test_opts_and_layout_transformation_programs(prog, know, res):
 
     if not os.path.exists(os.path.join(REF, know)):
         pytest.skip("knowledge file not in this checkout")
+    if know in SHARED_SLOW and not os.environ.get("EXAMG_SLOW"):
+        pytest.skip("512^3 on the CPU: set EXAMG_SLOW=1")
     k = knowledge.parse_file(os.path.join(REF, know))
     k["testing_enabled"] = True
     with open(os.path.join(REF, prog)) as f:
@@ -431,6 +437,58 @@ def test_interpreter_on_two_blocks_matches_single_block(tmp_path):
         assert len(meta["values"]) == len(single.printed_values)
         for x, y in zip(meta["values"], single.printed_values):
             assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * single.printed_values[0]
+
+
+# -- the reference's own 2 x 2 x 2 decomposition, one process per block, against the reference's results file -------------------
+def _worker_inlining(rank, world, port, out_dir):
+    import json
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import mg
+
+    from exastencils_amd.comm import Communicator
+
+    mg.lib().orc_set_num_threads(1)
+    ops = OracleOps()
+    base = os.path.join(REF, "Testing", "Misc", "inlining")
+    k = knowledge.parse_file(base + ".knowledge")
+    k["testing_enabled"] = True
+    dom = knowledge.domain_for_rank(k, rank)
+    with open(base + ".exa4") as f:
+        P = exa4.Exa4Program(f.read(), k, ops=ops, domain=dom, comm=Communicator(dom, ops))
+    out = P.run()
+    json.dump({"out": out, "messages": P.comm.stats["messages"]}, open(os.path.join(out_dir, "r%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_reference_program_on_its_own_eight_blocks_reproduces_its_results_file(tmp_path):
+    """Testing/Misc/inlining.{exa4,knowledge}: 2 x 2 x 2 blocks, `Solution = std::rand()/RAND_MAX` with std::srand(mpiRank) in
+    every process -- the duplicate planes of neighbouring blocks start with DIFFERENT values, so the first residual of the results
+    file pins which side `communicate` lets win (own upper plane -> the upper neighbour's lower plane, axis by axis).  Eight
+    processes over gloo, one per block, print the reference's file; so does the one-process run that merges the blocks
+    (test_more_reference_tests_reproduce_their_results_files)."""
+    import json
+
+    import torch.multiprocessing as mp
+    from oracle import mg
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_inlining, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    with open(os.path.join(REF, "Testing", "Misc", "inlining.results")) as f:
+        want = f.read()
+    meta = json.load(open(tmp_path / "r0.json"))
+    assert meta["messages"] > 0
+    assert mg.compare_with_golden(meta["out"], want) == []
 
 
 # -- periodic domain on two blocks: both neighbours along z are the other rank ---------------------------------------------
