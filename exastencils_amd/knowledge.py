@@ -34,6 +34,7 @@ def _value(tok: str):
 
 def parse_text(text: str, base_dir: Optional[str] = None, into: Optional[Dict] = None) -> Dict:
     out = {} if into is None else into
+    text = re.sub(r"/\*.*?\*/", lambda m: "\n" * m.group(0).count("\n"), text, flags=re.S)     # block comments (Settings_Parser.scala)
     for raw in text.splitlines():
         line = raw.split("//", 1)[0].strip()
         if not line:

@@ -43,3 +43,9 @@ def test_import_and_domain(tmp_path):
     assert dom.frag_len == (2, 1, 2)
     assert dom.ncells(5) == (64, 32, 64)
     assert abs(dom.h(5)[0] - 1.0 / 128) < 1e-18 and abs(dom.h(5)[2] - 1.0 / 64) < 1e-18
+
+
+def test_block_comments_are_skipped():
+    """`/* ... */` over several lines (Testing/Application/ExaStokes_2D.knowledge switches whole configurations that way)."""
+    k = K.parse_text("a = 1\n/*// pure mpi\nb = 2\n*/\nc = 3 // x\n/* d = 4 */ e = 5\n")
+    assert k == {"a": 1, "c": 3, "e": 5}
