@@ -391,6 +391,39 @@ def test_syntax_errors_carry_the_line():
         exa4.Parser("Function F {\n loop under u { } }").parse()
 
 
+RANDOM_START = """
+Domain global< [0.0, 0.0, 0.0] to [1.0, 1.0, 1.0] >
+Layout Halo< Real, Node >@all {
+  duplicateLayers = [1, 1, 1] with communication
+  ghostLayers     = [1, 1, 1] with communication
+}
+Field u< global, Halo, 0.0 >@all
+Function Application {
+  loop over u@finest sequentially {
+    u@finest = native ( "((double)std::rand()/RAND_MAX)" )
+  }
+  Var s : Real = 0.0
+  loop over u@finest with reduction ( + : s ) {
+    s += u@finest * u@finest
+  }
+  print ( sqrt ( s ) )
+}
+"""
+
+
+def test_native_rand_fill_is_glibc_rand():
+    """`native("((double)std::rand()/RAND_MAX)")` in a sequential loop: the first values of glibc's rand() after the default seed
+    (1804289383, 846930886, 1681692777 -- the well-known start of the TYPE_3 generator), x fastest over the loop's box."""
+    P = exa4.Exa4Program(RANDOM_START, dict(dimensionality=3, minLevel=2, maxLevel=3), ops=OracleOps())
+    P.run()
+    u = P.fields[("u", 3)]
+    v = OracleOps().to_host(u.data()).reshape(u.layout.shape_zyx)
+    first = v[2, 2, 2:5] * 2147483647.0          # iterator index 1 = array index 2 (one ghost layer, then the duplicate point)
+    assert [int(round(x)) for x in first] == [1804289383, 846930886, 1681692777]
+    assert v[1, :, :].max() == 0.0 and v[2, 1, :].max() == 0.0       # boundary planes untouched
+    assert abs(P.printed_values[0] - float((v ** 2).sum()) ** 0.5) < 1e-12
+
+
 # -- two blocks over gloo ------------------------------------------------------------------------------------------------
 def _worker(rank, world, port, out_dir):
     import json

@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +41,22 @@ def test_rbgs_program_on_gpu(hip):
     plain.run()
     assert plain.printed_values == P.printed_values              # fused sweeps change no bit
     assert plain.launches > P.launches
+
+
+def test_native_rand_fill_on_gpu(hip):
+    """The host-generated std::rand() start values (tests/test_exa4.py: glibc's sequence) reach the device field unchanged."""
+    from oracle_ops import OracleOps
+    from test_exa4 import RANDOM_START
+
+    from exastencils_amd import exa4
+
+    outs = []
+    for ops in (hip, OracleOps()):
+        P = exa4.Exa4Program(RANDOM_START, dict(dimensionality=3, minLevel=2, maxLevel=5), ops=ops)
+        P.run()
+        outs.append((P.printed_values[0], ops.to_host(P.fields[("u", 5)].data()).copy()))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-13 * outs[1][0]
 
 
 def test_jacobi_program_on_gpu(hip):
