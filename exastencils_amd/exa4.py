@@ -1192,76 +1192,25 @@ class Exa4Program:
             for b, e in boxes:
                 self._exec_point_assign(st, b, e, colour, fr)
 
-    # `loop over F sequentially { F = native("((double)std::rand()/RAND_MAX)") }` (Testing/Opts/base.exa4:161-165): the generated
-    # loop nest calls the C library's rand() once per point, x fastest.  The reference's results files were produced with glibc,
-    # whose rand() is the TYPE_3 additive feedback generator (r[i] = r[i-3] + r[i-31], 310 values discarded, seed 1, result >> 1):
-    # restated here on the host; the values are uploaded into the field.  One generator per program run, as in a process.
+    # `loop over F sequentially { F = native("((double)std::rand()/RAND_MAX)") }` (Testing/Opts/base.exa4:166-170): the generated
+    # loop nest calls the C library's rand() once per point, x fastest, in every process after std::srand(mpiRank); the values come
+    # from libexamg's restatement of glibc's generator (exastencils_amd/crand.py), written on the host and uploaded.
     @staticmethod
     def _is_std_rand(e) -> bool:
         return (e[0] == "call" and e[1] == "native" and len(e[3]) == 1 and e[3][0][0] == "str"
                 and e[3][0][1].replace(" ", "") == "((double)std::rand()/RAND_MAX)")
 
-    def _glibc_rand(self, n: int, seed: int = 1):
-        import numpy as np
-
-        st = getattr(self, "_rand_state", None)
-        if st is None:
-            r = [seed if seed != 0 else 1]        # srand(0) seeds with 1
-            for i in range(1, 31):
-                hi, lo = divmod(r[i - 1], 127773)
-                w = 16807 * lo - 2836 * hi
-                r.append(w + 2147483647 if w < 0 else w)
-            for i in range(31, 34):
-                r.append(r[i - 31])
-            for i in range(34, 344):
-                r.append((r[i - 31] + r[i - 3]) & 0xFFFFFFFF)
-            st = self._rand_state = r[-31:]
-        out = np.empty(n, dtype=np.float64)
-        for i in range(n):
-            v = (st[-31] + st[-3]) & 0xFFFFFFFF
-            st.append(v)
-            del st[0]
-            out[i] = (v >> 1) / 2147483647.0
-        return out
-
     def _exec_rand_fill(self, target, boxes, fr: _Frame):
+        from .crand import random_start
+
         f, slot = self._field(target, fr)
-        lay = f.layout
-        host = self.ops.to_host(f.data(slot)).copy().reshape(lay.shape_zyx)
-        if self._merged_blocks is not None:
-            # The knowledge file describes several blocks = processes of the reference, merged into one fragment here.  Every
-            # process of the reference draws from its OWN generator (seeded with its rank) over its own loop box, and the duplicate planes
-            # two processes share end up with the value of the lower one (`communicate`: upper duplicate plane -> the upper
-            # neighbour's lower one, axis by axis): the boxes are filled block by block, highest rank first.
-            nb, flen = self._merged_blocks
-            ranks = nb[0] * nb[1] * nb[2]
-            saved = getattr(self, "_rand_states", None) or [None] * ranks
-            for r in reversed(range(ranks)):
-                sub = RectDomain(self.nd, nb, r, flen)
-                nc = sub.ncells(f.level)
-                sb, se = sub.loop_bounds(FieldLayout.node(self.nd, nc, lay.ghost[0]))
-                gb = [sub.pos[d] * nc[d] + sb[d] if d < self.nd else 0 for d in range(3)]
-                ge = [sub.pos[d] * nc[d] + se[d] if d < self.nd else 1 for d in range(3)]
-                self._rand_state = saved[r]
-                # the generated main() of an MPI program calls std::srand(mpiRank) (parallelization/api/mpi/MPI_IVs.scala:41-45)
-                vals = self._glibc_rand((ge[0] - gb[0]) * (ge[1] - gb[1]) * (ge[2] - gb[2]), seed=r).reshape(ge[2] - gb[2], ge[1] - gb[1], ge[0] - gb[0])
-                saved[r] = self._rand_state
-                host[tuple(slice(lay.ref(d) + gb[d], lay.ref(d) + ge[d]) for d in (2, 1, 0))] = vals
-            self._rand_states, self._rand_state = saved, None
-            f.data(slot).copy_(self.ops.from_host(host.reshape(-1)))
-            self.launches += 1
-            return
-        for b, e in boxes:
-            n = 1
-            for d in range(3):
-                n *= max(0, e[d] - b[d])
-            if n == 0:
-                continue
-            # one process of several: the generated main() seeded its generator with the rank (MPI_IVs.scala:41-45)
-            vals = self._glibc_rand(n, seed=self.domain.rank if self.domain.world_size > 1 else 1).reshape(e[2] - b[2], e[1] - b[1], e[0] - b[0])
-            sl = tuple(slice(lay.ref(d) + b[d], lay.ref(d) + e[d]) for d in (2, 1, 0))
-            host[sl] = vals
-        f.data(slot).copy_(self.ops.from_host(host.reshape(-1)))
+        b, e = self.domain.loop_bounds(f.layout)
+        if len(boxes) != 1 or list(boxes[0][0]) != list(b) or list(boxes[0][1]) != list(e):
+            raise Exa4Unsupported("std::rand() start values on a restricted iteration space")
+        if getattr(self, "_rand_drawn", False):
+            raise Exa4Unsupported("a second loop drawing from std::rand(): the generators' states are not kept between loops")
+        self._rand_drawn = True
+        random_start(self.ops, f, slot, self.domain, self._merged_blocks[0] if self._merged_blocks is not None else None)
         self.launches += 1
 
     # pattern helpers ---------------------------------------------------------------------------------------------------

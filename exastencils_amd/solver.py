@@ -564,6 +564,9 @@ class ConfigL3:
     fused_prolong_min_points: int = 0 # single block + temporal_blocking: Correction folded into the first pair of post-smoothing steps (ConfigL4)
     ksq: float = 0.0                  # stencil 'helmholtz27': shift k^2 of  -div(a grad u) - k^2 u  (config 4)
     rhs_from_solution: bool = False   # RHS = A * sol_fn (discrete manufactured solution)
+    # InitSolution of Testing/Opts/base.exa4:166-170: Solution@finest = (double)std::rand()/RAND_MAX, drawn by every process of the
+    # reference's process grid after std::srand(mpiRank) (exastencils_amd/crand.py); None: Solution starts at zero
+    init_rand_procs: Optional[Tuple[int, int, int]] = None
 
 
 class SolverFromL3(_Program):
@@ -831,6 +834,11 @@ class SolverFromL3(_Program):
             self.ops.stencil_op(APPLY, S.lc, tmp, None, None, F.lc, F.data(), self.Laplace[hi], 0.0, -1, b, e)
         elif cfg.rhs_fn is not None:
             self.InitRHS(hi)
+        if cfg.init_rand_procs is not None:       # Function InitSolution (Testing/Opts/base.exa4:166-170)
+            from .crand import random_start
+
+            S = self.Solution[hi]
+            random_start(self.ops, S, S.active, self.domain, cfg.init_rand_procs)
         for l in self.levels:
             for s_ in range(self.Solution[l].num_slots):
                 self.apply_bc(self.Solution[l], s_)

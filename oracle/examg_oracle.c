@@ -456,6 +456,17 @@ void orc_fill_random(double *x, long n, uint64_t seed) {
   }
 }
 
+/* Start values of `loop over F sequentially { F = native("((double)std::rand()/RAND_MAX)") }` (Testing/Opts/base.exa4:166-170):
+ * the generated nest calls the C library's rand() once per point, x fastest, after std::srand(mpiRank) in an MPI program
+ * (parallelization/api/mpi/MPI_IVs.scala:41-45).  The oracle does what the generated code does: it calls the C library (glibc in
+ * this image, as on the machines the reference's results files come from).  seed < 0: keep the generator's state. */
+void orc_crand_fill(const orc_layout_t *l, double *x, const int32_t *begin, const int32_t *end, int seed) {
+  if (seed >= 0) srand((unsigned)seed);
+  for (int i2 = begin[2]; i2 < end[2]; ++i2)
+    for (int i1 = begin[1]; i1 < end[1]; ++i1)
+      for (int i0 = begin[0]; i0 < end[0]; ++i0) x[lay_idx(l, i0, i1, i2)] = (double)rand() / RAND_MAX;
+}
+
 #ifdef _OPENMP
 #include <omp.h>
 int orc_num_threads(void) { return omp_get_max_threads(); }

@@ -82,6 +82,8 @@ def lib():
         L.orc_restrict.restype = None
         L.orc_prolong_add.argtypes = [lp, dp, lp, dp, ip, ip]
         L.orc_prolong_add.restype = None
+        L.orc_crand_fill.argtypes = [lp, dp, ip, ip, C.c_int]
+        L.orc_crand_fill.restype = None
         L.orc_set.argtypes = [lp, dp, C.c_double, ip, ip]
         L.orc_set.restype = None
         L.orc_axpby.argtypes = [lp, dp, lp, dp, C.c_double, C.c_double, ip, ip]
@@ -738,6 +740,35 @@ class ConfigB:
     align: int = 0
     ksq: float = 0.0
     rhs_from_solution: bool = False
+    # InitSolution of Testing/Opts/base.exa4:166-170: Solution@finest = (double)std::rand()/RAND_MAX in every process of this grid
+    # (std::srand(mpiRank) first); None: Solution starts at zero
+    init_rand_procs: Optional[Tuple[int, int, int]] = None
+
+
+def rand_start(dom: "Domain", S: "FragField", procs):
+    """Every process of the reference fills ITS loop box of Solution<active>@finest from its own generator, seeded with its rank.
+    One fragment per process (decomposed oracle) or all processes' blocks merged into one fragment: then block by block, highest rank
+    first -- a duplicate plane shared by two processes ends up with the LOWER one's values (`communicate`, duplicate phase)."""
+    lay, nd = S.layout, dom.nd
+    nprocs = procs[0] * procs[1] * procs[2]
+    if tuple(dom.nfrag) == tuple(procs):
+        for p in dom.frags:
+            rank = p[0] + procs[0] * (p[1] + procs[1] * p[2])
+            b, e = loop_bounds(dom, lay, p)
+            lib().orc_crand_fill(C.byref(S.lc), _ptr(S.arr(p)), _ivec(b), _ivec(e), rank if nprocs > 1 else 1)
+        return
+    if tuple(dom.nfrag) != (1, 1, 1):
+        raise ValueError("rand_start: one fragment per process, or one merged fragment")
+    sub = Domain(nd, tuple(procs), tuple(dom.frag_len[d] // procs[d] for d in range(3)))
+    nc = sub.ncells(S.level)
+    sublay = Layout.node(nd, nc, lay.ghost[0])
+    p0 = dom.frags[0]
+    for p in reversed(sub.frags):
+        rank = p[0] + procs[0] * (p[1] + procs[1] * p[2])
+        sb, se = loop_bounds(sub, sublay, p)
+        b = [p[d] * nc[d] + sb[d] if d < nd else 0 for d in range(3)]
+        e = [p[d] * nc[d] + se[d] if d < nd else 1 for d in range(3)]
+        lib().orc_crand_fill(C.byref(S.lc), _ptr(S.arr(p0)), _ivec(b), _ivec(e), rank if nprocs > 1 else 1)
 
 
 class ProgramB:
@@ -908,6 +939,8 @@ class ProgramB:
                                      -1, _ivec(b), _ivec(e))
         elif cfg.rhs_fn is not None:
             fill_fn(self.dom, self.RHS[hi], cfg.rhs_fn, (cfg.kappa,))
+        if cfg.init_rand_procs is not None:
+            rand_start(self.dom, self.Solution[hi], cfg.init_rand_procs)
         for l in self.levels:
             for s in range(self.Solution[l].nslots):
                 apply_bc(self.Solution[l], s)

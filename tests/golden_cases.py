@@ -55,6 +55,20 @@ CASES = {
         program="B", nd=3, min_level=0, max_level=5, frags=(4, 4, 4), frag_len=(2, 2, 2), single_len=(8, 8, 8),
         smoother="jacobi", omega=0.85, stencil="varcoeff", restrict_scale=1.0, tol=1e-5, cg_max=1024,
         bc_fn=FN_KAPPA_EXPSOL, rhs_fn=FN_KAPPA_RHS, sol_fn=FN_KAPPA_EXPSOL, coef_fn=FN_KAPPA_COEF, kappa=10.0, fmg=True),
+    # Opts/base.exa4 + seq_*.knowledge (the generator-optimisation tests; results shared by Testing/LayoutTrafo/opts.exa4): the
+    # program of Smoothers/Jac with homogeneous boundary values and Solution@finest = (double)std::rand()/RAND_MAX; one block, 64^3
+    "Opts_seq": dict(
+        program="B", nd=3, min_level=0, max_level=6, frags=(1, 1, 1), frag_len=(1, 1, 1), single_len=(1, 1, 1),
+        smoother="jacobi", omega=0.8, stencil="unit", restrict_scale=4.0, tol=1e-5, cg_max=512, bc_fn=FN_ZERO, init_rand_procs=(1, 1, 1)),
+    # Opts/base_par.exa4 + par_*.knowledge: 2x2x2 processes (std::srand(mpiRank) each), levels 0..8 => 512^3
+    "Opts_par": dict(
+        program="B", nd=3, min_level=0, max_level=8, frags=(2, 2, 2), frag_len=(1, 1, 1), single_len=(2, 2, 2),
+        smoother="jacobi", omega=0.8, stencil="unit", restrict_scale=4.0, tol=1e-5, cg_max=512, bc_fn=FN_ZERO, init_rand_procs=(2, 2, 2)),
+    # Misc/inlining.{exa4,knowledge}: the same cycle, 2x2x2 processes, levels 0..7 => 256^3 (its two finest levels smooth with
+    # `repeat 3 times with contraction [1, 1, 1]` on three ghost layers: the same three Jacobi steps)
+    "Misc_inlining": dict(
+        program="B", nd=3, min_level=0, max_level=7, frags=(2, 2, 2), frag_len=(1, 1, 1), single_len=(2, 2, 2),
+        smoother="jacobi", omega=0.8, stencil="unit", restrict_scale=4.0, tol=1e-5, cg_max=512, bc_fn=FN_ZERO, init_rand_procs=(2, 2, 2)),
 }
 
 

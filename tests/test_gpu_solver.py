@@ -50,6 +50,24 @@ def test_golden_histories_on_gpu(hip, name):
         assert abs(x - y) <= 1e-9 * abs(y) + 1e-12, (P.err_history, O.err_history)
 
 
+@pytest.mark.parametrize("name", ["Opts_seq", "Misc_inlining", "Opts_par"])
+def test_golden_random_start_on_gpu(hip, name):
+    """The reference's random-start goldens (Testing/Opts/{seq,par}.results, Testing/Misc/inlining.results; 64^3, 512^3 and 256^3):
+    start values from libexamg's restatement of glibc's rand(), one generator per process of the reference's grid, uploaded;
+    V(3,3) Jacobi cycles as two-step passes.  The printed history is the reference's; at the sizes the oracle runs in seconds
+    every norm also agrees with the oracle (which calls the C library's rand()) within 1e-10."""
+    P = product_program(name, hip, temporal_blocking=True, fused_residual_restrict=True)
+    P.setup()
+    P.Solve()
+    assert mg.compare_with_golden(P.log, golden_text(name)) == [], P.log
+    if name != "Opts_par":
+        O = oracle_program(name)
+        O.setup()
+        O.Solve()
+        assert P.iterations == O.iterations
+        _close(P.res_history, O.res_history)
+
+
 def test_golden_rbgs_576_on_gpu(hip):
     """Testing/Smoothers/RBGS.results at its full size (576^3) -- only the golden text is checked here, the
     oracle run of this size is in the CPU suite."""

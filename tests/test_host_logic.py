@@ -27,7 +27,7 @@ def product_program(name, ops, domain=None, comm=None, **override):
 
 
 @pytest.mark.parametrize("name", ["CommBasic_PureMPI", "Poisson_2D_FD_Poisson_fromL4", "SISC_3D_ConstCoeff",
-                                  "SISC_3D_VarCoeff", "FMG_3D_Trigonometric"])
+                                  "SISC_3D_VarCoeff", "FMG_3D_Trigonometric", "Opts_seq", "Misc_inlining"])
 def test_host_driver_reproduces_goldens(name):
     P = product_program(name, OracleOps())
     P.setup()

@@ -28,6 +28,20 @@ def test_golden_reference_decomposition(name):
     _run(name, decomposed=True)
 
 
+@pytest.mark.parametrize("name,decomposed", [("Opts_seq", False), ("Misc_inlining", False), ("Misc_inlining", True)])
+def test_golden_random_start(name, decomposed):
+    """Testing/Opts/seq.results, Testing/Misc/inlining.results: the V(3,3) Jacobi cycle started from (double)std::rand()/RAND_MAX --
+    the oracle calls the C library's rand() like the generated code does, after srand(rank) per process.  The merged run fills
+    block by block; the decomposed one (one fragment per process of the 2 x 2 x 2 grid) lets `communicate` decide which of two
+    neighbours' different values a shared duplicate plane keeps: the first residual pins that direction."""
+    _run(name, decomposed)
+
+
+@pytest.mark.slow
+def test_golden_random_start_512():
+    _run("Opts_par", decomposed=False)
+
+
 def test_golden_rbgs_576():
     """Testing/Smoothers/RBGS.results pins the red-black colour convention (colour 0 first)."""
     _run("Smoothers_RBGS", decomposed=False)
