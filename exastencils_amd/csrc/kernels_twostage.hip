@@ -176,12 +176,13 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   // chunk's first plane is even.  Which terms a correction has is known at compile time but for the plane's parity.
   const int cy0 = (rw0 - 3) >> 1;                // first coarse row of the tile
   const int Pa = (mb - 2) >> 1;                  // coarse plane of the first input plane
-  long long cb0[2] = {0, 0};                     // this thread's (up to) two tile elements: global index on coarse plane 0
-  int cel[2] = {0, 0};
-  bool cv[2] = {false, false};
+  // this thread's (up to) two elements of the coarse tile: tid and tid + 64 * NW (index, row and column are recomputed where they
+  // are used -- every second step -- instead of being carried in registers through the plane loop)
   double Cpf[2] = {0.0, 0.0};                    // coarse plane in flight (the next one to enter LDS)
+  auto cel = [&](int kk) { return wv * 64 + lane + kk * 64 * NW; };
   auto cload = [&](int kk, int P) {
-    long long i = cb0[kk] + pr.lc.s2 * (long long)P;
+    const int e = cel(kk), row = e / CW, col = e - row * CW;
+    long long i = pr.lc.origin + (long long)((xw >> 1) + col) + pr.lc.s1 * (long long)(cy0 + row) + pr.lc.s2 * (long long)P;
     i = min(max(i, 0LL), pr.lc.size - 1);      // elements outside the coarse allocation are read by nobody
     return pr.uc[i];
   };
@@ -230,24 +231,14 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     else if (wv == NW - 1) O = corr(O, pon && orowon, Th, Tl, NW + 1, F_{}, OPc);
   };
   if constexpr (PROL) {
-    const int cx0 = xw >> 1;
-    const int tid = wv * 64 + lane;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int e = tid + kk * 64 * NW;
-      const int row = e / CW, col = e - row * CW;
-      cel[kk] = e;
-      cv[kk] = e < CT;
-      cb0[kk] = pr.lc.origin + (long long)(cx0 + col) + pr.lc.s1 * (long long)(cy0 + row);
-    }
     // coarse planes Pa, Pa + 1 cover the input planes mb-2 .. mb; plane Pa + 2 is in flight
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      if (!cv[kk]) continue;
+      if (cel(kk) >= CT) continue;
       const double a0 = cload(kk, Pa), a1 = cload(kk, Pa + 1);
       Cpf[kk] = cload(kk, Pa + 2);
-      CBp[(Pa & 1) * CT + cel[kk]] = a0;
-      CBp[((Pa + 1) & 1) * CT + cel[kk]] = a1;
+      CBp[(Pa & 1) * CT + cel(kk)] = a0;
+      CBp[((Pa + 1) & 1) * CT + cel(kk)] = a1;
     }
     __syncthreads();
     const double *Ta = CBp + (Pa & 1) * CT, *Tb = CBp + ((Pa + 1) & 1) * CT;
@@ -387,8 +378,8 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
           const int Pn = (q + 3) >> 1;
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk)
-            if (cv[kk]) {
-              CBp[(Pn & 1) * CT + cel[kk]] = Cpf[kk];
+            if (cel(kk) < CT) {
+              CBp[(Pn & 1) * CT + cel(kk)] = Cpf[kk];
               Cpf[kk] = cload(kk, Pn + 1);
             }
         }
