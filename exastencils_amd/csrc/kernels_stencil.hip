@@ -287,7 +287,7 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
 static thread_local int g_force_generic = 0;  // test hook (debug build only): examg_debug_force_generic
 // workgroup cap of the unrolled stencil-field kernel: none.  One short-lived workgroup per 256 points, dispatched in order, keeps
 // the front that sweeps the 30 streams (27 coefficient planes, u, rhs, dst) narrow: 512^3, 27 entries: 7.8 ms with 16384
-// grid-striding workgroups, 6.85 ms uncapped (tools/sweep_sf27.py); a tiled form with XCD-contiguous order: 7.7 ms.
+// grid-striding workgroups, 6.85 ms uncapped (round-2 sweep through examg_debug_sf27_blocks); a tiled form with XCD-contiguous order: 7.7 ms.
 static thread_local int g_sf27_blocks = 1 << 30;
 static thread_local int g_sf27_unrolled = 1;  // examg_debug_sf27(0): 27-entry stencil fields on the generic kernel
 

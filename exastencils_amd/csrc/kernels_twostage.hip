@@ -423,7 +423,7 @@ static thread_local int g_ts_disable = 0;
 static thread_local int g_ts_remap = -1;
 static thread_local int g_ts_minzc = -1;     // minimum planes per z chunk; -1: 16, 8 on small boxes
 // Which implementation: 5 / 8 = that many waves per workgroup; -2 = by size.
-// tools/tune_two_stage.py on MI355X, ms for a Jacobi pair / a red-black sweep (all variants bit-identical):
+// round-1 tuning runs on MI355X, ms for a Jacobi pair / a red-black sweep (all variants bit-identical):
 //   512^3: registers 0.97 / 0.93, LDS-5 0.79 / 0.77, LDS-8 0.717 / 0.716 (3072 workgroups), LDS-9 0.87 / 0.85
 //   256^3: LDS-5 0.138, LDS-8 0.119-0.124;  128^3: LDS-5 0.028, LDS-8 0.031
 // ~120 VGPRs -> 4 waves per SIMD = 16 per CU: two 8-wave workgroups fill a CU (a 9-wave workgroup runs alone)
