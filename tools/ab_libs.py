@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""A/B of two builds of libexamg in ONE process, steady state, interleaved rounds: python tools/ab_libs.py libA.so libB.so [n]"""
+import os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from exastencils_amd.field import laplace_fd
+from exastencils_amd.layout import FieldLayout
+from exastencils_amd.ops import HipOps
+
+paths = sys.argv[1:3]
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+opss = [HipOps(0, os.path.abspath(p)) for p in paths]
+ops = opss[0]
+lu, lf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0, True, False)
+lc = FieldLayout.node(3, (n // 2,) * 3, 1)
+u, un, f, uc = ops.new_array(lu.size), ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lc.size)
+ops.fill_random(u, 1); ops.fill_random(f, 2); ops.fill_random(uc, 3)
+A = laplace_fd(3, (1.0 / n,) * 3)
+w = 0.8 / A.diag
+b, e = [1, 1, 1], [n, n, n]
+Ls, Fs, Lc = lu.c_struct(), lf.c_struct(), lc.c_struct()
+cases = {
+    "two Jacobi steps": lambda o: o.jacobi2(Ls, u, un, None, Fs, f, A, w, b, e),
+    "fused red-black sweep": lambda o: o.rbgs_sweep_fused(Ls, u, un, Fs, f, A, w, 0, b, e),
+    "correction + sweep": lambda o: o.rbgs_sweep_fused_prolong(Ls, u, un, Fs, f, A, w, 0, b, e, Lc, uc),
+}
+
+
+def timed(fn, reps=30):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+for name, fn in cases.items():
+    for _ in range(150):
+        fn(opss[0])
+    res = [[], []]
+    for _ in range(5):
+        for i, o in enumerate(opss):
+            fn(o)
+            res[i].append(timed(lambda: fn(o)))
+    print("%-24s %s %.4f   %s %.4f" % (name, os.path.basename(paths[0]), statistics.median(res[0]), os.path.basename(paths[1]), statistics.median(res[1])), flush=True)
