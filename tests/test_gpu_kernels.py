@@ -198,10 +198,10 @@ def two_stage_variant(request, hipd):
 
 @pytest.mark.parametrize("kind", ["rbgs", "jacobi2"])
 @pytest.mark.parametrize("order", ["mp", "pm"])
-@pytest.mark.parametrize("n,first", [(65, 0), (130, 1), (200, 0)])
+@pytest.mark.parametrize("n,first", [(65, 0), (130, 1), (165, 0), (200, 0), (256, 1)])
 def test_two_stage_kernel_bit_exact(orc, two_stage_variant, kind, order, n, first):
     """Fused red-black sweep / two Jacobi steps in one pass == the two loops run one after the other, bit for bit;
-    130 and 200 leave ragged 124-point x windows, row groups and z chunks."""
+    130 ... 256 leave ragged 124-point x windows, row groups and z chunks."""
     hip = two_stage_variant
     st = laplace_fd(3, (1.0 / n,) * 3, order)
     b, e = box(3, n)
