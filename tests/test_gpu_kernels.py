@@ -717,6 +717,48 @@ def test_bad_arguments_fail_loudly(hip):
         hip.stencil_op(RESIDUAL, lu.c_struct(), u, None, None, lu.c_struct(), f, st, 0.1, -1, [1, 1, 1], [n, n, n])
 
 
+def test_bad_arguments_of_the_one_pass_forms_fail_loudly(hip):
+    """The folded-correction, zero-field and residual + norm entry points: aliasing arrays, a coarse field too small for the
+    correction's footprint, a fallback without its scratch array, and null pointers are errors with a message, not launches."""
+    import ctypes as C
+
+    from exastencils_amd import lib
+    from exastencils_amd.lib import ExamgError
+
+    n = 128
+    lu, lf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0, True, False)
+    lc, lc_small = FieldLayout.node(3, (n // 2,) * 3, 1), FieldLayout.node(3, (n // 4,) * 3, 1)
+    st = laplace_fd(3, (1.0 / n,) * 3)
+    w = 0.8 / st.diag
+    u, out, f, uc = hip.new_array(lu.size), hip.new_array(lu.size), hip.new_array(lf.size), hip.new_array(lc.size)
+    b, e = [1, 1, 1], [n, n, n]
+    with pytest.raises(ExamgError, match="out of place"):
+        hip.rbgs_sweep_fused_prolong(lu.c_struct(), u, u, lf.c_struct(), f, st, w, 0, b, e, lc.c_struct(), uc)
+    with pytest.raises(ExamgError, match="coarse footprint"):
+        hip.rbgs_sweep_fused_prolong(lu.c_struct(), u, out, lf.c_struct(), f, st, w, 0, b, e, lc_small.c_struct(), uc)
+    with pytest.raises(ExamgError, match="first colour"):
+        hip.rbgs_sweep_fused_zero(lu.c_struct(), out, lf.c_struct(), f, st, w, 2, b, e)
+    with pytest.raises(ExamgError, match="out of place"):
+        hip.jacobi2_prolong(lu.c_struct(), u, u, None, lf.c_struct(), f, st, w, b, e, lc.c_struct(), uc)
+    # 2-D stencil: residual + norm needs the residual array for its two-kernel path
+    l2, st2 = FieldLayout.node(2, (64, 64, 1), 1), laplace_unit(2)
+    u2, f2 = hip.new_array(l2.size), hip.new_array(l2.size)
+    with pytest.raises(ExamgError, match="needs the residual array"):
+        hip.residual_norm2(l2.c_struct(), u2, l2.c_struct(), f2, st2, [1, 1, 0], [64, 64, 1])
+    r2 = hip.new_array(l2.size)
+    hip.fill_random(u2, 3)
+    got = hip.scalar_value(hip.residual_norm2(l2.c_struct(), u2, l2.c_struct(), f2, st2, [1, 1, 0], [64, 64, 1], l2.c_struct(), r2))
+    hip.stencil_op(RESIDUAL, l2.c_struct(), u2, l2.c_struct(), f2, l2.c_struct(), r2, st2, 0.0, -1, [1, 1, 0], [64, 64, 1])
+    want = hip.scalar_value(hip.dot(l2.c_struct(), r2, l2.c_struct(), r2, [1, 1, 0], [64, 64, 1]))
+    assert got == want
+    L = hip.L
+    assert L.examg_crand_seed(None, 1) != 0 and b"null" in L.examg_last_error()
+    st_ = lib.CrandStateC()
+    assert L.examg_crand_seed(C.byref(st_), 1) == 0
+    lcs = lu.c_struct()
+    assert L.examg_crand_fill_host(C.byref(lcs), None, lib.ivec(b), lib.ivec(e), C.byref(st_)) != 0
+
+
 def test_external_field_copy(hip):
     """get<Name>/set<Name>: internal NodeWithComm field <-> external layout without ghost layers and with padding."""
     from exastencils_amd.external import ExternalField
