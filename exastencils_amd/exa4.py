@@ -58,7 +58,7 @@ from .domain import RectDomain
 from .field import Field, Stencil
 from .layout import FieldLayout
 from .exa4_parser import (Exa4SyntaxError, Exa4Unsupported, FunctionDecl, Parser, _COORD, _GRIDW, _MATH, _arith,  # noqa: F401
-                          _colour_cond, _conjuncts, _const_value, _contains, _find_calls, _has_coord, _lower_cond, _parity_expr)
+                          _colour_cond, _conjuncts, _const_value, _contains, _find_calls, _has_coord, _lower_cond, _parity_expr, _walk)
 
 APPLY, RESIDUAL, SMOOTH = 0, 1, 2
 
@@ -454,10 +454,19 @@ class Exa4Program:
         f, slot = self._field(args[pos[0]], fr)
         fname = str(self._eval(args[0], fr)).replace("$blockId", str(self.domain.rank))
         rest = [self._eval(a, fr) for a in args[pos[0] + 1:]]
-        include_ghost = bool(rest[0]) if len(rest) > 0 else False
-        binary = bool(rest[1]) if len(rest) > 1 else (base != "printField" and iface != "lock")
-        condition = rest[2] if len(rest) > 2 else True
-        separator = str(rest[3]) if len(rest) > 3 else " "
+        if iface in ("hdf5", "nc", "mpiio", "sion"):
+            # write/readField_hdf5 ( file, dataset, field ), _nc ( file, variable, field [, includeGhost] ), _mpiio ( file, field ),
+            # _sion ( file, field [, includeGhost [, condition]] ) (IOTest:115-168).  Those libraries are not part of this image: the
+            # values go to `file` as the raw doubles of the lock / fpp interfaces -- the same round trip, not those file formats
+            if base == "printField":
+                raise Exa4Unsupported("%s: visualisation output of the %s interface" % (name, iface))
+            include_ghost = bool(rest[0]) if rest and iface in ("nc", "sion") else False
+            binary, condition, separator = True, (rest[1] if len(rest) > 1 and iface == "sion" else True), " "
+        else:
+            include_ghost = bool(rest[0]) if len(rest) > 0 else False
+            binary = bool(rest[1]) if len(rest) > 1 else (base != "printField" and iface != "lock")
+            condition = rest[2] if len(rest) > 2 else True
+            separator = str(rest[3]) if len(rest) > 3 else " "
         if not isinstance(condition, bool):
             raise Exa4Unsupported("%s: only constant conditions" % name)
         d = os.path.dirname(fname)
@@ -546,6 +555,8 @@ class Exa4Program:
                 self._emit("Mean mean total time for Timer %s: %g" % (key, val * 1e3))
         elif name == "getTotalTime" or name == "getTotalFromTimer":
             return self.timers.get(args[0], 0.0) * 1e3
+        elif name == "exit":
+            raise SystemExit(int(args[0]) if args else 0)
         elif name in ("initGlobals", "initDomain", "initGeometry", "destroyGlobals", "initFieldsWithZero"):
             pass        # fields are allocated zeroed at declaration (initFieldsWithZero)
         elif name in ("benchmarkStart", "benchmarkStop"):
@@ -1133,21 +1144,32 @@ class Exa4Program:
                 else:
                     raise Exa4Unsupported("loop condition other than a colour test or (i_d > 0)")
         if only is not None:
-            region, direction = only
-            if region != "dup":
+            # `only <region> [dir] [on boundary]` (baseExt/ir/IR_LoopOverPointsInOneFragment.scala:57-72, 293-299): per dimension the
+            # region's whole extent <R>LB..<R>RE where dir is 0, its lower part <R>LB..<R>LE / upper part <R>RB..<R>RE where dir is
+            # -1 / +1, no iteration offsets; `on boundary`: only where the block has no neighbour in that direction
+            region, direction, on_boundary = only
+            code = {"dup": "D", "ghost": "G", "inner": "I"}.get(region)
+            if code is None:
                 raise Exa4Unsupported("loop ... only %s" % region)
-            nz = [d for d in range(len(direction)) if direction[d] != 0]
-            if len(nz) != 1:
-                raise Exa4Unsupported("loop only dup: axis directions only")
-            d, side = nz[0], direction[nz[0]]
-            if dom.neighbor(d, side) is not None:
-                return [], colour
+            direction = tuple(direction) + (0,) * (3 - len(direction))
+            if on_boundary:
+                nz = [d for d in range(nd) if direction[d] != 0]
+                if len(nz) != 1:
+                    raise Exa4Unsupported("loop only ... on boundary: axis directions only")
+                if dom.neighbor(nz[0], direction[nz[0]]) is not None:
+                    return [], colour
             b, e = [0, 0, 0], [1, 1, 1]
             for t in range(nd):
-                if t == d:
-                    b[t], e[t] = (lay.idx("DLB", t), lay.idx("DLE", t)) if side < 0 else (lay.idx("DRB", t), lay.idx("DRE", t))
+                if code == "I":
+                    lo_b, lo_e, hi_b, hi_e = "IB", "IE", "IB", "IE"
                 else:
-                    b[t], e[t] = lay.idx("DLB", t), lay.idx("DRE", t)
+                    lo_b, lo_e, hi_b, hi_e = code + "LB", code + "LE", code + "RB", code + "RE"
+                if direction[t] == 0:
+                    b[t], e[t] = lay.idx(lo_b, t), lay.idx(hi_e, t)
+                elif direction[t] < 0:
+                    b[t], e[t] = lay.idx(lo_b, t), lay.idx(lo_e, t)
+                else:
+                    b[t], e[t] = lay.idx(hi_b, t), lay.idx(hi_e, t)
             return [(b, e)], colour
         b, e = dom.loop_bounds(lay, reduction is not None)
         for d in range(nd):
@@ -1182,6 +1204,9 @@ class Exa4Program:
         if (len(body) == 1 and body[0][0] == "assign" and body[0][1] == "=" and body[0][2][0] == "fld" and colour is None
                 and self._is_std_rand(body[0][3])):
             return self._exec_rand_fill(body[0][2], boxes, fr)
+        cmp_ = self._match_compare_loop(body, fr)
+        if cmp_ is not None and colour is None:
+            return self._exec_compare_loop(cmp_, boxes, fr)
         for st in body:
             if st[0] != "assign":
                 raise Exa4Unsupported("statement %r inside a loop body" % st[0])
@@ -1212,6 +1237,91 @@ class Exa4Program:
         self._rand_drawn = True
         random_start(self.ops, f, slot, self.domain, self._merged_blocks[0] if self._merged_blocks is not None else None)
         self.launches += 1
+
+    # `loop over B sequentially { Var d : Real = fabs ( B - A ); if ( d > tol ) { print ( ... ) ... return v } }`
+    # (Testing/IOTest/3D_Scalar_CheckEquality_ReadAfterWrite.exa4:25-33): a search for the first point where two fields differ by
+    # more than a tolerance.  One difference loop and one max-reduction on the device decide whether such a point exists; only then
+    # are the fields brought to the host to find the first one in loop order for the program's messages and its `return`.
+    def _match_compare_loop(self, body, fr: _Frame):
+        if len(body) != 2 or body[0][0] != "decl" or body[1][0] != "if" or body[1][3]:
+            return None
+        name, init = body[0][1], body[0][2]
+        if init is None or init[0] != "call" or init[1] not in ("fabs", "abs") or len(init[3]) != 1:
+            return None
+        d = init[3][0]
+        if d[0] != "bin" or d[1] != "-" or d[2][0] != "fld" or d[3][0] != "fld":
+            return None
+        cond, guards = None, []      # `diff > tol`, possibly and-ed with conditions that do not depend on the point
+        for c in _conjuncts(body[1][1]):
+            if c[0] == "bin" and c[1] in (">", ">=") and c[2] == ("id", name, None) and self._is_scalar(c[3]) and cond is None:
+                cond = c
+            elif self._is_scalar(c) and ("id", name, None) not in list(_walk(c)) and not any(
+                    x[0] == "id" and x[1] in ("i0", "i1", "i2") for x in _walk(c)):
+                guards.append(c)
+            else:
+                return None
+        if cond is None:
+            return None
+        if not all(bool(self._eval(gd, fr)) for gd in guards):
+            return ("skip",)
+        then = body[1][2]
+        if not then or then[-1][0] != "return" or any(st[0] not in ("callstmt", "return") for st in then):
+            return None
+        return d[2], d[3], cond[1], cond[3], then
+
+    def _exec_compare_loop(self, m, boxes, fr: _Frame):
+        import numpy as np
+
+        if m == ("skip",):
+            return
+        ea, eb, op, tol_e, then = m
+        A, sa = self._field(ea, fr)
+        B, sb = self._field(eb, fr)
+        tol = float(self._eval(tol_e, fr))
+        if not hasattr(self, "_cmp_tmp") or self._cmp_tmp.numel() < A.layout.size:
+            self._cmp_tmp = self.ops.new_array(A.layout.size)
+        worst = 0.0
+        for b, e in boxes:
+            self.ops.axpby(A.lc, A.data(sa), A.lc, self._cmp_tmp, 1.0, 0.0, b, e)            # tmp = A
+            self.ops.axpby(B.lc, B.data(sb), A.lc, self._cmp_tmp, -1.0, 1.0, b, e)           # tmp -= B
+            t = self.ops.max_err_fn(A.lc, self._cmp_tmp, self.domain.geom(A.level), 0, (), b, e)
+            self.launches += 3
+            worst = max(worst, self.ops.scalar_value(self.comm.allreduce(t, "max")))
+        if not (worst > tol if op == ">" else worst >= tol):
+            return
+        # a point beyond the tolerance exists: the first one in loop order (x fastest) on this block, for the program's messages
+        ha = self.ops.to_host(A.data(sa)).reshape(A.layout.shape_zyx)
+        hb = self.ops.to_host(B.data(sb)).reshape(B.layout.shape_zyx)
+        for b, e in boxes:
+            sl = tuple(slice(A.layout.ref(d) + b[d], A.layout.ref(d) + e[d]) for d in (2, 1, 0))
+            bad = np.argwhere(np.abs(ha[sl] - hb[sl]) > tol if op == ">" else np.abs(ha[sl] - hb[sl]) >= tol)
+            if len(bad):
+                k2, k1, k0 = (int(v) for v in bad[0])
+                vals = {"i0": b[0] + k0, "i1": b[1] + k1, "i2": b[2] + k2}
+                self._cmp_point = (vals, float(ha[sl][k2, k1, k0]), float(hb[sl][k2, k1, k0]))
+                break
+        self._exec_block_at_point(then, fr, A, sa, B, sb)
+
+    def _exec_block_at_point(self, stmts, fr: _Frame, A, sa, B, sb):
+        """The statements of the compare loop's `if` at the offending point: prints see the fields' values and i0 / i1 / i2 there."""
+        vals, va, vb = getattr(self, "_cmp_point", ({"i0": -1, "i1": -1, "i2": -1}, float("nan"), float("nan")))
+        for st in stmts:
+            if st[0] == "return":
+                raise _Return(self._eval(st[1], fr) if st[1] is not None else None)
+            c = st[1]
+            if c[1] != "print":
+                self._exec(st, fr)
+                continue
+            out = []
+            for a in c[3]:
+                if a[0] == "fld":
+                    f, _ = self._field(a, fr)
+                    out.append(va if f is A else vb)
+                elif a[0] == "id" and a[1] in vals:
+                    out.append(vals[a[1]])
+                else:
+                    out.append(self._eval(a, fr))
+            self._emit(" ".join(self._fmt(x) for x in out))
 
     # pattern helpers ---------------------------------------------------------------------------------------------------
     def _is_scalar(self, e) -> bool:

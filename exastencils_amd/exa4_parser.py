@@ -561,9 +561,11 @@ class Parser:
         if self.accept("only"):
             region = self.ident()
             direction = tuple(int(_const_value(e)) for e in self._const_list())
-            self.expect("on")
-            self.expect("boundary")
-            only = (region, direction)
+            on_boundary = False
+            if self.accept("on"):
+                self.expect("boundary")
+                on_boundary = True
+            only = (region, direction, on_boundary)
         # `sequentially` (baseExt/l4/L4_LoopOverField.scala: no OpenMP/SIMD for this loop) concerns the reference's CPU code
         # generation only; the statements of a `loop over` are independent per point either way
         self.accept("sequentially")

@@ -424,6 +424,72 @@ def test_native_rand_fill_is_glibc_rand():
     assert abs(P.printed_values[0] - float((v ** 2).sum()) ** 0.5) < 1e-12
 
 
+COMPARE = """
+Domain global< [0.0, 0.0, 0.0] to [1.0, 1.0, 1.0] >
+Layout Halo< Real, Node >@all {
+  duplicateLayers = [1, 1, 1] with communication
+  ghostLayers     = [1, 1, 1] with communication
+}
+Field a< global, Halo, None >@all
+Field b< global, Halo, None >@all
+Function differ@finest ( ) : Int {
+  loop over b sequentially {
+    Var diff : Real = fabs ( b - a )
+    if ( diff > 0.001 ) {
+      print ( "fields differ: a =", a, " b =", b )
+      print ( "at", i0, i1, i2 )
+      return -1
+    }
+  }
+  return 0
+}
+Function Application {
+  loop over a@finest only dup [0, 0, 0] {
+    a@finest = vf_nodePos_x + 2.0 * vf_nodePos_y + 4.0 * vf_nodePos_z
+  }
+  loop over b@finest only dup [0, 0, 0] {
+    b@finest = vf_nodePos_x + 2.0 * vf_nodePos_y + 4.0 * vf_nodePos_z
+  }
+  print ( differ@finest ( ) )
+  loop over b@finest only inner [0, 0, 0] {
+    b@finest = vf_nodePos_x + 2.0 * vf_nodePos_y + 4.0 * vf_nodePos_z + 0.5
+  }
+  print ( differ@finest ( ) )
+}
+"""
+
+
+def test_compare_loop_and_region_loop():
+    """`loop over f only dup [0, 0, 0]` (the whole duplicate-to-duplicate extent, boundary points included: region bounds of
+    IR_LoopOverPointsInOneFragment.scala:57-72) and the sequential compare loop of the reference's IOTest programs (`Var diff =
+    fabs(b - a); if (diff > tol) { print(...); return -1 }`): silent while the fields agree, the first offending point in loop
+    order otherwise."""
+    P = exa4.Exa4Program(COMPARE, dict(dimensionality=3, minLevel=3, maxLevel=3), ops=OracleOps())
+    out = P.run()
+    assert out[0] == "0" and out[-1] == "-1", out
+    assert out[1].startswith("fields differ: a = ") and out[2] == "at 1 1 1", out      # the first inner point in x-fastest order
+    a = P.fields[("a", 3)]
+    v = OracleOps().to_host(a.data()).reshape(a.layout.shape_zyx)
+    assert v[1, 1, 1] == 0.0 and abs(v[9, 9, 9] - 7.0) < 1e-14 and v[0].max() == 0.0     # duplicates written, ghost layer not
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("name", ["3D_Scalar", "2D_Scalar", "2D_LayoutTrafo"])
+def test_reference_io_programs_pass_their_round_trips(name, tmp_path, monkeypatch):
+    """Testing/IOTest/<name>_CheckEquality_ReadAfterWrite.{exa4,knowledge}, as they are: write, read back and compare through the
+    lock (ascii), fpp (binary, one file per block), hdf5, MPI-I/O, netCDF and SIONlib interfaces -- the last four carried by raw
+    binary files here (those libraries are not in this image: the round trip is the reference's, the file formats are not)."""
+    monkeypatch.chdir(tmp_path)
+    base = os.path.join(REF, "Testing", "IOTest", name + "_CheckEquality_ReadAfterWrite")
+    k = knowledge.parse_file(base + ".knowledge")
+    k["testing_enabled"] = True
+    with open(base + ".exa4") as f:
+        P = exa4.Exa4Program(f.read(), k, ops=OracleOps())
+    out = [l for l in P.run() if l.startswith("Passed")]
+    assert out == ["Passed lock test", "Passed fpp test", "Passed hdf5 test", "Passed MPI I/O test", "Passed nc test", "Passed sion test"]
+    assert os.path.getsize(tmp_path / "data" / "src_lock.txt") > 1000
+
+
 # -- two blocks over gloo ------------------------------------------------------------------------------------------------
 def _worker(rank, world, port, out_dir):
     import json
