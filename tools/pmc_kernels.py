@@ -56,6 +56,16 @@ def cases(ops, level, with27=True, align=0):
         ("residual_norm", lambda: ops.residual_norm2(L, u, F, f, A, b, e, out=out), "k_stencil7_zmarch<3", 16 * pts, pts),
         ("dot_norm", lambda: ops.dot(L, r, L, r, b, e, out), "k_dot_rows", 8 * pts, pts),
     ]
+    if align == 0 and level >= 8:
+        # the one-step kernel on the padded layout the reference produces with data_alignFieldPointers (rows of 544 doubles at
+        # 512^3, field/ir/IR_AddPaddingToFieldLayouts.scala:36-41): every 16-byte access aligned, no partial lines at window edges
+        lup, lfp = FieldLayout.node(3, nc, 1, True, True, 16), FieldLayout.node(3, nc, 0, True, False, 16)
+        up, unp, fp = ops.new_array(lup.size), ops.new_array(lup.size), ops.new_array(lfp.size)
+        ops.fill_random(up, 201)
+        ops.fill_random(fp, 202)
+        Lp, Fp = lup.c_struct(), lfp.c_struct()
+        cs.insert(1, ("jacobi_1step_padded_rows", lambda: ops.stencil_op(2, Lp, up, Fp, fp, Lp, unp, A, w, -1, b, e), "k_stencil7_zmarch<2",
+                      24 * pts, pts))
     if with27:
         nocomm = FieldLayout.node(3, nc, 0, False, False, align)
         cf = ops.new_array(27 * nocomm.size)
