@@ -1,6 +1,7 @@
 """Start values of `loop over F sequentially { F = native ( "((double)std::rand()/RAND_MAX)" ) }` (Testing/Opts/base.exa4:166-170,
-Testing/Misc/inlining.exa4:199-203): the values come from libexamg's restatement of glibc's rand() (include/examg.h:
-examg_crand_seed / examg_crand_fill_host, host code), are written on the host in the loop order of the generated nest and uploaded.
+Testing/Misc/inlining.exa4:199-203, Testing/PolyExpl/Jac3Dcc.exa4:32-41): the values come from libexamg's restatement of glibc's rand()
+(include/examg.h: examg_crand_seed / examg_crand_draw_host, host code), are placed on the host in the loop order of the generated
+nest -- x fastest, the statements of the loop body drawing one after the other at every point -- and uploaded.
 
 Which generator a point's value comes from follows the reference's processes: the generated main() of an MPI program calls
 std::srand(mpiRank) (Compiler/src/exastencils/parallelization/api/mpi/MPI_IVs.scala:41-45; srand(0) seeds like the default, 1),
@@ -11,7 +12,7 @@ the value of the LOWER one (`communicate`: own upper duplicate plane -> the uppe
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -19,25 +20,58 @@ from .domain import RectDomain
 from .layout import FieldLayout
 
 
-def random_start(ops, field, slot: Optional[int], domain: RectDomain, former_processes: Optional[Sequence[int]] = None):
-    from . import lib as _lib
+class CRand:
+    """One C-library generator (glibc's rand(), restated in libexamg): seed like std::srand, draw like (double)std::rand()/RAND_MAX."""
 
-    L = _lib.load()
+    def __init__(self, seed: int = 1):
+        from . import lib as _lib
+
+        self._lib, self._L = _lib, _lib.load()
+        self._st = _lib.CrandStateC()
+        self.seed(seed)
+
+    def seed(self, seed: int):
+        self._lib.check(self._L.examg_crand_seed(C.byref(self._st), int(seed) & 0xFFFFFFFF), "examg_crand_seed")
+
+    def draw(self, n: int) -> np.ndarray:
+        out = np.empty(int(n), dtype=np.float64)
+        self._lib.check(self._L.examg_crand_draw_host(C.byref(self._st), out.ctypes.data_as(C.c_void_p), int(n)), "examg_crand_draw_host")
+        return out
+
+
+def fill_boxes(ops, targets: Sequence[Tuple[object, Optional[int]]], fills: List[Tuple[CRand, Sequence[int], Sequence[int]]]):
+    """targets: (field, slot) per statement of the loop body, in statement order (same layout); fills: (generator, begin, end)
+    boxes in the order they are to be written.  Every point draws len(targets) values in a row."""
+    lay = targets[0][0].layout
+    hosts = [np.ascontiguousarray(ops.to_host(f.data(s)), dtype=np.float64).copy().reshape(lay.shape_zyx) for f, s in targets]
+    k = len(targets)
+    for gen, b, e in fills:
+        n = [max(0, e[d] - b[d]) for d in range(3)]
+        if n[0] * n[1] * n[2] == 0:
+            continue
+        vals = gen.draw(n[0] * n[1] * n[2] * k).reshape(n[2], n[1], n[0], k)
+        sl = tuple(slice(lay.ref(d) + b[d], lay.ref(d) + e[d]) for d in (2, 1, 0))
+        for j in range(k):
+            hosts[j][sl] = vals[..., j]
+    for (f, s), h in zip(targets, hosts):
+        f.data(s).copy_(ops.from_host(h.reshape(-1)))
+
+
+def random_start(ops, field, slot: Optional[int], domain: RectDomain, former_processes: Optional[Sequence[int]] = None,
+                 generator: Optional[CRand] = None, more_targets: Sequence[Tuple[object, Optional[int]]] = ()):
+    """`field<slot>` (and `more_targets`, the further statements of the same loop body) over the loop's box.  `generator`: the
+    process' generator when the program seeded it itself (std::srand) or drew from it before; None: the reference's default per
+    process (seed = rank, 1 without MPI)."""
     lay, nd = field.layout, domain.nd
-    host = np.ascontiguousarray(ops.to_host(field.data(slot)), dtype=np.float64).copy()
-    lc = lay.c_struct()
-
-    def fill(seed, b, e):
-        st = _lib.CrandStateC()
-        _lib.check(L.examg_crand_seed(C.byref(st), int(seed)), "examg_crand_seed")
-        _lib.check(L.examg_crand_fill_host(C.byref(lc), host.ctypes.data_as(C.c_void_p), _lib.ivec(b), _lib.ivec(e), C.byref(st)),
-                   "examg_crand_fill_host")
-
+    targets = [(field, slot)] + list(more_targets)
     procs = tuple(former_processes) if former_processes is not None else (1, 1, 1)
+    fills = []
     if domain.world_size > 1:
         b, e = domain.loop_bounds(lay)
-        fill(domain.rank, b, e)
+        fills.append((generator or CRand(domain.rank), b, e))
     elif procs != (1, 1, 1):
+        if generator is not None or len(targets) != 1:
+            raise NotImplementedError("merged blocks: one statement per loop and the default seeding only")
         flen = tuple(domain.frag_len[d] // procs[d] for d in range(3))
         if any(flen[d] * procs[d] != domain.frag_len[d] for d in range(3)):
             raise ValueError("the merged fragment is not a whole number of former blocks")
@@ -47,8 +81,8 @@ def random_start(ops, field, slot: Optional[int], domain: RectDomain, former_pro
             sb, se = sub.loop_bounds(FieldLayout.node(nd, nc, lay.ghost[0]))
             b = [sub.pos[d] * nc[d] + sb[d] if d < nd else 0 for d in range(3)]
             e = [sub.pos[d] * nc[d] + se[d] if d < nd else 1 for d in range(3)]
-            fill(r, b, e)
+            fills.append((CRand(r), b, e))
     else:
         b, e = domain.loop_bounds(lay)
-        fill(1, b, e)
-    field.data(slot).copy_(ops.from_host(host))
+        fills.append((generator or CRand(1), b, e))
+    fill_boxes(ops, targets, fills)

@@ -5,7 +5,8 @@
 // produced with glibc, whose rand() is the TYPE_3 additive feedback generator: 31 words seeded by the Lehmer sequence
 // 16807 * x mod (2^31 - 1), r[i] = r[i-3] + r[i-31] (mod 2^32), the first 310 values discarded, result = r >> 1, RAND_MAX = 2^31 - 1.
 // Restated here so that the values do not depend on the C library the host program happens to run with.  Host code: the values
-// are written to a host array in the loop order of the generated nest (x fastest); the caller uploads them.
+// are written to a host buffer in the order they are drawn -- the loop order of the generated nest, x fastest --; the caller places
+// and uploads them.
 #include <stdint.h>
 
 #include "examg_common.h"
@@ -37,17 +38,8 @@ static inline uint32_t crand_next(examg_crand_state_t *st) {
   return v >> 1;
 }
 
-extern "C" int examg_crand_fill_host(const examg_layout_t *l, double *host_x, const int32_t *begin, const int32_t *end,
-                                     examg_crand_state_t *st) {
-  if (!l || !host_x || !begin || !end || !st) { examg::set_error("examg_crand_fill_host: null argument"); return 1; }
-  const examg::Box box = examg::make_box(begin, end);
-  if (box.count() == 0) return 0;
-  if (!examg::box_inside(l, box, 0)) { examg::set_error("examg_crand_fill_host: box leaves the allocation"); return 1; }
-  const examg::LayoutDev ld = examg::make_layout(l);
-  for (int i2 = box.b2; i2 < box.e2; ++i2)
-    for (int i1 = box.b1; i1 < box.e1; ++i1) {
-      double *row = host_x + examg::lidx(ld, 0, i1, i2);
-      for (int i0 = box.b0; i0 < box.e0; ++i0) row[i0] = (double)crand_next(st) / 2147483647.0;
-    }
+extern "C" int examg_crand_draw_host(examg_crand_state_t *st, double *host_out, int64_t n) {
+  if (!st || (!host_out && n > 0) || n < 0) { examg::set_error("examg_crand_draw_host: null argument or negative count"); return 1; }
+  for (int64_t i = 0; i < n; ++i) host_out[i] = (double)crand_next(st) / 2147483647.0;
   return 0;
 }

@@ -246,8 +246,13 @@ class Exa4Program:
                     raise Exa4Unsupported("layout %s: node fields need one duplicate layer" % ld.name)
                 inner = tuple(nc[i] - 1 if i < nd else 1 for i in range(3))
                 if ld.inner and tuple(ld.inner[:nd]) != inner[:nd]:
-                    raise Exa4Unsupported("layout %s: innerPoints %s differ from the %s points level %d gives one fragment"
-                                          % (ld.name, list(ld.inner[:nd]), list(inner[:nd]), lvl))
+                    # an explicit size (fieldlike/l4/L4_FieldLikeLayoutDecl.scala:49-51: innerPoints replaces the default 2^level * fragLen
+                    # - 1): the benchmark programs of Testing/PolyExpl put a 256^3 array on level 0.  Loops follow the layout; grid
+                    # widths and node positions stay those of the level, as in the reference.  Only without inter-grid transfers
+                    if self.min_level != self.max_level or dom.world_size != 1:
+                        raise Exa4Unsupported("layout %s: innerPoints %s differ from the %s points level %d gives one fragment"
+                                              % (ld.name, list(ld.inner[:nd]), list(inner[:nd]), lvl))
+                    inner = tuple(int(ld.inner[i]) if i < nd else 1 for i in range(3))
                 lay = FieldLayout(nd, inner, ghost, dup, (0, 0, 0), (0, 0, 0), ld.dup_comm, ld.ghost_comm)
                 bc_fn, bc_par = None, ()
                 if fd.bc is not None:
@@ -428,6 +433,10 @@ class Exa4Program:
             return _MATH[name](*[self._eval(a, fr) for a in args])
         if name.split("_")[0] in ("printField", "writeField", "readField") and name not in self.functions:
             return self._field_io(name, args, fr)
+        if name in ("startTimer", "stopTimer", "getTotalFromTimer", "getTotalTime", "getMeanFromTimer") and args and \
+                args[0][0] == "id" and args[0][1] not in fr.vars and args[0][1] not in self.globals:
+            # timers may be named by a bare identifier (Testing/PolyExpl/Jac3Dcc.exa4:49: startTimer(benchTimer))
+            args = [("str", args[0][1])] + list(args[1:])
         if name == "getKnowledge":
             key = self._eval(args[0], fr)
             return self.k.get(key, {"testing_enabled": False, "testing_printRes": True, "testing_printErr": True}.get(key, False))
@@ -535,6 +544,14 @@ class Exa4Program:
         elif name == "printWithReducedPrec":
             self.printed_values.append(float(args[0]))
             self._emit(reduced_prec(float(args[0])))
+        elif name == "native" and re.fullmatch(r"\s*std::srand\s*\(\s*(\d+)\s*\)\s*;?\s*", str(args[0])):
+            from .crand import CRand
+
+            seed = int(re.search(r"\d+", str(args[0])).group(0))      # native('std::srand(42)') (Testing/PolyExpl/Jac3Dcc.exa4:33)
+            if getattr(self, "_crand", None) is None:
+                self._crand = CRand(seed)
+            else:
+                self._crand.seed(seed)
         elif name == "native":
             m = re.search(r"cout\.precision\((\w+)\)", str(args[0]))
             if m and "oldPrec =" not in str(args[0]):
@@ -1201,12 +1218,14 @@ class Exa4Program:
             return self._exec_reduction(f, boxes, reduction, body, fr)
         if body and all(st[0] == "assign" and st[2][0] == "sentry" for st in body):
             return self._exec_stencil_field_init(body, boxes, fr)
-        if (len(body) == 1 and body[0][0] == "assign" and body[0][1] == "=" and body[0][2][0] == "fld" and colour is None
-                and self._is_std_rand(body[0][3])):
-            return self._exec_rand_fill(body[0][2], boxes, fr)
+        if (body and colour is None and all(st[0] == "assign" and st[1] == "=" and st[2][0] == "fld" and self._is_std_rand(st[3])
+                                            for st in body)):
+            return self._exec_rand_fill([st[2] for st in body], boxes, fr)
         cmp_ = self._match_compare_loop(body, fr)
         if cmp_ is not None and colour is None:
             return self._exec_compare_loop(cmp_, boxes, fr)
+        if colour is None and self._is_check_loop(body):
+            return self._exec_check_loop(body, boxes, fr)
         for st in body:
             if st[0] != "assign":
                 raise Exa4Unsupported("statement %r inside a loop body" % st[0])
@@ -1225,17 +1244,25 @@ class Exa4Program:
         return (e[0] == "call" and e[1] == "native" and len(e[3]) == 1 and e[3][0][0] == "str"
                 and e[3][0][1].replace(" ", "") == "((double)std::rand()/RAND_MAX)")
 
-    def _exec_rand_fill(self, target, boxes, fr: _Frame):
-        from .crand import random_start
+    def _exec_rand_fill(self, targets, boxes, fr: _Frame):
+        """One loop whose statements all draw from std::rand(): every point draws once per statement, in statement order."""
+        from .crand import CRand, random_start
 
-        f, slot = self._field(target, fr)
+        fs = [self._field(t, fr) for t in targets]
+        f, slot = fs[0]
         b, e = self.domain.loop_bounds(f.layout)
         if len(boxes) != 1 or list(boxes[0][0]) != list(b) or list(boxes[0][1]) != list(e):
             raise Exa4Unsupported("std::rand() start values on a restricted iteration space")
-        if getattr(self, "_rand_drawn", False):
-            raise Exa4Unsupported("a second loop drawing from std::rand(): the generators' states are not kept between loops")
+        if any(g.layout.shape_zyx != f.layout.shape_zyx for g, _ in fs):
+            raise Exa4Unsupported("std::rand() start values for fields of different layouts in one loop")
+        merged = self._merged_blocks[0] if self._merged_blocks is not None else None
+        gen = getattr(self, "_crand", None)
+        if merged is not None and (gen is not None or getattr(self, "_rand_drawn", False)):
+            raise Exa4Unsupported("merged blocks: one loop drawing from std::rand(), with the default seeding")
+        if merged is None and gen is None:      # this process' generator: seeded by the generated main() (rank; 1 without MPI)
+            gen = self._crand = CRand(self.domain.rank if self.domain.world_size > 1 else 1)
         self._rand_drawn = True
-        random_start(self.ops, f, slot, self.domain, self._merged_blocks[0] if self._merged_blocks is not None else None)
+        random_start(self.ops, f, slot, self.domain, merged, generator=gen, more_targets=fs[1:])
         self.launches += 1
 
     # `loop over B sequentially { Var d : Real = fabs ( B - A ); if ( d > tol ) { print ( ... ) ... return v } }`
@@ -1301,6 +1328,96 @@ class Exa4Program:
                 self._cmp_point = (vals, float(ha[sl][k2, k1, k0]), float(hb[sl][k2, k1, k0]))
                 break
         self._exec_block_at_point(then, fr, A, sa, B, sb)
+
+    # A loop that writes no field -- point-wise `Var`s and `if ( cond ) { print ( ... ) }` -- is a check of the data, not part of the
+    # hot path (Testing/PolyExpl/Jac3Dcc.exa4:58-65: `Var s = Solution<active> * Solution<nextSlot>; if (s == 0.0 || s == 1./0. || ...)
+    # print`): the fields it reads come to the host once, the expressions are evaluated over the whole box with numpy, and the
+    # prints run for the offending points in loop order.
+    @staticmethod
+    def _is_check_loop(body) -> bool:
+        def ok(st):
+            if st[0] == "decl":
+                return True
+            if st[0] == "if":
+                return not st[3] and all(x[0] == "callstmt" and x[1][1] == "print" for x in st[2])
+            return False
+        return bool(body) and all(ok(st) for st in body) and any(st[0] == "if" for st in body)
+
+    def _np_eval(self, e, env, fr: _Frame, box):
+        import numpy as np
+
+        k = e[0]
+        if k == "num":
+            return float(e[1]) if not isinstance(e[1], bool) else e[1]
+        if k == "str":
+            return e[1]
+        if k == "fld":
+            f, slot = self._field(e, fr)
+            key = (f.name, f.level, slot)
+            if key not in env["_fields"]:
+                lay = f.layout
+                sl = tuple(slice(lay.ref(d) + box[0][d], lay.ref(d) + box[1][d]) for d in (2, 1, 0))
+                env["_fields"][key] = self.ops.to_host(f.data(slot)).reshape(lay.shape_zyx)[sl]
+            return env["_fields"][key]
+        if k == "id":
+            if e[1] in env:
+                return env[e[1]]
+            if e[1] in ("i0", "i1", "i2"):
+                d = int(e[1][1])
+                n = [box[1][t] - box[0][t] for t in range(3)]
+                shape = [1, 1, 1]
+                shape[2 - d] = n[d]
+                return (np.arange(box[0][d], box[1][d]).reshape(shape) + np.zeros((n[2], n[1], n[0]), dtype=np.int64))
+            return self._eval(e, fr)
+        if k == "neg":
+            return -self._np_eval(e[1], env, fr, box)
+        if k == "not":
+            return np.logical_not(self._np_eval(e[1], env, fr, box))
+        if k == "bin":
+            a, b = self._np_eval(e[2], env, fr, box), self._np_eval(e[3], env, fr, box)
+            op = e[1]
+            with np.errstate(all="ignore"):
+                if op in ("&&", "and"):
+                    return np.logical_and(a, b)
+                if op in ("||", "or"):
+                    return np.logical_or(a, b)
+                if op == "/":
+                    return np.divide(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
+                table = {"+": np.add, "-": np.subtract, "*": np.multiply, "**": np.power, "%": np.mod, "==": np.equal, "!=": np.not_equal,
+                         "<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal}
+                if op not in table:
+                    raise Exa4Unsupported("operator %s in a check loop" % op)
+                return table[op](a, b)
+        if k == "call" and e[1] in ("fabs", "abs", "sqrt", "exp", "sin", "cos") and len(e[3]) == 1:
+            fn = {"fabs": np.abs, "abs": np.abs, "sqrt": np.sqrt, "exp": np.exp, "sin": np.sin, "cos": np.cos}[e[1]]
+            with np.errstate(all="ignore"):
+                return fn(self._np_eval(e[3][0], env, fr, box))
+        raise Exa4Unsupported("expression %s in a check loop" % (k,))
+
+    def _exec_check_loop(self, body, boxes, fr: _Frame):
+        import numpy as np
+
+        self.ops.synchronize()
+        for box in boxes:
+            n = [box[1][d] - box[0][d] for d in range(3)]
+            if n[0] * n[1] * n[2] == 0:
+                continue
+            env = {"_fields": {}}
+            for st in body:
+                if st[0] == "decl":
+                    env[st[1]] = self._np_eval(st[2], env, fr, box) if st[2] is not None else 0.0
+                    continue
+                mask = np.broadcast_to(np.asarray(self._np_eval(st[1], env, fr, box), dtype=bool), (n[2], n[1], n[0]))
+                for k2, k1, k0 in np.argwhere(mask)[:1000]:      # (a check that fires on every point need not print them all)
+                    pt = {"i0": box[0][0] + int(k0), "i1": box[0][1] + int(k1), "i2": box[0][2] + int(k2)}
+                    for x in st[2]:
+                        out = []
+                        for a in x[1][3]:
+                            v = self._np_eval(a, {**env, **pt}, fr, box) if a[0] != "str" else a[1]
+                            if isinstance(v, np.ndarray):
+                                v = np.broadcast_to(v, (n[2], n[1], n[0]))[k2, k1, k0].item()
+                            out.append(v)
+                        self._emit(" ".join(self._fmt(v) for v in out))
 
     def _exec_block_at_point(self, stmts, fr: _Frame, A, sa, B, sb):
         """The statements of the compare loop's `if` at the offending point: prints see the fields' values and i0 / i1 / i2 there."""

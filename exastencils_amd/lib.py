@@ -74,7 +74,7 @@ SYMBOLS = [
     "examg_cg_coarse", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
     "examg_comm_unique_id", "examg_comm_create", "examg_comm_destroy", "examg_comm_rank", "examg_comm_size",
     "examg_exchange_workspace_bytes", "examg_exchange", "examg_allreduce", "examg_allgather",
-    "examg_jacobi2_blocks", "examg_rbgs_sweep_blocks", "examg_crand_seed", "examg_crand_fill_host",
+    "examg_jacobi2_blocks", "examg_rbgs_sweep_blocks", "examg_crand_seed", "examg_crand_draw_host",
 ]
 
 COMM_ID_BYTES = 128
@@ -155,7 +155,7 @@ def load(path=None):
     L.examg_allreduce.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     nbp = C.POINTER(NeighborsC)
     L.examg_crand_seed.argtypes = [C.POINTER(CrandStateC), C.c_uint32]
-    L.examg_crand_fill_host.argtypes = [lp, vp, ip, ip, C.POINTER(CrandStateC)]
+    L.examg_crand_draw_host.argtypes = [C.POINTER(CrandStateC), vp, C.c_int64]
     L.examg_jacobi2_blocks.argtypes = [vp, nbp, lp, vp, vp, vp, lp, vp, sp, C.c_double, ip, ip, C.c_int, vp, C.c_size_t, C.c_int, vp]
     L.examg_rbgs_sweep_blocks.argtypes = [vp, nbp, lp, vp, vp, vp, lp, vp, sp, C.c_double, C.c_int, ip, ip, C.c_int, vp, C.c_size_t, C.c_int, vp]
     L.examg_allgather.argtypes = [vp, vp, vp, C.c_int64, vp]

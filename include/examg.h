@@ -226,16 +226,16 @@ int examg_residual_norm2(const examg_layout_t *lu, const double *u, const examg_
 /* ---- start values from the C library's generator (host side).  Programs of the reference's test suite initialise their solution
  * with `loop over F sequentially { F = native ( "((double)std::rand()/RAND_MAX)" ) }` (Testing/Opts/base.exa4:166-170), every
  * MPI process after std::srand(mpiRank) (parallelization/api/mpi/MPI_IVs.scala:41-45); their results files come from glibc's rand()
- * (TYPE_3 additive feedback generator).  examg_crand_seed / examg_crand_fill_host restate that generator, so that a host program
- * gets the reference's start values whatever C library it runs with: (double)rand()/RAND_MAX into [begin,end) of a HOST array in
- * the loop order of the generated nest (x fastest).  The caller uploads the array. */
+ * (TYPE_3 additive feedback generator).  examg_crand_seed / examg_crand_draw_host restate that generator, so that a host program
+ * gets the reference's start values whatever C library it runs with: the next n values of (double)rand()/RAND_MAX into a HOST
+ * buffer, in the order the generated loop nest draws them (x fastest; several draws per point interleave).  The caller places and
+ * uploads them. */
 typedef struct {
   uint32_t r[31];
   int32_t k;
 } examg_crand_state_t;
 int examg_crand_seed(examg_crand_state_t *state, uint32_t seed);
-int examg_crand_fill_host(const examg_layout_t *l, double *host_x, const int32_t *begin, const int32_t *end,
-                          examg_crand_state_t *state);
+int examg_crand_draw_host(examg_crand_state_t *state, double *host_out, int64_t n);
 
 /* ---- analytic expressions as stack programs: the ONE mechanism for boundary values, right-hand sides, exact solutions and
  * coefficient profiles (round 1 also had 17 built-in function ids of the reference's test programs; they are gone -- the same

@@ -9,6 +9,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -471,6 +472,31 @@ def test_compare_loop_and_region_loop():
     a = P.fields[("a", 3)]
     v = OracleOps().to_host(a.data()).reshape(a.layout.shape_zyx)
     assert v[1, 1, 1] == 0.0 and abs(v[9, 9, 9] - 7.0) < 1e-14 and v[0].max() == 0.0     # duplicates written, ghost layer not
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("prog,know", [("Jac3Dcc.exa4", "3D_f0.knowledge"), ("Jac3Dcc.exa4", "3D_f5.knowledge"),
+                                       ("Jac2Dccd.exa4", "2D_f0.knowledge"), ("RBGS2Dcc.exa4", "2D_f0.knowledge")])
+def test_reference_contracting_loop_programs(prog, know):
+    """Testing/PolyExpl (`repeat 5 times with contraction [1, 1, 1]` on five ghost layers, Jac3Dcc.exa4:27), as they
+    are: explicit `innerPoints` (a 256^3 array on level 0), `native('std::srand(42)')` and two std::rand() draws per point in one
+    sequential loop, timers named by identifiers, and the program's own check of every value (no zero, infinite or NaN product of the
+    two slots) evaluated on the host.  Expected output: Testing/PolyExpl/all.results (no ERROR line)."""
+    from oracle import mg
+
+    if prog.startswith(("Jac2D", "RBGS2D")) and not os.environ.get("EXAMG_SLOW"):
+        pytest.skip("2-D programs of 20 s each on the CPU: set EXAMG_SLOW=1")
+    base = os.path.join(REF, "Testing", "PolyExpl")
+    k = knowledge.parse_file(os.path.join(base, know))
+    k["testing_enabled"] = True
+    with open(os.path.join(base, prog)) as f:
+        P = exa4.Exa4Program(f.read(), k, ops=OracleOps())
+    out = P.run()
+    with open(os.path.join(base, "all.results")) as f:
+        assert mg.compare_with_golden(out, f.read()) == []
+    S = P.fields[("Solution", 0)]
+    v = OracleOps().to_host(S.data(S.active))
+    assert np.isfinite(v).all() and 0.0 < float(np.abs(v).max()) < 10.0
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")

@@ -755,8 +755,10 @@ def test_bad_arguments_of_the_one_pass_forms_fail_loudly(hip):
     assert L.examg_crand_seed(None, 1) != 0 and b"null" in L.examg_last_error()
     st_ = lib.CrandStateC()
     assert L.examg_crand_seed(C.byref(st_), 1) == 0
-    lcs = lu.c_struct()
-    assert L.examg_crand_fill_host(C.byref(lcs), None, lib.ivec(b), lib.ivec(e), C.byref(st_)) != 0
+    assert L.examg_crand_draw_host(C.byref(st_), None, 4) != 0
+    buf = (C.c_double * 3)()
+    assert L.examg_crand_draw_host(C.byref(st_), buf, 3) == 0
+    assert [int(round(v * 2147483647.0)) for v in buf] == [1804289383, 846930886, 1681692777]
 
 
 def test_external_field_copy(hip):
