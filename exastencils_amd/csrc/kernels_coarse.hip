@@ -79,8 +79,9 @@ __device__ __forceinline__ void cg_zero_faces(const FaceBoxesCG &fb, const Layou
 __global__ void __launch_bounds__(CG_THREADS)
 k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDev lr, double *res, LayoutDev lp, double *p,
             LayoutDev lq, double *ap, LayoutDev lc, StencilCG st, FaceBoxesCG fbr, FaceBoxesCG fbp, FaceBoxesCG fbs, int max_it,
-            double rel_tol, Box box, double *info) {
+            double rel_tol, Box box, double *info, unsigned flags) {
   __shared__ double sm[CG_THREADS / 64];
+  const bool from_norm = flags & EXAMG_CG_ALPHA_FROM_NORM, bc = !(flags & EXAMG_CG_NO_BC);
   const int total = (int)box.count();
   int i0, i1, i2;
 
@@ -92,7 +93,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
     res[lidx(lr, i0, i1, i2)] = r;
     s = s + r * r;
   }
-  cg_zero_faces(fbr, lr, res);
+  if (bc) cg_zero_faces(fbr, lr, res);
   double curRes = sqrt(cg_block_sum(s, sm));
   const double initRes = curRes;
   // cgTmp0 = Residual ; apply bc to cgTmp0
@@ -100,7 +101,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
     cg_unflatten(box, t, i0, i1, i2);
     p[lidx(lp, i0, i1, i2)] = res[lidx(lr, i0, i1, i2)];
   }
-  cg_zero_faces(fbp, lp, p);
+  if (bc) cg_zero_faces(fbp, lp, p);
   __syncthreads();
 
   int it = 0;
@@ -116,7 +117,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
       sn = sn + r * r;
       sd = sd + p[lidx(lp, i0, i1, i2)] * q;
     }
-    const double alphaNom = cg_block_sum(sn, sm);
+    const double alphaNom = from_norm ? curRes * curRes : cg_block_sum(sn, sm);
     const double alphaDenom = cg_block_sum(sd, sm);
     const double alpha = alphaNom / alphaDenom;
     // Solution += alpha * cgTmp0 ; Residual -= alpha * cgTmp1 ; nextRes = ResNorm()
@@ -142,7 +143,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
     curRes = nextRes;
     __syncthreads();
   }
-  cg_zero_faces(fbs, lu, sol);  // apply bc to Solution (homogeneous on coarse levels)
+  if (bc) cg_zero_faces(fbs, lu, sol);  // apply bc to Solution (homogeneous on coarse levels)
   if (threadIdx.x == 0 && info) {
     info[0] = (double)it;
     info[1] = initRes;
@@ -167,11 +168,22 @@ struct StencilCGL {
 __global__ void __launch_bounds__(CG_THREADS)
 k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDev lr, double *res, LayoutDev lp, double *p,
                 LayoutDev lq, double *ap, StencilCG st, StencilCGL sl, FaceBoxesCG fbr, FaceBoxesCG fbp, FaceBoxesCG fbs, int max_it,
-                double rel_tol, Box box, double *info, int ldx, int ldxy, int ldtot) {
+                double rel_tol, Box box, double *info, int ldx, int ldxy, int ldtot, unsigned flags) {
   extern __shared__ double P[];
   __shared__ double sm[CG_THREADS / 64];
   const int total = (int)box.count();
-  for (int t = threadIdx.x; t < ldtot; t += CG_THREADS) P[t] = 0.0;
+  const bool from_norm = flags & EXAMG_CG_ALPHA_FROM_NORM, bc = !(flags & EXAMG_CG_NO_BC);
+  // halo of the search direction: the boundary planes `apply bc` keeps at zero -- or, for a solver without `apply bc` statements,
+  // whatever those planes hold
+  for (int t = threadIdx.x; t < ldtot; t += CG_THREADS) {
+    double v = 0.0;
+    if (!bc) {
+      const int a = t % ldx, rw = t / ldx, b2 = rw % (ldxy / ldx), c = rw / (ldxy / ldx);
+      v = p[lidx(lp, box.b0 - 1 + a, box.b1 - 1 + b2, box.b2 - 1 + c)];
+    }
+    P[t] = v;
+  }
+  __syncthreads();
   double r[CG_PPT], x[CG_PPT], q[CG_PPT], pv[CG_PPT];
   int li[CG_PPT];
   long long ku[CG_PPT], kr[CG_PPT], kp[CG_PPT], kq[CG_PPT];
@@ -195,8 +207,10 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
       s = s + r[j] * r[j];
     }
   }
-  cg_zero_faces(fbr, lr, res);   // apply bc to Residual / cgTmp0: their boundary planes in memory, as the statements leave them
-  cg_zero_faces(fbp, lp, p);
+  if (bc) {
+    cg_zero_faces(fbr, lr, res);   // apply bc to Residual / cgTmp0: their boundary planes in memory, as the statements leave them
+    cg_zero_faces(fbp, lp, p);
+  }
   double curRes = sqrt(cg_block_sum(s, sm));
   const double initRes = curRes;
 #pragma unroll
@@ -220,7 +234,7 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
         sd = sd + pv[j] * acc;
       }
     }
-    const double alphaNom = cg_block_sum(sn, sm);
+    const double alphaNom = from_norm ? curRes * curRes : cg_block_sum(sn, sm);
     const double alphaDenom = cg_block_sum(sd, sm);
     const double alpha = alphaNom / alphaDenom;
     double s2 = 0.0;
@@ -255,7 +269,7 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
       ap[kq[j]] = q[j];
     }
   }
-  cg_zero_faces(fbs, lu, sol);
+  if (bc) cg_zero_faces(fbs, lu, sol);
   if (threadIdx.x == 0 && info) {
     info[0] = (double)it;
     info[1] = initRes;
@@ -304,11 +318,21 @@ extern "C" int examg_cg_coarse(const examg_layout_t *lu_, double *sol, const exa
                                const examg_layout_t *lq_, double *ap, const examg_stencil_t *st, const examg_geom_t *g,
                                uint32_t face_mask, int max_it, double rel_tol, const int32_t *begin, const int32_t *end,
                                double *info, examg_stream_t stream) {
+  return examg_cg_coarse_variant(lu_, sol, lf_, rhs, lr_, res, lp_, p, lq_, ap, st, g, face_mask, max_it, rel_tol, begin, end, 0u, info,
+                                 stream);
+}
+
+extern "C" int examg_cg_coarse_variant(const examg_layout_t *lu_, double *sol, const examg_layout_t *lf_, const double *rhs,
+                                       const examg_layout_t *lr_, double *res, const examg_layout_t *lp_, double *p,
+                                       const examg_layout_t *lq_, double *ap, const examg_stencil_t *st, const examg_geom_t *g,
+                                       uint32_t face_mask, int max_it, double rel_tol, const int32_t *begin, const int32_t *end,
+                                       uint32_t flags, double *info, examg_stream_t stream) {
   (void)g;
   if (!lu_ || !sol || !lf_ || !rhs || !lr_ || !res || !lp_ || !p || !lq_ || !ap || !st || !begin || !end) {
     set_error("examg_cg_coarse: null argument");
     return 1;
   }
+  if (flags & ~(EXAMG_CG_ALPHA_FROM_NORM | EXAMG_CG_NO_BC)) { set_error("examg_cg_coarse_variant: unknown flag"); return 1; }
   const uint32_t all = (1u << (2 * lu_->nd)) - 1;
   if ((face_mask & all) != all) {
     set_error("examg_cg_coarse: fused coarse solve needs every face on the physical boundary (single fragment)");
@@ -361,13 +385,13 @@ extern "C" int examg_cg_coarse(const examg_layout_t *lu_, double *sol, const exa
     }
     hipLaunchKernelGGL(k_cg_coarse_lds, dim3(1), dim3(CG_THREADS), (size_t)ldtot * 8, s, lu, sol, make_layout(lf_), rhs, make_layout(lr_), res,
                        lp, p, make_layout(lq_), ap, sd, sl, face_boxes(lr_, face_mask), face_boxes(lp_, face_mask),
-                       face_boxes(lu_, face_mask), max_it, rel_tol, box, info, (int)ldx, (int)ldxy, (int)ldtot);
+                       face_boxes(lu_, face_mask), max_it, rel_tol, box, info, (int)ldx, (int)ldxy, (int)ldtot, flags);
     EXAMG_CHECK_LAUNCH("k_cg_coarse_lds");
     return 0;
   }
   hipLaunchKernelGGL(k_cg_coarse, dim3(1), dim3(CG_THREADS), 0, s, lu, sol, make_layout(lf_), rhs, make_layout(lr_), res, lp, p,
                      make_layout(lq_), ap, lc, sd, face_boxes(lr_, face_mask), face_boxes(lp_, face_mask),
-                     face_boxes(lu_, face_mask), max_it, rel_tol, box, info);
+                     face_boxes(lu_, face_mask), max_it, rel_tol, box, info, flags);
   EXAMG_CHECK_LAUNCH("k_cg_coarse");
   return 0;
 }

@@ -71,7 +71,7 @@ SYMBOLS = [
     "examg_rbgs_colour", "examg_residual", "examg_rbgs_sweep_fused", "examg_rbgs_sweep_fused_boxes", "examg_jacobi2", "examg_jacobi2_boxes", "examg_rbgs_sweep_fused_prolong", "examg_jacobi2_prolong", "examg_rbgs_sweep_fused_zero", "examg_two_stage_eligible", "examg_restrict", "examg_residual_restrict", "examg_prolong_add",
     "examg_set", "examg_axpby", "examg_axpby_dev", "examg_reduce_work_bytes", "examg_dot", "examg_residual_norm2",
     "examg_fill_expr", "examg_apply_dirichlet_expr", "examg_max_err_expr", "examg_init_varcoeff7", "examg_init_helmholtz27", "examg_pack", "examg_unpack",
-    "examg_cg_coarse", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
+    "examg_cg_coarse", "examg_cg_coarse_variant", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
     "examg_comm_unique_id", "examg_comm_create", "examg_comm_destroy", "examg_comm_rank", "examg_comm_size",
     "examg_exchange_workspace_bytes", "examg_exchange", "examg_allreduce", "examg_allgather",
     "examg_jacobi2_blocks", "examg_rbgs_sweep_blocks", "examg_crand_seed", "examg_crand_draw_host",
@@ -79,6 +79,7 @@ SYMBOLS = [
 
 COMM_ID_BYTES = 128
 EXCH_DUP, EXCH_GHOST, EXCH_ALL, EXCH_CONCURRENT_AXES = 1, 2, 3, 4
+CG_ALPHA_FROM_NORM, CG_NO_BC = 1, 2
 
 
 class CrandStateC(C.Structure):
@@ -141,6 +142,8 @@ def load(path=None):
     L.examg_pack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_unpack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_cg_coarse.argtypes = [lp, vp, lp, vp, lp, vp, lp, vp, lp, vp, sp, gp, C.c_uint32, C.c_int, C.c_double, ip, ip, vp, vp]
+    L.examg_cg_coarse_variant.argtypes = [lp, vp, lp, vp, lp, vp, lp, vp, lp, vp, sp, gp, C.c_uint32, C.c_int, C.c_double, ip, ip,
+                                          C.c_uint32, vp, vp]
     L.examg_copy_to_external.argtypes = [lp, vp, lp, vp, vp]
     L.examg_copy_from_external.argtypes = [lp, vp, lp, vp, vp]
     L.examg_fill_random.argtypes = [vp, C.c_int64, C.c_uint64, vp]

@@ -205,12 +205,13 @@ class HipOps:
 
     # -- coarse solve ---------------------------------------------------------------------------------
     def cg_coarse(self, lu, sol, lf, rhs, lr, res, lp, p, lq, ap, st: Stencil, geom, face_mask: int, max_it: int,
-                  rel_tol: float, begin, end, info):
+                  rel_tol: float, begin, end, info, flags: int = 0):
+        """flags: CG_ALPHA_FROM_NORM | CG_NO_BC (include/examg.h: the layer-3 generator's form of the solver)."""
         sc = st.c_struct(self.ptr)
-        check(self.L.examg_cg_coarse(C.byref(lu), self.ptr(sol), C.byref(lf), self.ptr(rhs), C.byref(lr), self.ptr(res),
-                                     C.byref(lp), self.ptr(p), C.byref(lq), self.ptr(ap), C.byref(sc), C.byref(geom),
-                                     int(face_mask), int(max_it), float(rel_tol), ivec(begin), ivec(end), self.ptr(info),
-                                     self._stream()), "examg_cg_coarse")
+        check(self.L.examg_cg_coarse_variant(C.byref(lu), self.ptr(sol), C.byref(lf), self.ptr(rhs), C.byref(lr), self.ptr(res),
+                                             C.byref(lp), self.ptr(p), C.byref(lq), self.ptr(ap), C.byref(sc), C.byref(geom),
+                                             int(face_mask), int(max_it), float(rel_tol), ivec(begin), ivec(end), int(flags),
+                                             self.ptr(info), self._stream()), "examg_cg_coarse_variant")
 
     def fill_random(self, x, seed: int):
         check(self.L.examg_fill_random(self.ptr(x), int(x.numel()), int(seed), self._stream()), "examg_fill_random")

@@ -561,7 +561,10 @@ class ConfigL3:
     temporal_blocking: bool = False   # pairs of Jacobi steps in one pass (exastencils_amd/smoothers.py)
     fused_residual_restrict: bool = False   # single block: UpResidual + Restriction as one pass (fine residual not stored)
     fused_rbgs: bool = False          # red-black sweeps as one out-of-place pass (with neighbours: fused interior + shell)
-    fused_prolong_min_points: int = 0 # single block + temporal_blocking: Correction folded into the first pair of post-smoothing steps (ConfigL4)
+    fused_prolong_min_points: int = 0 # single block: Correction folded into the first post-smoothing pass (pair of Jacobi steps with temporal_blocking, red-black sweep with fused_rbgs; ConfigL4)
+    fused_zero_start: bool = False    # single block + fused_rbgs: SetSolution@coarser(0) left to the first pre-smoothing sweep of the coarser level (ConfigL4)
+    fused_residual_norm: bool = False # single block + fused_residual_restrict: UpResidual@finest + NormResidual of the Solve loop in one pass (ConfigL4)
+    fused_coarse: bool = False        # single block: VCycle_0@coarsest as one persistent kernel (examg_cg_coarse_variant)
     ksq: float = 0.0                  # stencil 'helmholtz27': shift k^2 of  -div(a grad u) - k^2 u  (config 4)
     rhs_from_solution: bool = False   # RHS = A * sol_fn (discrete manufactured solution)
     # InitSolution of Testing/Opts/base.exa4:166-170: Solution@finest = (double)std::rand()/RAND_MAX, drawn by every process of the
@@ -605,7 +608,9 @@ class SolverFromL3(_Program):
                 ops.init_varcoeff7(nocomm.c_struct(), cf, dom.geom(l), cfg.coef_fn, prm, b, e)
                 self.Laplace[l] = Stencil(stencil_field_offsets(nd), [], cf, nocomm)
         nc = dom.ncells(lo)
-        self._shell_epoch: Dict[int, int] = {}
+        self._func_dir: Dict[int, bool] = {}       # level -> its boundary planes hold SetFuncDir's values (FMG start), not the field's bc
+        self._rb_alt, self._rb_tmp, self._one_pass = {}, {}, {}
+        self._cg_info = ops.new_array(4)
         self.VecP = Field("VecP", lo, FieldLayout.node(nd, nc, 1, True, True, cfg.align), ops, 1, FN_ZERO)
         self.VecGradP = Field("VecGradP", lo, FieldLayout.node(nd, nc, 0, False, False, cfg.align), ops, 1, None)
 
@@ -626,6 +631,21 @@ class SolverFromL3(_Program):
         R = self.Residual[l]
         return math.sqrt(self._dot_host(R, R, R))
 
+    def _residual_and_norm(self, l: int) -> float:
+        """`UpResidual@finest ( )` followed by `NormResidual_0@finest ( )` (Function Solve)."""
+        cfg, A = self.cfg, self.Laplace[l]
+        if not (cfg.fused_residual_norm and cfg.fused_residual_restrict and self._single_block() and A.cfield is None and
+                l != cfg.min_level and hasattr(self.ops, "residual_norm2")):
+            self.UpResidual(l)
+            return self.NormResidual(l)
+        # nothing reads Residual@finest before the cycle's own residual pass writes it again: the squares are summed where the
+        # residual would be stored (SolverFromL4._residual_and_norm)
+        S, R, F = self.Solution[l], self.Residual[l], self.RHS[l]
+        self.communicate(S, S.active)
+        b, e = self.bounds(R, reduction=True)
+        t = self.ops.residual_norm2(S.lc, S.data(), F.lc, F.data(), A, b, e, R.lc, R.data())
+        return math.sqrt(self.ops.scalar_value(self.comm.allreduce(t, "sum")))
+
     # Function NormError_0@finest : Real
     def NormError(self, l: int) -> float:
         S = self.Solution[l]
@@ -634,57 +654,101 @@ class SolverFromL3(_Program):
         return self.ops.scalar_value(self.comm.allreduce(t, "max"))
 
     # Function Smoother@((coarsest + 1) to finest)
-    def Smoother(self, l: int):
+    def _one_pass_sweep(self, l: int) -> bool:
+        """Does the kernel layer run the red-black sweep of level l as one pass (examg_two_stage_eligible)?"""
+        if l not in self._one_pass:
+            S = self.Solution[l]
+            b, e = self.bounds(S)
+            self._one_pass[l] = self.nd == 3 and (not hasattr(self.ops, "two_stage_eligible") or
+                                                  self.ops.two_stage_eligible(S.lc, self.RHS[l].lc, self.Laplace[l], b, e, b, e))
+        return self._one_pass[l]
+
+    def _sweep_arrays(self, l: int):
+        """Second Solution array of the out-of-place red-black sweeps (+ the scratch field of the shell on blocks with neighbours)."""
+        S = self.Solution[l]
+        if l not in self._rb_alt:
+            self._rb_alt[l] = self.ops.new_array(S.layout.size)
+            if not self._single_block():
+                self._rb_tmp[l] = Field("SolutionSweepTmp", l, S.layout, self.ops, 1, None)
+            self._boundary_planes(l, self._rb_alt[l])
+        return self._rb_alt[l]
+
+    def _boundary_planes(self, l: int, array):
+        """Write the values Solution@l currently carries on the physical faces -- SetFuncDir's while the FMG start works on the
+        level, the field's bc otherwise; both are functions of the position -- into `array` (second array of the sweeps)."""
+        S = self.Solution[l]
+        if self._func_dir.get(l):
+            self._set_func_dir(l, array)
+        elif S.bc_fn is not None and self.domain.face_mask():
+            self.ops.apply_dirichlet(S.lc, array, self.domain.geom(l), S.bc_fn, S.bc_params, self.domain.face_mask())
+
+    def Smoother(self, l: int, correction_from: Optional[Field] = None, zero_input: bool = False):
         S, F, A = self.Solution[l], self.RHS[l], self.Laplace[l]
         b, e = self.bounds(S)
         if self.cfg.smoother == "jacobi":       # Testing/Smoothers/Jac.exa4:125-131
+            assert correction_from is None and not zero_input
             self.communicate(S, S.active, "ghost")
             self.ops.stencil_op(SMOOTH, S.lc, S.data(S.active), F.lc, F.data(), S.lc, S.data(S.next), A, self._w(l), -1, b, e)
             S.advance()
-        elif self.cfg.fused_rbgs and A.cfield is None:
-            # both colour loops in one out-of-place pass; the second array carries the field's boundary planes, refreshed
-            # whenever they were rewritten (SetFuncDir / ResetBC of the FMG start)
+        elif self.cfg.fused_rbgs and A.cfield is None and not (self._single_block() and not self._one_pass_sweep(l)):
+            # both colour loops in one out-of-place pass; the second array carries the field's boundary planes, rewritten
+            # together with them (setup, SetFuncDir / ResetBC of the FMG start).  (Single block, rows too short for the
+            # one-pass kernel: the entry point would copy the field and run the colour loops on the copy -- the loops in place,
+            # below, are the same statements with one launch less.)
+            alt = self._sweep_arrays(l)
+            if self._single_block():
+                # the exchange is empty; the correction loop before the sweep / the zero field the sweep starts from ride along
+                w = self._w(l)
+                if correction_from is not None:
+                    Sc = correction_from
+                    self.ops.rbgs_sweep_fused_prolong(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e, Sc.lc, Sc.data())
+                elif zero_input:
+                    self.ops.rbgs_sweep_fused_zero(S.lc, alt, F.lc, F.data(), A, w, 0, b, e)
+                else:
+                    self.ops.rbgs_sweep_fused(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e)
+                self._rb_alt[l], S.slots[S.active] = S.slots[S.active], alt
+                return
+            assert correction_from is None and not zero_input
             from .smoothers import rbgs_sweep
 
-            if not hasattr(self, "_rb_alt"):
-                self._rb_alt, self._rb_tmp, self._rb_epoch = {}, {}, {}
-            alt = self._rb_alt.get(l)
-            if alt is None:
-                alt = self._rb_alt[l] = self.ops.new_array(S.layout.size)
-                self._rb_tmp[l] = Field("SolutionSweepTmp", l, S.layout, self.ops, 1, None)
-            if self._rb_epoch.get(l) != self._shell_epoch.get(l, 0):
-                lay = S.layout
-                gb = [lay.idx("GLB", d) if d < self.nd else 0 for d in range(3)]
-                ge = [lay.idx("GRE", d) if d < self.nd else 1 for d in range(3)]
-                self.ops.axpby(S.lc, S.data(), S.lc, alt, 1.0, 0.0, gb, ge)
-                self._rb_epoch[l] = self._shell_epoch.get(l, 0)
             self.communicate(S, S.active, "dup")       # the ghost part of `communicate Solution` is inside rbgs_sweep
             self._rb_alt[l] = rbgs_sweep(self.ops, self.comm, self.domain, S, F, A, self._w(l), alt, self._rb_tmp[l], 0)
         else:                                   # Testing/Smoothers/RBGS.exa4:125-133
+            assert correction_from is None and not zero_input
             for colour in (0, 1):
                 self.communicate(S, S.active)
                 self.ops.stencil_op(SMOOTH, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, self._w(l), colour, b, e)
 
     # `repeat n times { Smoother@current ( ) }`
     def _folds_prolongation(self, l: int) -> bool:
-        """Is Correction@l folded into the first pair of post-smoothing Jacobi steps?"""
+        """Is Correction@l folded into the first post-smoothing pass (pair of Jacobi steps / red-black sweep)?"""
         cfg = self.cfg
-        if not (cfg.fused_prolong_min_points > 0 and cfg.temporal_blocking and cfg.smoother == "jacobi" and cfg.n_smooth >= 2
-                and self._single_block() and self.nd == 3 and self.Laplace[l].cfield is None):
+        jac = cfg.temporal_blocking and cfg.smoother == "jacobi" and cfg.n_smooth >= 2
+        rb = cfg.fused_rbgs and cfg.smoother == "rbgs" and cfg.n_smooth >= 1
+        if not (cfg.fused_prolong_min_points > 0 and (jac or rb) and self._single_block() and self.nd == 3 and
+                self.Laplace[l].cfield is None):
             return False
         S = self.Solution[l]
         b, e = self.bounds(S)
         if (e[0] - b[0]) * (e[1] - b[1]) * (e[2] - b[2]) < cfg.fused_prolong_min_points:
             return False
-        return not hasattr(self.ops, "two_stage_eligible") or self.ops.two_stage_eligible(S.lc, self.RHS[l].lc, self.Laplace[l], b, e, b, e)
+        return self._one_pass_sweep(l)
 
-    def Smoothers(self, l: int, n: int, correction_from: Optional[Field] = None):
+    def _starts_from_zero(self, l: int) -> bool:
+        """Is `SetSolution@l ( 0 )` (in VCycle@(l+1)) left to the first pre-smoothing sweep of level l?  Its boundary planes must be
+        the zeros of the field's bc (not the values SetFuncDir puts there while the FMG start works ON that level)."""
+        cfg = self.cfg
+        return bool(cfg.fused_zero_start and cfg.fused_rbgs and cfg.smoother == "rbgs" and self._single_block() and
+                    l != cfg.min_level and l < cfg.max_level and cfg.n_smooth >= 1 and self.Solution[l].bc_fn == FN_ZERO and
+                    not self._func_dir.get(l) and self.Laplace[l].cfield is None and self._one_pass_sweep(l))
+
+    def Smoothers(self, l: int, n: int, correction_from: Optional[Field] = None, zero_input: bool = False):
         cfg = self.cfg
         if not (cfg.temporal_blocking and cfg.smoother == "jacobi"):
-            assert correction_from is None
-            for _ in range(n):
-                self.Smoother(l)
+            for i in range(n):
+                self.Smoother(l, correction_from if i == 0 else None, zero_input and i == 0)
             return
+        assert not zero_input
         # pairs of Smoother calls as one pass over HBM (exastencils_amd/smoothers.py), bit-identical
         from .smoothers import jacobi_pair
 
@@ -723,10 +787,10 @@ class SolverFromL3(_Program):
         self.ops.set(S.lc, S.data(), v, b, e)
 
     # Function VCycle@((coarsest + 1) to finest)
-    def VCycle(self, l: int):
+    def VCycle(self, l: int, solution_is_zero: bool = False):
         if l == self.cfg.min_level:
             return self.VCycle_0(l)
-        self.Smoothers(l, self.cfg.n_smooth)
+        self.Smoothers(l, self.cfg.n_smooth, zero_input=solution_is_zero)
         if self.cfg.fused_residual_restrict and self._single_block():
             # UpResidual@current + Restriction@current: nothing reads Residual@current before UpResidual writes it again
             S, R, F, Fc = self.Solution[l], self.Residual[l], self.RHS[l], self.RHS[l - 1]
@@ -738,8 +802,10 @@ class SolverFromL3(_Program):
         else:
             self.UpResidual(l)
             self.Restriction(l)
-        self.SetSolution(l - 1, 0.0)
-        self.VCycle(l - 1)
+        zero_start = self._starts_from_zero(l - 1)
+        if not zero_start:
+            self.SetSolution(l - 1, 0.0)
+        self.VCycle(l - 1, solution_is_zero=zero_start)
         if self._folds_prolongation(l):
             Sc = self.Solution[l - 1]
             self.communicate(Sc, Sc.active, "ghost")      # Correction@current's exchange (empty on a single block)
@@ -752,6 +818,16 @@ class SolverFromL3(_Program):
     def VCycle_0(self, l: int):
         ops, A = self.ops, self.Laplace[l]
         S, R, P, GP = self.Solution[l], self.Residual[l], self.VecP, self.VecGradP
+        if self.cfg.fused_coarse and self._single_block() and hasattr(ops, "cg_coarse"):
+            # the whole function as one persistent workgroup: alpha from the squared norm, no `apply bc` in this solver
+            # (include/examg.h: examg_cg_coarse_variant); reductions in the kernel's fixed order, iteration count stays on the device
+            from .lib import CG_ALPHA_FROM_NORM, CG_NO_BC
+
+            b, e = self.bounds(S)
+            ops.cg_coarse(S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), R.lc, R.data(), P.lc, P.data(), GP.lc, GP.data(), A,
+                          self.domain.geom(l), self.domain.face_mask(), self.cfg.cg_max, self.cfg.cg_tol, b, e, self._cg_info,
+                          flags=CG_ALPHA_FROM_NORM | CG_NO_BC)
+            return
         self.UpResidual(l)
         self.communicate(R)
         res = self.NormResidual(l)
@@ -782,6 +858,14 @@ class SolverFromL3(_Program):
     def SetFuncDir(self, l: int):
         """`loop over Solution<s> only dup [dir] on boundary`: duplicate plane of each physical face, DLB..DRE
         tangentially (baseExt/ir/IR_LoopOverPointsInOneFragment.scala:57-70)."""
+        S = self.Solution[l]
+        for s_ in range(S.num_slots):
+            self._set_func_dir(l, S.data(s_))
+        self._func_dir[l] = True
+        if l in self._rb_alt:
+            self._boundary_planes(l, self._rb_alt[l])
+
+    def _set_func_dir(self, l: int, array):
         S, lay, dom = self.Solution[l], self.Solution[l].layout, self.domain
         for d in range(dom.nd):
             for side in (-1, 1):
@@ -793,9 +877,7 @@ class SolverFromL3(_Program):
                         b[t], e[t] = (lay.idx("DLB", t), lay.idx("DLE", t)) if side < 0 else (lay.idx("DRB", t), lay.idx("DRE", t))
                     else:
                         b[t], e[t] = lay.idx("DLB", t), lay.idx("DRE", t)
-                for s_ in range(S.num_slots):
-                    self.ops.fill_fn(S.lc, S.data(s_), dom.geom(l), self.cfg.bc_fn, (self.cfg.kappa,), b, e)
-        self._shell_epoch[l] = self._shell_epoch.get(l, 0) + 1
+                self.ops.fill_fn(S.lc, array, dom.geom(l), self.cfg.bc_fn, (self.cfg.kappa,), b, e)
 
     def InitRHS(self, l: int):
         F = self.RHS[l]
@@ -808,7 +890,9 @@ class SolverFromL3(_Program):
     def ResetBC(self, l: int):
         for s_ in range(self.Solution[l].num_slots):
             self.apply_bc(self.Solution[l], s_)
-        self._shell_epoch[l] = self._shell_epoch.get(l, 0) + 1
+        self._func_dir[l] = False
+        if l in self._rb_alt:
+            self._boundary_planes(l, self._rb_alt[l])
 
     def FMG(self, l: int):
         self.SetFuncDir(l)
@@ -843,6 +927,14 @@ class SolverFromL3(_Program):
             for s_ in range(self.Solution[l].num_slots):
                 self.apply_bc(self.Solution[l], s_)
         self.apply_bc(self.VecP)
+        if cfg.fused_rbgs and cfg.smoother == "rbgs":
+            # the second array of the out-of-place sweeps belongs to the set-up, not to the first cycle
+            for l in self.levels[1:]:
+                if self.Laplace[l].cfield is None and not (self._single_block() and not self._one_pass_sweep(l)):
+                    if l in self._rb_alt:
+                        self._boundary_planes(l, self._rb_alt[l])      # after reset()
+                    else:
+                        self._sweep_arrays(l)
         if cfg.temporal_blocking and cfg.smoother == "jacobi":
             # the scratch fields of the two-step passes are part of the set-up (a 43 GB allocation inside Solve shows up there)
             if not hasattr(self, "_pair_tmp"):
@@ -853,22 +945,82 @@ class SolverFromL3(_Program):
                     self._pair_tmp[l] = Field("SolutionTmp", l, S.layout, self.ops, 1, S.bc_fn, S.bc_params)
                     self.apply_bc(self._pair_tmp[l])
 
+    # -- hipGraph capture (single block, one-call coarse solve: nothing in FMG / VCycle returns to the host) --------------------
+    def _pointer_state(self):
+        st = []
+        for l in self.levels:
+            S = self.Solution[l]
+            st.append((S.active, tuple(t.data_ptr() for t in S.slots), self._rb_alt[l].data_ptr() if l in self._rb_alt else 0))
+        return st
+
+    def reset(self):
+        """Back to the state after initFieldsWithZero + setup(): arrays are zeroed in place (device pointers, and with them the
+        captured graphs, stay valid)."""
+        arrays = list(self.VecP.slots) + list(self.VecGradP.slots) + list(self._rb_alt.values())
+        for l in self.levels:
+            arrays += self.Solution[l].slots + self.RHS[l].slots + self.Residual[l].slots
+        for f in list(self._rb_tmp.values()) + list(getattr(self, "_pair_tmp", {}).values()):
+            arrays += f.slots
+        for t in arrays:
+            t.zero_()
+        for f in getattr(self, "_pair_tmp", {}).values():
+            self.apply_bc(f)
+        self._func_dir = {}
+        self.log, self.res_history, self.err_history, self.cg_iters = [], [], [], []
+        self.setup()
+
+    def capture(self):
+        """Record the FMG start (if the program has one) and one VCycle@finest as hipGraphs -- what a compiled host issues in a few
+        microseconds per launch -- and go back to the initial state; Solve(use_graph=True) replays them."""
+        cfg = self.cfg
+        if not (self._single_block() and cfg.fused_coarse and hasattr(self.ops, "torch")):
+            raise RuntimeError("graph capture needs a single block, the one-call coarse solve and the HIP kernel layer")
+        torch, dev = self.ops.torch, self.ops.device
+        hi, lo = cfg.max_level, cfg.min_level
+
+        def phases():
+            out = []
+            if cfg.fmg and hi > lo:
+                out.append(("fmg", lambda: self.FMG(lo)))
+            out.append(("cycle", lambda: self.VCycle(hi)))
+            return out
+
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _, fn in phases():        # warm-up outside capture (lazy allocations)
+                before = self._pointer_state()
+                fn()
+                if self._pointer_state() != before:
+                    raise RuntimeError("graph capture needs an even number of array swaps per level and phase")
+        torch.cuda.current_stream(dev).wait_stream(side)
+        for name, fn in phases():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                fn()
+            self._graphs[name] = g
+        self.reset()
+
     # Function Solve
-    def Solve(self) -> int:
+    def Solve(self, use_graph: bool = False) -> int:
         cfg, hi = self.cfg, self.cfg.max_level
-        self.UpResidual(hi)
-        resStart = self.NormResidual(hi)
+        resStart = self._residual_and_norm(hi)
         res = resStart
         self.res_history.append(res)
         self.log.append(reduced_prec(res))
         if cfg.fmg:
-            self.FMG(cfg.min_level)
+            if use_graph:
+                self._graphs["fmg"].replay()
+            else:
+                self.FMG(cfg.min_level)
         numIt = 0
         while not (res < cfg.tol * resStart or numIt >= cfg.max_it):
             numIt += 1
-            self.VCycle(hi)
-            self.UpResidual(hi)
-            res = self.NormResidual(hi)
+            if use_graph:
+                self._graphs["cycle"].replay()
+            else:
+                self.VCycle(hi)
+            res = self._residual_and_norm(hi)
             self.res_history.append(res)
             if cfg.sol_fn is not None:
                 err = self.NormError(hi)

@@ -297,6 +297,18 @@ int examg_cg_coarse(const examg_layout_t *lu, double *sol, const examg_layout_t 
                     const examg_layout_t *lq, double *ap, const examg_stencil_t *st, const examg_geom_t *g,
                     uint32_t face_mask, int max_it, double rel_tol, const int32_t *begin, const int32_t *end,
                     double *info, examg_stream_t stream);
+/* The same solver as the reference's layer-3 solver generator writes it (Function VCycle_0@coarsest, Testing/Smoothers/Jac.exa4:75-109,
+ * Testing/FMG/3D_Trigonometric.exa4: the programs with slotted fields): the numerator of alpha is the SQUARE OF THE ROUNDED NORM carried
+ * from the previous iteration (`alpha = res * res / alphaDenom`) instead of a fresh sum of squares, and the solver contains no
+ * `apply bc` statements -- boundary planes are read as they are and never written (Solution@coarsest carries the Dirichlet values of
+ * the FMG start there). */
+#define EXAMG_CG_ALPHA_FROM_NORM 1u
+#define EXAMG_CG_NO_BC 2u
+int examg_cg_coarse_variant(const examg_layout_t *lu, double *sol, const examg_layout_t *lf, const double *rhs,
+                            const examg_layout_t *lr, double *res, const examg_layout_t *lp, double *p,
+                            const examg_layout_t *lq, double *ap, const examg_stencil_t *st, const examg_geom_t *g,
+                            uint32_t face_mask, int max_it, double rel_tol, const int32_t *begin, const int32_t *end,
+                            uint32_t flags, double *info, examg_stream_t stream);
 
 /* ---- external fields: get<Name>(dest, slot) / set<Name>(src, slot) of `external Field` declarations
  * (interfacing/ir/IR_CopyToExternalField.scala:31-90, IR_CopyFromExternalField.scala): device-to-device copy between a

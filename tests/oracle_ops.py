@@ -147,12 +147,13 @@ class OracleOps:
         self.stencil_op(1, lu, u, lf, rhs, lu, tmp, st, 0.0, -1, begin, end)
         return self.dot(lu, tmp, lu, tmp, begin, end, out)
 
-    def cg_coarse(self, lu, sol, lf, rhs, lr, res, lp, p, lq, ap, st, geom, face_mask, max_it, rel_tol, begin, end, info):
-        """The statements examg_cg_coarse fuses (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:152-201), one oracle loop each."""
+    def cg_coarse(self, lu, sol, lf, rhs, lr, res, lp, p, lq, ap, st, geom, face_mask, max_it, rel_tol, begin, end, info, flags=0):
+        """The statements examg_cg_coarse fuses (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:152-201), one oracle loop each;
+        flags 1: alpha = res * res / alphaDenom, 2: no `apply bc` (the layer-3 generator's form, Testing/Smoothers/Jac.exa4:75-109)."""
         import math
 
         def bc(l, x):
-            if face_mask:
+            if face_mask and not (flags & 2):
                 self.apply_dirichlet(l, x, geom, 0, (), face_mask)
 
         def norm():
@@ -166,7 +167,7 @@ class OracleOps:
         steps = max_it
         for it in range(max_it):
             self.stencil_op(0, lp, p, None, None, lq, ap, st, 0.0, -1, begin, end)
-            num = self.scalar_value(self.dot(lr, res, lr, res, begin, end))
+            num = cur * cur if flags & 1 else self.scalar_value(self.dot(lr, res, lr, res, begin, end))
             den = self.scalar_value(self.dot(lp, p, lq, ap, begin, end))
             alpha = num / den if den != 0.0 else float("nan")
             self.axpby(lp, p, lu, sol, alpha, 1.0, begin, end)

@@ -98,8 +98,10 @@ def test_config5_512_fmg_history_vs_own_oracle(hip, fused):
     red-black V(3,3) cycles (Testing/Smoothers/RBGS.exa4:125-133), levels 2..9."""
     rec = _fixture("config5_512")
     kw = dict(rec["config"])
-    P = SolverFromL3(ConfigL3(**kw, fused_rbgs=fused, fused_residual_restrict=fused), hip)
+    P = SolverFromL3(ConfigL3(**kw, fused_rbgs=fused, fused_residual_restrict=fused, fused_prolong_min_points=50_000_000 if fused else 0,
+                              fused_zero_start=fused, fused_residual_norm=fused, fused_coarse=fused), hip)
     P.setup()
+    assert P._folds_prolongation(kw["max_level"]) == fused
     P.Solve()
     assert P.iterations == rec["iterations"]
     _check_history(P.res_history, rec["res"])

@@ -358,6 +358,93 @@ def test_lds_resident_coarse_cg_equals_global_memory_solver():
         assert np.array_equal(hist[0][1], hist[1][1])
 
 
+def test_coarse_cg_variant_of_the_layer3_generator():
+    """examg_cg_coarse_variant(ALPHA_FROM_NORM | NO_BC) -- VCycle_0@coarsest of Testing/Smoothers/Jac.exa4:75-109: alpha from the
+    squared norm, no `apply bc` -- against the oracle's loops in that order, with NON-ZERO boundary planes in Solution and in the
+    search direction (the FMG start keeps Dirichlet values in Solution@coarsest): both forms of the kernel (LDS-resident and
+    global-memory) agree bit for bit with each other and to rounding with the oracle; boundary planes stay untouched."""
+    from exastencils_amd import lib
+    from exastencils_amd.field import laplace_fd
+    from exastencils_amd.layout import FieldLayout
+    from exastencils_amd.ops import HipOps
+    from oracle_ops import OracleOps
+
+    hip, orc = HipOps(0, lib.DBG_LIB_PATH), OracleOps()
+    for n in (4, 16, 32):        # 3^3 and 15^3 unknowns: LDS form available; 31^3: global-memory form only
+        lu, ln = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0)
+        A = laplace_fd(3, (1.0 / n,) * 3, "pm", "mul")
+        b, e = [1, 1, 1], [n, n, n]
+        from exastencils_amd.domain import RectDomain
+
+        geom, mask = RectDomain(3).geom(2), 63
+        results = []
+        for ops, lds in ((orc, None), (hip, 1), (hip, 0)):
+            if lds is not None:
+                hip.L.examg_debug_cg(lds)
+            sol, rhs, res, p, ap = (ops.new_array(lu.size), ops.new_array(ln.size), ops.new_array(lu.size), ops.new_array(lu.size),
+                                    ops.new_array(ln.size))
+            info = ops.new_array(4)
+            ops.fill_random(sol, 5)        # whole arrays, boundary and ghost planes included
+            ops.fill_random(rhs, 6)
+            ops.fill_random(p, 7)
+            ops.fill_random(res, 8)
+            before = [ops.to_host(t).copy() for t in (sol, p, res)]
+            ops.cg_coarse(lu.c_struct(), sol, ln.c_struct(), rhs, lu.c_struct(), res, lu.c_struct(), p, ln.c_struct(), ap, A, geom, mask,
+                          200, 1e-3, b, e, info, flags=lib.CG_ALPHA_FROM_NORM | lib.CG_NO_BC)
+            ops.synchronize()
+            results.append(([ops.to_host(t).copy() for t in (sol, p, res)], before, float(ops.to_host(info)[0])))
+        hip.L.examg_debug_cg(1)
+        (o_out, o_in, o_it), (l_out, l_in, l_it), (g_out, g_in, g_it) = results
+        assert o_it == l_it == g_it and 1 <= o_it < 200, (n, o_it, l_it, g_it)
+        inner = tuple(slice(2, n + 1) for _ in range(3))
+        for k in range(3):
+            assert np.array_equal(l_out[k], g_out[k])                            # the two forms of the kernel
+            scale = np.abs(o_out[k]).max()
+            assert np.allclose(l_out[k], o_out[k], rtol=1e-10, atol=1e-12 * scale)
+            shell_after, shell_before = l_out[k].reshape(lu.shape_zyx).copy(), l_in[k].reshape(lu.shape_zyx).copy()
+            shell_after[inner] = 0.0
+            shell_before[inner] = 0.0
+            assert np.array_equal(shell_after, shell_before)                     # no `apply bc`: nothing outside the box is written
+
+
+def test_fmg_driver_one_pass_forms_on_gpu(hip):
+    """The FMG driver with every one-pass form (tests/test_host_logic.py::test_fmg_driver_with_one_pass_forms) on the HIP kernels at
+    256^3: folded correction and zero-field sweeps change no bit; residual + norm and the one-call coarse solve sum in another order --
+    same iteration count, histories within 1e-10 of the statement-by-statement driver and of the oracle program."""
+    from exastencils_amd.solver import ConfigL3, SolverFromL3
+
+    kw = dict(nd=3, min_level=2, max_level=8, smoother="rbgs", omega=1.0, stencil="scaled", restrict_scale=1.0, tol=1e-8, bc_fn=1, fmg=True)
+    base = dict(fused_rbgs=True, fused_residual_restrict=True)
+    runs = {}
+    for name, extra in (("plain", {}), ("sweeps", dict(base)),
+                        ("fold_zero", dict(base, fused_prolong_min_points=1, fused_zero_start=True)),
+                        ("all", dict(base, fused_prolong_min_points=1, fused_zero_start=True, fused_residual_norm=True, fused_coarse=True))):
+        P = SolverFromL3(ConfigL3(**kw, **extra), hip)
+        P.setup()
+        P.Solve()
+        runs[name] = (P.iterations, P.res_history, hip.to_host(P.Solution[8].data()).copy(), P)
+    P = runs["all"][3]
+    assert P._folds_prolongation(8) and P._folds_prolongation(7) and P._starts_from_zero(7) and not P._starts_from_zero(6)      # 64^3 has rows of 63 points
+    assert runs["fold_zero"][1] == runs["sweeps"][1] and np.array_equal(runs["fold_zero"][2], runs["sweeps"][2])
+    O = mg.ProgramB(mg.ConfigB(**kw))
+    O.setup()
+    O.Solve()
+    for name in ("plain", "sweeps", "all"):
+        assert runs[name][0] == O.iterations, name
+        _close(runs[name][1], O.res_history)
+    # FMG start and VCycle@finest replayed from hipGraphs (nothing in them returns to the host): the same launches, the same bits
+    G = SolverFromL3(ConfigL3(**kw, **dict(base, fused_prolong_min_points=1, fused_zero_start=True, fused_residual_norm=True,
+                                           fused_coarse=True)), hip)
+    G.setup()
+    G.capture()
+    G.Solve(use_graph=True)
+    assert G.res_history == runs["all"][1]
+    assert np.array_equal(hip.to_host(G.Solution[8].data()), runs["all"][2])
+    G.reset()
+    G.Solve(use_graph=True)           # ... and again after a reset
+    assert G.res_history == runs["all"][1]
+
+
 def test_folded_prolongation_changes_no_bit(hip):
     """V-cycles with the correction loop folded into the first post-smoothing sweep (examg_rbgs_sweep_fused_prolong on every
     level with rows of 64 points or more) leave the same residual history and the same solution, bit for bit."""

@@ -63,6 +63,28 @@ def test_folded_prolongation_in_the_host_driver():
     assert hist[0] == hist[1] and len(hist[0]) > 3
 
 
+def test_fmg_driver_with_one_pass_forms():
+    """The layer-3 style driver (FMG start of Testing/FMG/3D_Trigonometric.exa4:189-242 with the red-black smoother of
+    Testing/Smoothers/RBGS.exa4:125-133) with every one-pass form switched on -- correction folded into the first post-smoothing sweep,
+    zero field left to the first pre-smoothing sweep, residual + norm, VCycle_0 as one call (alpha from the squared norm, no `apply bc`)
+    -- against the statement-by-statement driver; on the CPU the oracle's loops stand in, so the histories are equal to the last bit."""
+    kw = dict(nd=3, min_level=2, max_level=5, smoother="rbgs", omega=1.0, stencil="scaled", restrict_scale=1.0, tol=1e-9, bc_fn=1, fmg=True)
+    plain = SolverFromL3(ConfigL3(**kw), OracleOps())
+    plain.setup()
+    plain.Solve()
+    fused = SolverFromL3(ConfigL3(**kw, fused_rbgs=True, fused_residual_restrict=True, fused_prolong_min_points=1, fused_zero_start=True,
+                                  fused_residual_norm=True, fused_coarse=True), OracleOps())
+    fused.setup()
+    assert fused._folds_prolongation(5) and fused._starts_from_zero(4) and not fused._starts_from_zero(2)
+    fused.Solve()
+    assert fused.iterations == plain.iterations and len(plain.res_history) > 2
+    assert fused.res_history == plain.res_history
+    O = mg.ProgramB(mg.ConfigB(**kw))
+    O.setup()
+    O.Solve()
+    assert plain.res_history == O.res_history
+
+
 def test_layout_matches_reference_sizes():
     # SURVEY.md section 8: 512^3 NodeWithComm => TOT = 2^L + 3 = 515 per dim, NodeNoGhost => 513
     l = FieldLayout.node(3, (512, 512, 512), 1)
