@@ -441,6 +441,11 @@ def main():
                 more.update(fmg_solve(ops, L, args.align))
             except Exception as ex:
                 more["fmg_error"] = repr(ex)[:300]
+            try:
+                torch.cuda.empty_cache()
+                more.update(helmholtz27_cycle(ops, L))
+            except Exception as ex:
+                more["helmholtz27_error"] = repr(ex)[:300]
         done.set()
         if rank == 0:
             if "roofline_kernels" in more and "vcycle_ms" in more:
@@ -634,6 +639,46 @@ def fmg_solve(ops, L, align=0):
         best = ms if best is None else min(best, ms)
     return {"fmg_solve_ms": best, "fmg_v_cycles": P.iterations, "fmg_levels": L - 1,
             "fmg_residual_reduction": (P.res_history[-1] / P.res_history[0]) if P.res_history and P.res_history[0] else None}
+
+
+def helmholtz27_cycle(ops, L):
+    """BASELINE configs[3]'s operator on one block: -div(a grad u) - k^2 u as a 27-entry stencil field on every level, Jacobi V(3,3)
+    cycle of the slotted program (Testing/Smoothers/Jac.exa4 with `Laplace` a stencil field, as Testing/SISC/3D_VarCoeff.exa4 has
+    it), 2^L cells per dimension, coarsest level 4^3 cells; the cycle replayed from a hipGraph."""
+    import torch
+
+    from exastencils_amd.solver import ConfigL3, SolverFromL3
+
+    cfg = ConfigL3(nd=3, min_level=1, max_level=L - 1, frag_len=(2, 2, 2), smoother="jacobi", omega=0.8, stencil="helmholtz27",
+                   restrict_scale=1.0, tol=1e-8, cg_max=512, bc_fn=0, sol_fn=9, coef_fn=7, kappa=10.0, ksq=2.0, rhs_from_solution=True,
+                   fused_coarse=True)
+    P = SolverFromL3(cfg, ops)
+    P.setup()
+    r0 = P._residual_and_norm(cfg.max_level)
+    P.capture()
+    run = P._graphs["cycle"].replay
+    for _ in range(2):
+        run()
+    n = 4
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    r1 = P._residual_and_norm(cfg.max_level)
+    # compulsory bytes per cycle and level above the coarsest: 6 Jacobi steps + the residual at 24 + 8 * 27 B per point, restriction
+    # (8 B per point + 8 B per coarse point), zeroing the coarse solution, prolongation + correction (16 B per point + 8 B per coarse point)
+    comp = 0.0
+    for l in range(cfg.min_level + 1, cfg.max_level + 1):
+        lb, le = P.domain.loop_bounds(P.Solution[l].layout)
+        cb, ce = P.domain.loop_bounds(P.Solution[l - 1].layout)
+        p = float((le[0] - lb[0]) * (le[1] - lb[1]) * (le[2] - lb[2]))
+        c = float((ce[0] - cb[0]) * (ce[1] - cb[1]) * (ce[2] - cb[2]))
+        comp += 7 * 240.0 * p + (8.0 * p + 8.0 * c) + 8.0 * c + (16.0 * p + 8.0 * c)
+    return {"helmholtz27_vcycle_ms": ms, "helmholtz27_levels": cfg.max_level - cfg.min_level + 1,
+            "helmholtz27_residual_reduction_6_cycles": r1 / r0 if r0 else None,
+            "helmholtz27_vcycle_frac": comp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 if __name__ == "__main__":
