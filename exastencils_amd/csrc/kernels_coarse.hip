@@ -105,6 +105,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
   __syncthreads();
 
   int it = 0;
+  bool converged = false;
   double nextRes = curRes;
   for (; it < max_it;) {
     // cgTmp1 = Laplace * cgTmp0 ; alphaNom = sum Residual^2 ; alphaDenom = sum cgTmp0 * cgTmp1
@@ -132,7 +133,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
     }
     nextRes = sqrt(cg_block_sum(s2, sm));
     ++it;
-    if (nextRes <= rel_tol * initRes) break;  // uniform: every thread holds the same sums
+    if (nextRes <= rel_tol * initRes) { converged = true; break; }  // uniform: every thread holds the same sums
     const double beta = (nextRes * nextRes) / (curRes * curRes);
     // cgTmp0 = Residual + beta * cgTmp0
     for (int t = threadIdx.x; t < total; t += CG_THREADS) {
@@ -148,6 +149,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
     info[0] = (double)it;
     info[1] = initRes;
     info[2] = nextRes;
+    if (!converged) info[3] = info[3] + 1.0;   // the statement after the loop: print ( "Maximum number of cgs iterations (..) was exceeded" )
   }
 }
 
@@ -221,6 +223,7 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
   __syncthreads();
 
   int it = 0;
+  bool converged = false;
   double nextRes = curRes;
   for (; it < max_it;) {
     double sn = 0.0, sd = 0.0;
@@ -248,7 +251,7 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
     }
     nextRes = sqrt(cg_block_sum(s2, sm));
     ++it;
-    if (nextRes <= rel_tol * initRes) break;
+    if (nextRes <= rel_tol * initRes) { converged = true; break; }
     const double beta = (nextRes * nextRes) / (curRes * curRes);
 #pragma unroll
     for (int j = 0; j < CG_PPT; ++j) {
@@ -274,6 +277,7 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
     info[0] = (double)it;
     info[1] = initRes;
     info[2] = nextRes;
+    if (!converged) info[3] = info[3] + 1.0;   // the statement after the loop: print ( "Maximum number of cgs iterations (..) was exceeded" )
   }
 }
 

@@ -92,6 +92,17 @@ class _Program:
     def _single_block(self) -> bool:
         return self.domain.world_size == 1
 
+    def _report_cg_limit(self):
+        """One-call coarse solves count on the device how often the CG loop ran out of iterations (info[3]); the message the generated
+        function prints at that point is appended to the log when the host next looks (end of Solve)."""
+        info = getattr(self, "_cg_info", None)
+        if info is None or not getattr(self.cfg, "fused_coarse", False):
+            return
+        n = int(self.ops.to_host(info)[3])
+        for _ in range(n - getattr(self, "_cg_limit_seen", 0)):
+            self.log.append("Maximum number of cgs iterations (%d) was exceeded" % self.cfg.cg_max)
+        self._cg_limit_seen = n
+
 
 # =================================================================================================
 # Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4
@@ -310,6 +321,7 @@ class SolverFromL4(_Program):
             self.res_history.append(curRes)
             self.log.append(reduced_prec(curRes))
         self.iterations = curIt
+        self._report_cg_limit()
         return curIt
 
     # repeat 3 times { color with { (i0+i1+i2) % 2, communicate; loop over Solution {...}; apply bc } }  (:204-213)
@@ -1028,6 +1040,7 @@ class SolverFromL3(_Program):
                 self.log.append(reduced_prec(err))
             else:
                 self.log.append(reduced_prec(res))
+        self._report_cg_limit()
         self.log.append(str(numIt))
         self.iterations = numIt
         return numIt

@@ -290,8 +290,10 @@ int examg_unpack(const examg_layout_t *l, double *x, const double *buf, const in
                  examg_stream_t stream);
 
 /* ---- a-16: coarse-grid CG, mgCycle@coarsest (...exa4:152-201) as ONE persistent single-workgroup
- * kernel (no host round trips).  Fields in the reference layout; `scratch` >= 8 doubles.
- * info[0] = iterations, info[1] = initial residual, info[2] = final residual (device). */
+ * kernel (no host round trips).  Fields in the reference layout.  info: >= 4 doubles in device memory, zeroed by the
+ * caller once: info[0] = iterations, info[1] = initial residual, info[2] = final residual of this call; info[3] is
+ * incremented when the loop ended at max_it without meeting the tolerance -- where the generated function prints
+ * "Maximum number of cgs iterations (max_it) was exceeded" (the host reads the count when it next synchronises). */
 int examg_cg_coarse(const examg_layout_t *lu, double *sol, const examg_layout_t *lf, const double *rhs,
                     const examg_layout_t *lr, double *res, const examg_layout_t *lp, double *p,
                     const examg_layout_t *lq, double *ap, const examg_stencil_t *st, const examg_geom_t *g,

@@ -182,6 +182,8 @@ class OracleOps:
             self.axpby(lr, res, lp, p, 1.0, beta, begin, end)
             bc(lp, p)
             cur = nxt
+        else:
+            info[3] += 1           # the loop ran out: the statement after it prints "Maximum number of cgs iterations ... exceeded"
         info[0] = steps
 
     def max_err_fn(self, l, x, geom, fn, params, begin, end, out=None):

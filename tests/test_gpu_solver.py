@@ -405,6 +405,22 @@ def test_coarse_cg_variant_of_the_layer3_generator():
             shell_after[inner] = 0.0
             shell_before[inner] = 0.0
             assert np.array_equal(shell_after, shell_before)                     # no `apply bc`: nothing outside the box is written
+    # the iteration limit: info[3] counts the solves whose loop ran out (where the generated function prints its message)
+    n = 16
+    lu, ln = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0)
+    A = laplace_fd(3, (1.0 / n,) * 3, "pm", "mul")
+    for lds in (1, 0):
+        hip.L.examg_debug_cg(lds)
+        sol, rhs, res, p, ap, info = (hip.new_array(lu.size), hip.new_array(ln.size), hip.new_array(lu.size), hip.new_array(lu.size),
+                                      hip.new_array(ln.size), hip.new_array(4))
+        hip.fill_random(rhs, 6)
+        for flags, limit, want in ((0, 2, 1.0), (3, 2, 2.0), (0, 200, 2.0)):
+            hip.cg_coarse(lu.c_struct(), sol, ln.c_struct(), rhs, lu.c_struct(), res, lu.c_struct(), p, ln.c_struct(), ap, A, geom, 63,
+                          limit, 1e-3, [1, 1, 1], [n, n, n], info, flags=flags)
+            hip.synchronize()
+            got = hip.to_host(info)
+            assert got[3] == want and got[0] <= limit, (lds, flags, limit, got)
+    hip.L.examg_debug_cg(1)
 
 
 def test_fmg_driver_one_pass_forms_on_gpu(hip):

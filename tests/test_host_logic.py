@@ -85,6 +85,18 @@ def test_fmg_driver_with_one_pass_forms():
     assert plain.res_history == O.res_history
 
 
+def test_one_call_coarse_solve_keeps_the_iteration_limit_message():
+    """`print ( "Maximum number of cgs iterations (", n, ") was exceeded" )` after the CG loop: the one-call coarse solve counts the
+    event on the device and the driver appends the message when Solve ends -- as often as the statement-by-statement driver prints it."""
+    msgs = []
+    for fused in (False, True):
+        P = SolverFromL4(ConfigL4(nd=3, min_level=2, max_level=4, tol=1e-6, cg_max=2, max_it=3, fused_coarse=fused), OracleOps())
+        P.setup()
+        P.Solve()
+        msgs.append([m for m in P.log if m.startswith("Maximum number of cgs iterations (2)")])
+    assert msgs[0] == msgs[1] and len(msgs[0]) == 3
+
+
 def test_layout_matches_reference_sizes():
     # SURVEY.md section 8: 512^3 NodeWithComm => TOT = 2^L + 3 = 515 per dim, NodeNoGhost => 513
     l = FieldLayout.node(3, (512, 512, 512), 1)
