@@ -649,7 +649,19 @@ class Exa4Program:
 
     def run(self, name: str = "Application"):
         self.call(name)
+        self._flush_cg_limit()
         return self.out
+
+    def _flush_cg_limit(self):
+        """The one-call coarse solve counts on the device how often its loop ran out of iterations (info[3]); the statements the
+        program has after that loop -- a print -- run that often when the program ends."""
+        if not hasattr(self, "_cg_tail"):
+            return
+        tail, lvl = self._cg_tail
+        n = int(self.ops.to_host(self._cg_info)[3])
+        for _ in range(n - getattr(self, "_cg_limit_seen", 0)):
+            self._exec_block(tail, _Frame(lvl, {}))
+        self._cg_limit_seen = n
 
     # -- statements -----------------------------------------------------------------------------------------------------
     def _exec_block(self, body: list, fr: _Frame):
@@ -1050,6 +1062,7 @@ class Exa4Program:
         if rep[0] != "repeat" or pos[0] < len(body) and not all(x[0] == "callstmt" and x[1][1] == "print" for x in body[pos[0]:]):
             return None
         max_it = int(self._eval(rep[1], fr))
+        tail = body[pos[0]:]                                # print statements after the loop: reached when it runs out of iterations
         body, pos[0] = self._inline(rep[3], lvl), 0
         if body is None:
             return None
@@ -1120,13 +1133,14 @@ class Exa4Program:
                 return None
         if any(x.num_slots != 1 for x in (U, F, R, P, Q)):
             return None
-        return U, F, R, P, Q, A, max_it, tol
+        return U, F, R, P, Q, A, max_it, tol, tail
 
     def _run_coarse_cg(self, plan):
-        U, F, R, P, Q, A, max_it, tol = plan
+        U, F, R, P, Q, A, max_it, tol, tail = plan
         b, e = self.domain.loop_bounds(U.layout)
         if not hasattr(self, "_cg_info"):
             self._cg_info = self.ops.new_array(4)
+        self._cg_tail = (tail, U.level)
         self.launches += 1
         self.ops.cg_coarse(U.lc, U.data(), F.lc, F.data(), R.lc, R.data(), P.lc, P.data(), Q.lc, Q.data(), A,
                            self.domain.geom(U.level), self.domain.face_mask(), max_it, tol, b, e, self._cg_info)

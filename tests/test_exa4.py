@@ -247,6 +247,20 @@ def test_generated_cg_solver_is_recognised():
             assert R._coarse_cg_plan(R._resolve("mgCycle", R.min_level), R.min_level) is not None
 
 
+def test_coarse_solver_limit_message_survives_the_one_call_form():
+    """The statement after the CG loop (a print, reached when the loop runs out of iterations) is executed as often with the
+    one-call coarse solve -- which counts the event in info[3] -- as by the statement-by-statement interpretation."""
+    with open(os.path.join(EX, "poisson3d_rbgs.exa4")) as f:
+        text = f.read().replace("repeat 128 times {", "repeat 2 times {")
+    outs = []
+    for fuse in (False, True):
+        P = exa4.Exa4Program(text, dict(dimensionality=3, minLevel=2, maxLevel=4), ops=OracleOps(), fuse_coarse_solver=fuse)
+        P.run()
+        outs.append(sorted(P.out))          # the fused form prints the message at the end of the program, not where it happened
+    assert outs[0] == outs[1]
+    assert sum(1 for l in outs[0] if "iteration limit reached" in l) >= 3
+
+
 # -- parser -----------------------------------------------------------------------------------------------------------
 def _levels(text, lo=0, hi=6, cur=None):
     pr = exa4.Parser("Function F@%s { }" % text).parse()
