@@ -33,8 +33,9 @@ examg_init_varcoeff7 when they are -div(a grad) with a built-in `a`, else one ex
 Fewer passes than statements, where the statements allow it (`fuse=True`, bit-identical): a `color with` red-black
 sweep is one out-of-place pass (examg_rbgs_sweep_fused), `repeat n times { Smoother ( ) }` with a slotted Jacobi body runs
 as n/2 two-step passes (examg_jacobi2_boxes) -- both only while the boundary planes involved are known to hold the
-field's Dirichlet values.  A coarsest-level function that is statement for statement the generated CG solver becomes one
-persistent kernel (examg_cg_coarse; `fuse_coarse_solver`, agrees to reduction-order rounding); a cycle is then free of host
+field's Dirichlet values.  A coarsest-level function that is statement for statement the generated CG solver -- in the form of the
+layer-4 benchmark program or in the one the layer-3 solver generator writes (_match_coarse_cg) -- becomes one persistent kernel
+(examg_cg_coarse / examg_cg_coarse_variant; `fuse_coarse_solver`, agrees to reduction-order rounding); a cycle is then free of host
 synchronisation and `capture()` records it into a hipGraph.
 
 Two deliberate readings of printed-L4 files (Testing/Smoothers/Jac.exa4:43 declares the finest `Solution` without level
@@ -1001,9 +1002,14 @@ class Exa4Program:
 
     def _match_coarse_cg(self, fn: FunctionDecl, lvl: int):
         """The conjugate-gradient solver the reference's generator emits for `mgCycle@coarsest`
-        (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:152-201), recognised statement by statement."""
+        (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:152-201), recognised statement by statement -- and the form its layer-3
+        solver generator writes (Function VCycle_0@coarsest, Testing/Smoothers/Jac.exa4:75-109): alpha = res * res / alphaDenom
+        with the norm carried over instead of a sum of squares, both vector updates in one loop, no `apply bc` statements, the
+        solution possibly slotted (accessed through <active> only)."""
         if self.domain.world_size != 1 or not hasattr(self.ops, "cg_coarse"):
             return None
+        if self.domain.face_mask() != (1 << (2 * self.nd)) - 1:
+            return None         # a periodic block is its own neighbour: the solver's `communicate` statements do something
         body = self._inline(fn.body, lvl)
         if body is None:
             return None
@@ -1025,6 +1031,9 @@ class Exa4Program:
         def fld(e):
             return self._field(e, fr)[0]
 
+        def active_only(e):       # a slotted field may take part if the solver touches its active slot only
+            return e[0] == "fld" and e[2] in (None, "active", "activeSlot", "current", "currentSlot")
+
         def opt_comm(F):
             if peek()[0] == "comm" and fld(peek()[3]) is F:
                 take()
@@ -1043,6 +1052,8 @@ class Exa4Program:
         if rf is None:
             return None
         R, F, A, U = fld(a[2]), fld(rf[0]), rf[1], fld(rf[2])
+        if not active_only(rf[2]):
+            return None
         bc_r = opt_bc(R)
         opt_comm(R)
         # Var rr = Norm(); Var rr0 = rr
@@ -1090,17 +1101,32 @@ class Exa4Program:
                 name = take()[1]
             return name
 
+        sq = lambda v: ("bin", "*", ("id", v, None), ("id", v, None))
+        mark = pos[0]
         num = reduction(R, R)
-        den = reduction(P, Q) if num else None
+        from_norm = num is None                             # no sum of squares: alpha's numerator is the squared norm
+        if from_norm:
+            pos[0] = mark
+        den = reduction(P, Q)
         d = take()
-        if not den or d[0] != "decl" or d[2] != ("bin", "/", ("id", num, None), ("id", den, None)):
+        if not den or d[0] != "decl" or d[2] != ("bin", "/", sq(rr) if from_norm else ("id", num, None), ("id", den, None)):
             return None
         alpha = d[1]
-        a = loop1(take())                                   # u += alpha p
-        if not a or a[1] != "+=" or fld(a[2]) is not U or a[3] != ("bin", "*", ("id", alpha, None), a[3][3]) or fld(a[3][3]) is not P:
+        st = take()
+        if st[0] == "loop" and st[2] is None and st[3] is None and st[4] is None and len(st[5]) == 2 and all(x[0] == "assign" for x in st[5]):
+            a, a2 = st[5]                                   # both updates in one loop
+            bc_u = False
+        else:
+            a = loop1(st)
+            bc_u = None
+        # u += alpha p
+        if (not a or a[1] != "+=" or not active_only(a[2]) or fld(a[2]) is not U or a[3] != ("bin", "*", ("id", alpha, None), a[3][3])
+                or fld(a[3][3]) is not P):
             return None
-        bc_u = opt_bc(U)
-        a = loop1(take())                                   # r -= alpha q
+        if bc_u is None:
+            bc_u = opt_bc(U)
+            a2 = loop1(take())
+        a = a2                                              # r -= alpha q
         if not a or a[1] != "-=" or fld(a[2]) is not R or a[3] != ("bin", "*", ("id", alpha, None), a[3][3]) or fld(a[3][3]) is not Q:
             return None
         if opt_bc(R) != bc_r:
@@ -1115,7 +1141,6 @@ class Exa4Program:
             return None
         tol = float(self._eval(c[1][3][2], fr))
         d = take()                                          # Var beta = (rrNew * rrNew) / (rr * rr)
-        sq = lambda v: ("bin", "*", ("id", v, None), ("id", v, None))
         if d[0] != "decl" or d[2] != ("bin", "/", sq(new), sq(rr)):
             return None
         beta = d[1]
@@ -1127,23 +1152,30 @@ class Exa4Program:
             return None
         if take() != ("assign", "=", ("id", rr, None), ("id", new, None)) or pos[0] != len(body):
             return None
-        # the kernel applies homogeneous Dirichlet values to r, p and u on every face: the program must do the same
-        for fld_, has in ((R, bc_r), (P, bc_p), (U, bc_u)):
-            if not has or fld_.bc_fn != 0:
-                return None
-        if any(x.num_slots != 1 for x in (U, F, R, P, Q)):
+        # the kernel applies homogeneous Dirichlet values to r, p and u on every face, or leaves every boundary plane alone: the
+        # program must do one or the other
+        from .lib import CG_ALPHA_FROM_NORM, CG_NO_BC
+
+        flags = CG_ALPHA_FROM_NORM if from_norm else 0
+        if not (bc_r or bc_p or bc_u):
+            flags |= CG_NO_BC
+        else:
+            for fld_, has in ((R, bc_r), (P, bc_p), (U, bc_u)):
+                if not has or fld_.bc_fn != 0:
+                    return None
+        if any(x.num_slots != 1 for x in (F, R, P, Q)) or (U.num_slots != 1 and not flags & CG_NO_BC):
             return None
-        return U, F, R, P, Q, A, max_it, tol, tail
+        return U, F, R, P, Q, A, max_it, tol, tail, flags
 
     def _run_coarse_cg(self, plan):
-        U, F, R, P, Q, A, max_it, tol, tail = plan
+        U, F, R, P, Q, A, max_it, tol, tail, flags = plan
         b, e = self.domain.loop_bounds(U.layout)
         if not hasattr(self, "_cg_info"):
             self._cg_info = self.ops.new_array(4)
         self._cg_tail = (tail, U.level)
         self.launches += 1
         self.ops.cg_coarse(U.lc, U.data(), F.lc, F.data(), R.lc, R.data(), P.lc, P.data(), Q.lc, Q.data(), A,
-                           self.domain.geom(U.level), self.domain.face_mask(), max_it, tol, b, e, self._cg_info)
+                           self.domain.geom(U.level), self.domain.face_mask(), max_it, tol, b, e, self._cg_info, flags=flags)
         return None
 
     def _apply_bc(self, f: Field, slot: int):

@@ -228,7 +228,8 @@ def test_fused_passes_change_no_bit():
 
 def test_generated_cg_solver_is_recognised():
     """`Cycle@coarsest` of the example (and the reference's mgCycle@coarsest, when present) is the generated CG solver
-    and becomes one examg_cg_coarse call; the slotted program's CG (alpha from the squared norm) is left alone."""
+    and becomes one examg_cg_coarse call; so does the slotted program's CG -- the layer-3 generator's form: alpha from the squared
+    norm, no `apply bc`, both updates in one loop (examg_cg_coarse_variant, flags 3)."""
     P = example("poisson3d_rbgs.exa4", 2, 5)
     assert P._coarse_cg_plan(P._resolve("Cycle", 2), 2) is not None
     P.run()
@@ -236,8 +237,13 @@ def test_generated_cg_solver_is_recognised():
     Q.run()
     assert P.printed_values == Q.printed_values          # on the CPU ops the fused call runs the same loops
     assert P.launches < Q.launches
-    J = example("jacobi3d_slots.exa4", 0, 4)
-    assert J._coarse_cg_plan(J._resolve("Cycle", 0), 0) is None
+    J = example("jacobi3d_slots.exa4", 1, 4)
+    plan = J._coarse_cg_plan(J._resolve("Cycle", 1), 1)
+    assert plan is not None and plan[-1] == 3 and plan[0].num_slots == 2
+    J.run()
+    K = example("jacobi3d_slots.exa4", 1, 4, fuse_coarse_solver=False)
+    K.run()
+    assert J.printed_values == K.printed_values and J.launches < K.launches
     if os.path.isdir(REF):
         for prog, know in (("Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4", None),
                            ("Examples/Poisson/2D_FD_Poisson_fromL4.exa4", "Testing/Poisson/2D_FD_Poisson_fromL4.knowledge")):
@@ -245,6 +251,13 @@ def test_generated_cg_solver_is_recognised():
             with open(os.path.join(REF, prog)) as f:
                 R = exa4.Exa4Program(f.read(), k, ops=OracleOps())
             assert R._coarse_cg_plan(R._resolve("mgCycle", R.min_level), R.min_level) is not None
+        k = knowledge.parse_file(os.path.join(REF, "Testing/Smoothers/Jac.knowledge"))
+        for d in "xyz":     # one block: the one-call form needs every face on the physical boundary
+            k["domain_rect_numBlocks_" + d] = k["domain_rect_numFragsPerBlock_" + d] = 1
+        with open(os.path.join(REF, "Testing/Smoothers/Jac.exa4")) as f:
+            R = exa4.Exa4Program(f.read(), k, ops=OracleOps())
+        plan = R._coarse_cg_plan(R._resolve("VCycle_0", R.min_level), R.min_level)
+        assert plan is not None and plan[-1] == 3 and plan[6] == 512 and plan[7] == 0.001
 
 
 def test_coarse_solver_limit_message_survives_the_one_call_form():
