@@ -26,6 +26,9 @@ for p in (ROOT, HERE):
 # Testing/FMG/3D_VarCoeff.exa4 at a reduced size: stencil field, FMG start, error print
 _FMG_VAR = dict(nd=3, min_level=1, max_level=4, smoother="jacobi", omega=0.85, stencil="varcoeff", restrict_scale=1.0, tol=1e-5,
                 cg_max=1024, bc_fn=6, rhs_fn=5, sol_fn=6, coef_fn=7, kappa=10.0, fmg=True)
+# BASELINE configs[4]'s algorithm: FMG start (Testing/FMG/3D_Trigonometric.exa4:189-242) + red-black cycles
+_FMG_RBGS = dict(nd=3, min_level=1, max_level=4, smoother="rbgs", omega=1.0, stencil="scaled", restrict_scale=1.0, tol=1e-8, cg_max=512,
+                 bc_fn=1, fmg=True)
 
 
 def _free_port():
@@ -85,6 +88,9 @@ def _worker_solver(rank, world, port, blocks, case, out_dir):
                                   restrict_scale=4.0, tol=1e-5, cg_max=512, fused_rbgs=True), ops, dom, comm)
     elif case == "fmg_varcoeff":
         P = SolverFromL3(ConfigL3(**_FMG_VAR, frag_len=flen), ops, dom, comm)
+    elif case == "fmg_rbgs_fused":
+        # the second array of the out-of-place sweeps follows the boundary planes SetFuncDir / ResetBC rewrite, physical faces only
+        P = SolverFromL3(ConfigL3(**_FMG_RBGS, frag_len=flen, fused_rbgs=True), ops, dom, comm)
     elif case == "helmholtz27":
         from test_host_logic import HELMHOLTZ27
 
@@ -120,6 +126,8 @@ def _reference_single(case):
                                   restrict_scale=4.0, tol=1e-5, cg_max=512), ops)
     elif case == "fmg_varcoeff":
         P = SolverFromL3(ConfigL3(**_FMG_VAR, frag_len=flen), ops)
+    elif case == "fmg_rbgs_fused":
+        P = SolverFromL3(ConfigL3(**_FMG_RBGS, frag_len=flen), ops)
     elif case == "helmholtz27":
         from test_host_logic import HELMHOLTZ27
 
@@ -137,6 +145,7 @@ def _reference_single(case):
 
 
 @pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"), ((1, 2, 2), "rbgs_l3_fused"),
+                                         ((1, 1, 2), "fmg_rbgs_fused"),
                                          ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
                                          ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 2, 1), "rbgs_l4_cg"), ((2, 2, 1), "rbgs_l4_nodup_cg"), ((2, 1, 1), "rbgs_l4_fused"),
                                          ((2, 2, 1), "rbgs_l4_fused_nodup_cg"), ((2, 1, 1), "rbgs_l4_agg"), ((1, 1, 2), "rbgs_l4_fused_aggx_nodup_cg"), ((1, 1, 2), "jacobi_l3_tb_cg"),
