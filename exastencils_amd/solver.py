@@ -136,7 +136,8 @@ class ConfigL4:
     # one-pass sweep: it takes the zero field as a constant (examg_rbgs_sweep_fused_zero: no zeroing loop, 16 instead of 24 B per point)
     fused_zero_start: bool = False
     # Solve@finest: `Residual = RHS - A * Solution` + ResNorm as one pass that does not store the residual (nothing reads
-    # Residual@finest between two of the loop's updates when the cycle runs residual + restriction as one pass)
+    # Residual@finest between two of the loop's updates: every path of mgCycle starts with its own residual pass); also on blocks
+    # with neighbours (the exchange first, then one pass over the reduction's box, then the all-reduce)
     fused_residual_norm: bool = False
     overlap_transfers: bool = True            # blocks > 1: residual / restriction as interior + shell around their halo exchange
     agglomerate_level: Optional[int] = None   # blocks > 1: levels <= this are solved redundantly on every rank (see _agg_cycle)
@@ -236,9 +237,12 @@ class SolverFromL4(_Program):
     def _residual_and_norm(self, l: int) -> float:
         """`Residual = RHS - A * Solution` (statement of Solve@finest) followed by ResNorm()."""
         cfg = self.cfg
-        if not (cfg.fused_residual_norm and cfg.fused_residual_restrict and self._single_block()):
+        if not (cfg.fused_residual_norm and hasattr(self.ops, "residual_norm2")):
             self._update_residual(l)
             return self.ResNorm(l)
+        # nothing reads Residual@finest before the cycle writes it again (its own residual pass comes first on every path of
+        # mgCycle, with or without neighbours): the squares are summed where the residual would be stored, over the reduction's
+        # box (duplicate planes at interior faces count once), then all-reduced
         S, R, A = self.Solution[l], self.Residual[l], self.Laplace[l]
         self.communicate(S, axis_only=self._faces_only(A))
         b, e = self.bounds(R, reduction=True)

@@ -98,6 +98,7 @@ def _worker_solver(rank, world, port, blocks, case, out_dir):
     else:
         P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, frag_len=flen, tol=1e-6, fused_coarse=False,
                                   fused_rbgs="_fused" in case, agglomerate_level=2 if "_agg" in case else None,
+                                  fused_residual_norm="_rnorm" in case,      # Solve's residual + norm as one pass, across blocks
                                   agglomerate_extra_levels=1 if "_aggx" in case else 0), ops, dom, comm)
     P.setup()
     P.Solve()
@@ -145,7 +146,7 @@ def _reference_single(case):
 
 
 @pytest.mark.parametrize("blocks,case", [((2, 1, 1), "jacobi_l3"), ((2, 1, 1), "rbgs_l4"), ((1, 2, 1), "rbgs_l3"), ((1, 2, 2), "rbgs_l3_fused"),
-                                         ((1, 1, 2), "fmg_rbgs_fused"),
+                                         ((1, 1, 2), "fmg_rbgs_fused"), ((1, 2, 2), "rbgs_l4_fused_rnorm_nodup_cg"),
                                          ((2, 2, 1), "jacobi_l3"), ((2, 1, 1), "jacobi_l3_tb"), ((2, 2, 1), "jacobi_l3_tb"),
                                          ((2, 2, 1), "jacobi_l3_tb_cg"), ((2, 2, 1), "rbgs_l4_cg"), ((2, 2, 1), "rbgs_l4_nodup_cg"), ((2, 1, 1), "rbgs_l4_fused"),
                                          ((2, 2, 1), "rbgs_l4_fused_nodup_cg"), ((2, 1, 1), "rbgs_l4_agg"), ((1, 1, 2), "rbgs_l4_fused_aggx_nodup_cg"), ((1, 1, 2), "jacobi_l3_tb_cg"),
