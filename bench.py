@@ -649,6 +649,10 @@ def helmholtz27_cycle(ops, L):
 
     from exastencils_amd.solver import ConfigL3, SolverFromL3
 
+    need = 33 * 8.0 * float((1 << L) + 3) ** 3 * 8.0 / 7.0      # 27 coefficient planes, 2 + 1 + 1 + 2 field arrays, all levels
+    free = torch.cuda.mem_get_info(ops.device)[0]
+    if need > 0.9 * free:
+        return {"helmholtz27_skipped": "needs %.0f GB, %.0f GB free" % (need / 1e9, free / 1e9)}
     cfg = ConfigL3(nd=3, min_level=1, max_level=L - 1, frag_len=(2, 2, 2), smoother="jacobi", omega=0.8, stencil="helmholtz27",
                    restrict_scale=1.0, tol=1e-8, cg_max=512, bc_fn=0, sol_fn=9, coef_fn=7, kappa=10.0, ksq=2.0, rhs_from_solution=True,
                    fused_coarse=True)
