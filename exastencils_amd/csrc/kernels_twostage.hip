@@ -411,7 +411,7 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
 }
 
 // launch knobs (debug build: examg_debug_two_stage*; per host thread): workgroup count target, tile order
-static thread_local int g_ts_blocks = -1;      // workgroup count target; -1: 8192 from 5*10^7 points, 3072 below
+static thread_local int g_ts_blocks = -1;      // workgroup count target; -1: by size and variant (launch_two_stage_lds)
 static thread_local int g_ts_disable = 0;
 // tile order: 0 = plain (x fastest, then y, then z chunk); 1 = one contiguous run of tiles per XCD; 2 = XCD-contiguous within every
 // z layer of tiles: workgroups are dealt round-robin to the 8 XCDs, so within a layer each XCD gets a band of y-adjacent tiles
@@ -449,11 +449,22 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   g.ntx = (box.n0() + g.xs + TS_OUT - 1) / TS_OUT;
   g.nty = (box.n1() + g.ys + NO - 1) / NO;
   const int xy = g.ntx * g.nty;
-  // (with the correction folded in, a step costs more and longer chunks pay: 512^3, 3072 / 8192 workgroups: 0.87 / 0.92 ms)
-  const int blocks_target = g_ts_blocks > 0 ? g_ts_blocks : (box.count() >= 50000000LL && !prol ? 8192 : 3072);
+  // Workgroup count = chunk length in z.  From 5*10^7 points the plain passes take the shortest chunks (16 planes: 512^3 0.667 ms; a
+  // fixed count of 8192 workgroups made the chunks of larger blocks long again -- 768^3 2.37 -> 2.20 ms, 1024^3 5.60 -> 5.13 ms with
+  // 16-plane chunks, tools/sweep_two_stage_big.py).  With the correction folded in a step costs more and longer chunks pay: about 48
+  // planes (512^3: 16 / 32 / 48 planes 0.954 / 0.907 / 0.882 ms; 768^3 2.99 / 2.90 / 2.90; 1024^3 6.86 / 6.48 / 6.33), but at least
+  // ~1536 workgroups (384^3: 21 planes 0.427 against 16 planes 0.451).
+  const int n2 = box.n2() + g.zs;
+  int blocks_target = 3072;
+  if (prol) {
+    blocks_target = xy * ((n2 + 47) / 48);
+    if (blocks_target < 1536) blocks_target = 1536;
+  } else if (box.count() >= 50000000LL) {
+    blocks_target = 1 << 24;
+  }
+  if (g_ts_blocks > 0) blocks_target = g_ts_blocks;
   int ntz = (blocks_target + xy - 1) / xy;
   if (ntz < 1) ntz = 1;
-  const int n2 = box.n2() + g.zs;
   int zc = (n2 + ntz - 1) / ntz;
   // at least 16 planes per chunk (4 halo planes each); 8 on small boxes that would leave most of the chip idle otherwise
   // (tools/sweep_two_stage3.py, 5-wave workgroups, 16 / 8 / 4 planes: 128^3 0.0243 / 0.0186 / 0.0300 ms, 96^3 0.0235 / 0.0149 / 0.0129)
