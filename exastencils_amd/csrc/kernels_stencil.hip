@@ -297,6 +297,7 @@ int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const L
                          double *dst, const LayoutDev &lc, const double *cf, double w, const Box &box, hipStream_t s);
 
 constexpr int ZM_RY = 2, ZM_WY = 4, ZM_BLOCKS = 512, ZM_BLOCKS_COL = 1024, ZM_MINCHUNK = 16;   // half sweeps: 0.68 ms at 512 workgroups, 0.64 at 1024
+static thread_local int g_zm_blocks = -1, g_zm_minchunk = -1;    // examg_debug_zmarch (debug build): workgroup target, planes per chunk
 
 // returns the number of waves of the grid (ZM_RESNORM: the number of partial sums written to dst)
 template <int MODE, int ORDER>
@@ -315,10 +316,20 @@ static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &
   g.ntx = (box.e0 - g.xo + 127) / 128;
   g.nty = (box.n1() + ZM_RY * ZM_WY - 1) / (ZM_RY * ZM_WY);
   const int xy = g.ntx * g.nty;
-  int ntz = ((colour >= 0 ? ZM_BLOCKS_COL : ZM_BLOCKS) + xy - 1) / xy;
+  // Workgroup count = chunk length in z.  Up to 512^3 ~512 long-lived workgroups are best (1024 for the half sweeps); on larger blocks
+  // that makes every chunk a whole column and the front that sweeps memory as wide as the block -- from 2*10^8 points the chunks
+  // are 16 planes whatever the count (tools/sweep_big_others.py: Jacobi step 768^3 2.79 -> 2.22 ms, 1024^3 5.61 -> 4.89 ms = 0.66;
+  // half sweep 1024^3 5.58 -> 5.16).  The residual + norm mode writes one partial sum per wave into a fixed work buffer: 4096
+  // workgroups there (768^3 1.69 -> 1.53 ms).
+  const bool big = box.count() >= 200000000LL;
+  int target = colour >= 0 ? ZM_BLOCKS_COL : ZM_BLOCKS;
+  if (big) target = MODE == ZM_RESNORM ? 4096 : (1 << 24);
+  if (g_zm_blocks > 0) target = g_zm_blocks;
+  int ntz = (target + xy - 1) / xy;
   if (ntz < 1) ntz = 1;
   int zc = (box.n2() + ntz - 1) / ntz;
-  if (zc < ZM_MINCHUNK) zc = ZM_MINCHUNK;
+  const int minchunk = g_zm_minchunk > 0 ? g_zm_minchunk : ZM_MINCHUNK;
+  if (zc < minchunk) zc = minchunk;
   if (zc > box.n2()) zc = box.n2();
   g.zc = zc;
   g.ntz = (box.n2() + zc - 1) / zc;
@@ -344,6 +355,11 @@ using namespace examg;
 
 #ifdef EXAMG_DEBUG_HOOKS
 // Variant selection for the parity tests (debug build libexamg_dbg.so only; per host thread)
+extern "C" int examg_debug_zmarch(int blocks, int minchunk) {
+  g_zm_blocks = blocks;
+  g_zm_minchunk = minchunk;
+  return 0;
+}
 extern "C" int examg_debug_sf27(int unrolled) {
   g_sf27_unrolled = unrolled;
   return 0;

@@ -323,8 +323,10 @@ k_prolong_add3_pairs(LayoutDev lc, const double *__restrict__ uc, LayoutDev lfin
 static thread_local int g_restrict_wide = 1;
 // residual_restrict: wave count target, minimum coarse planes per wave.  MI355X, 512^3 -> 256^3 (tools/sweep_rr.py), ms by target:
 // 4096: 0.560, 9216: 0.511, 18432: 0.486, 24576: 0.479, 36864: 0.481 -- many short waves keep the tail of the launch short
-static thread_local int g_rr_waves = 24576, g_rr_minzc = 8;
-static thread_local int g_prolong_zb = 2;    // planes per workgroup of the pair prolongation (examg_debug_prolong)   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
+// chunks of 8 coarse planes at any size: with a fixed count of 24576 waves the chunks of blocks larger than 512^3 grew long and the
+// front wide (tools/sweep_big_others.py: 768^3 1.86 -> 1.75 ms, 1024^3 4.69 -> 4.16 ms; 512^3 0.527 -> 0.523, there 13 planes before)
+static thread_local int g_rr_waves = 1 << 22, g_rr_minzc = 8;
+static thread_local int g_prolong_zb = -1;    // planes per workgroup of the pair prolongation (examg_debug_prolong)   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
 
 static inline dim3 grid_for(long long total) {
   long long nb = (total + 255) / 256;
@@ -339,13 +341,13 @@ using namespace examg;
 
 #ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_residual_restrict(int waves, int minzc) {
-  if (waves > 0) examg::g_rr_waves = waves;
+  examg::g_rr_waves = waves > 0 ? waves : (1 << 22);
   if (minzc > 0) examg::g_rr_minzc = minzc;
   return 0;
 }
 
 extern "C" int examg_debug_prolong(int zb) {
-  examg::g_prolong_zb = zb > 0 ? zb : 8;
+  examg::g_prolong_zb = zb;
   return 0;
 }
 extern "C" int examg_debug_restrict(int wide) {
@@ -448,7 +450,7 @@ extern "C" int examg_prolong_add(const examg_layout_t *lc_, const double *uc, co
   if (lfine_->nd == 3 && box.n0() >= 32) {
     const int x0 = box.b0 & ~1;
     const int npairs = (box.e0 - x0 + 1) / 2;
-    const int zb = g_prolong_zb;
+    const int zb = g_prolong_zb > 0 ? g_prolong_zb : (box.count() >= 200000000LL ? 1 : 2);    // 768^3: 1.73 -> 1.68 ms with one plane pair per workgroup
     dim3 grid((npairs + 63) / 64, (box.n1() + 3) / 4, (box.n2() + zb - 1) / zb), block(64, 4, 1);
     hipLaunchKernelGGL(k_prolong_add3_pairs, grid, block, 0, s, lc, uc, lf, uf, box, x0, npairs, zb);
   } else if (lfine_->nd == 3) hipLaunchKernelGGL((k_prolong_add<3>), grid_for(box.count()), dim3(256), 0, s, lc, uc, lf, uf, box);
