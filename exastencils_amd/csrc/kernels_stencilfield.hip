@@ -152,7 +152,7 @@ k_stencilfield7_zmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf,
 // tuning hook (examg_debug_stencilfield): 0 = RY1/PF1, 1 = RY2/PF0, 2 = RY2/PF1, 3 = RY1/PF2; -1 = generic kernel.
 // tools/varcoeff_times.py at 512^3 (Jacobi, ms): generic 2.64, variant 0 2.31, 1 1.99, 2 2.74, 3 2.44 -> variant 1
 static thread_local int g_sf_variant = 1;
-static thread_local int g_sf_blocks = 2048;
+static thread_local int g_sf_blocks = -1;       // -1: 2048 workgroups, 16-plane chunks from 2*10^8 points (768^3 7.24 -> 6.95 ms, 1024^3 18.1 -> 17.1 ms)
 
 template <int MODE, int RY, int WY, int PF>
 static void launch_sf(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld, double *dst,
@@ -161,7 +161,8 @@ static void launch_sf(const LayoutDev &lu, const double *u, const LayoutDev &lf,
   g.ntx = (box.n0() + 127) / 128;
   g.nty = (box.n1() + RY * WY - 1) / (RY * WY);
   const int xy = g.ntx * g.nty;
-  int ntz = (g_sf_blocks + xy - 1) / xy;
+  const int blocks_target = g_sf_blocks > 0 ? g_sf_blocks : (box.count() >= 200000000LL ? (1 << 24) : 2048);
+  int ntz = (blocks_target + xy - 1) / xy;
   if (ntz < 1) ntz = 1;
   int zc = (box.n2() + ntz - 1) / ntz;
   if (zc < 16) zc = 16;
@@ -208,7 +209,7 @@ int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const L
 #ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_stencilfield(int variant, int blocks) {
   examg::g_sf_variant = variant;   // -1 disables the fast path
-  if (blocks > 0) examg::g_sf_blocks = blocks;
+  examg::g_sf_blocks = blocks > 0 ? blocks : -1;
   return 0;
 }
 #endif

@@ -326,6 +326,7 @@ static thread_local int g_restrict_wide = 1;
 // chunks of 8 coarse planes at any size: with a fixed count of 24576 waves the chunks of blocks larger than 512^3 grew long and the
 // front wide (tools/sweep_big_others.py: 768^3 1.86 -> 1.75 ms, 1024^3 4.69 -> 4.16 ms; 512^3 0.527 -> 0.523, there 13 planes before)
 static thread_local int g_rr_waves = 1 << 22, g_rr_minzc = 8;
+static thread_local int g_restrict_waves = -1;   // examg_debug_restrict(n > 1): wave count target of the wide restriction kernel
 static thread_local int g_prolong_zb = -1;    // planes per workgroup of the pair prolongation (examg_debug_prolong)   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
 
 static inline dim3 grid_for(long long total) {
@@ -351,7 +352,8 @@ extern "C" int examg_debug_prolong(int zb) {
   return 0;
 }
 extern "C" int examg_debug_restrict(int wide) {
-  examg::g_restrict_wide = wide;
+  examg::g_restrict_wide = wide != 0;
+  examg::g_restrict_waves = wide > 1 ? wide : -1;
   return 0;
 }
 #endif
@@ -373,7 +375,10 @@ extern "C" int examg_restrict(const examg_layout_t *lfine_, const double *rf, co
   if (lfine_->nd == 3 && box.n0() >= 32 && g_restrict_wide) {
     const int ntx = (box.n0() + 63) / 64;
     const long long cols = (long long)ntx * box.n1();
-    int ntz = (int)((4096 + cols - 1) / cols);
+    // ~4096 waves up to 512^3 -> 256^3; beyond that shorter chunks (tools/sweep_big_others2.py: 768^3 -> 384^3 0.90 -> 0.83 ms,
+    // 1024^3 -> 512^3 2.35 -> 2.14 ms with 65536 waves)
+    const int waves_target = g_restrict_waves > 0 ? g_restrict_waves : (box.count() >= 25000000LL ? 65536 : 4096);
+    int ntz = (int)((waves_target + cols - 1) / cols);
     if (ntz < 1) ntz = 1;
     int zc = (box.n2() + ntz - 1) / ntz;
     if (zc < 8) zc = 8;

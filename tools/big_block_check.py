@@ -82,6 +82,40 @@ ops.stencil_op(1, L, u, F, f, L, a, A, 0.0, -1, b, e)
 want = ops.scalar_value(ops.dot(L, a, L, a, b, e))
 got = ops.scalar_value(ops.residual_norm2(L, u, F, f, A, b, e))
 out["residual_norm2_rel_diff"] = abs(got - want) / want
+# one Jacobi step and the residual with the one-step kernel against the generic kernel, residual + restriction against its two loops
+import ctypes as C
+ops.stencil_op(2, L, u, F, f, L, a, A, w, -1, b, e)
+ops.L.examg_debug_force_generic(1)
+ops.stencil_op(2, L, u, F, f, L, b_, A, w, -1, b, e)
+ops.L.examg_debug_force_generic(0)
+out["one_step_kernel_equals_generic"] = bool(torch.equal(a, b_))
+bc_, ec_ = [1, 1, 1], [n // 2] * 3
+ops.residual_restrict(L, u, F, f, L, t, A, Lc, fc1, 1.0, b, e, bc_, ec_)
+ops.stencil_op(1, L, u, F, f, L, t, A, 0.0, -1, b, e)
+ops.restrict(L, t, Lc, fc2, 1.0, bc_, ec_)
+out["residual_restrict_equals_two_loops"] = bool(torch.equal(fc1, fc2))
+out["residual_restrict_ms"] = timed(lambda: ops.residual_restrict(L, u, F, f, L, t, A, Lc, fc1, 1.0, b, e, bc_, ec_))
+# prolongation + correction: pair kernel against the one-thread-per-point kernel
+lcu = FieldLayout.node(3, (n // 2,) * 3, 1)
+ucs = ops.new_array(lcu.size)
+ops.fill_random(ucs, 5)
+a.copy_(u); b_.copy_(u)
+ops.prolong_add(lcu.c_struct(), ucs, L, a, b, e)
+out["prolong_ms"] = timed(lambda: ops.prolong_add(lcu.c_struct(), ucs, L, b_, b, e))
+# 7-entry stencil field: z-march kernel against the generic kernel (skipped above 800^3: 7 coefficient planes of a 1024^3 block are 60 GB)
+if n <= 800:
+    from exastencils_amd.field import Stencil, stencil_field_offsets
+    ops.L.examg_debug_stencilfield.argtypes = [C.c_int, C.c_int]
+    cf = ops.new_array(7 * lf.size)
+    ops.fill_random(cf, 3)
+    cf += 3.0
+    sf = Stencil(stencil_field_offsets(3), [], cf, lf)
+    ops.stencil_op(2, L, u, F, f, L, a, sf, 0.8, -1, b, e)
+    ops.L.examg_debug_stencilfield(-1, 0)
+    ops.stencil_op(2, L, u, F, f, L, b_, sf, 0.8, -1, b, e)
+    ops.L.examg_debug_stencilfield(1, 0)
+    out["stencilfield7_kernel_equals_generic"] = bool(torch.equal(a, b_))
+    out["stencilfield7_ms"] = timed(lambda: ops.stencil_op(2, L, u, F, f, L, a, sf, 0.8, -1, b, e))
 pts = (n - 1) ** 3
 out["jacobi2_lups"] = 2 * pts / (out["jacobi2_ms"] * 1e-3)
 out["jacobi2_algorithmic_gbs"] = 48.0 * pts / (out["jacobi2_ms"] * 1e-3) / 1e9
