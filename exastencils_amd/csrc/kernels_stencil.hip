@@ -317,13 +317,16 @@ static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &
   g.nty = (box.n1() + ZM_RY * ZM_WY - 1) / (ZM_RY * ZM_WY);
   const int xy = g.ntx * g.nty;
   // Workgroup count = chunk length in z.  Up to 512^3 ~512 long-lived workgroups are best (1024 for the half sweeps); on larger blocks
-  // that makes every chunk a whole column and the front that sweeps memory as wide as the block -- from 2*10^8 points the chunks
+  // that makes every chunk a whole column and the front that sweeps memory as wide as the block -- from 1.5*10^8 points the chunks
   // are 16 planes whatever the count (tools/sweep_big_others.py: Jacobi step 768^3 2.79 -> 2.22 ms, 1024^3 5.61 -> 4.89 ms = 0.66;
   // half sweep 1024^3 5.58 -> 5.16).  The residual + norm mode writes one partial sum per wave into a fixed work buffer: 4096
   // workgroups there (768^3 1.69 -> 1.53 ms).
-  const bool big = box.count() >= 200000000LL;
   int target = colour >= 0 ? ZM_BLOCKS_COL : ZM_BLOCKS;
-  if (big) target = MODE == ZM_RESNORM ? 4096 : (1 << 24);
+  if (MODE == ZM_RESNORM) {
+    if (box.count() >= 200000000LL) target = 4096;
+  } else if (box.count() >= 150000000LL) {     // 512^3 (1.3*10^8 points) is a tie: 0.625 / 0.630 ms; 576^3: 1.06 -> 0.97 ms
+    target = 1 << 24;
+  }
   if (g_zm_blocks > 0) target = g_zm_blocks;
   int ntz = (target + xy - 1) / xy;
   if (ntz < 1) ntz = 1;
