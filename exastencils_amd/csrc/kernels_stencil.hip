@@ -132,6 +132,7 @@ struct ZMarchGeom {
   int xo;             // x of lane 0's first point in tile 0: box.b0, or box.b0 - 1 where that makes every 16-byte access aligned
   int ntx, nty, ntz;  // tiles per dim
   int zc;             // planes per march chunk
+  int remap;          // 2: XCD-contiguous within every z layer of tiles (kernels_twostage.hip); 0: plain order
 };
 
 template <bool ALIAS> struct Ptr { typedef double *__restrict__ out; typedef const double *__restrict__ in; };
@@ -153,6 +154,12 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
   const int lane = threadIdx.x;   // 0..63
   const int wv = threadIdx.y;     // wave in block
   int t = blockIdx.x;
+  if (g.remap == 2) {   // workgroups are dealt round-robin to the 8 XCDs: within a layer of tiles every XCD takes a band of y-adjacent tiles
+    const int xy = g.ntx * g.nty;
+    const int lz = t / xy, r = t - lz * xy;
+    const int per = xy >> 3;
+    t = lz * xy + (r < (per << 3) ? (r & 7) * per + (r >> 3) : r);
+  }
   const int tx = t % g.ntx;
   t /= g.ntx;
   const int ty = t % g.nty;
@@ -297,7 +304,7 @@ int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const L
                          double *dst, const LayoutDev &lc, const double *cf, double w, const Box &box, hipStream_t s);
 
 constexpr int ZM_RY = 2, ZM_WY = 4, ZM_BLOCKS = 512, ZM_BLOCKS_COL = 1024, ZM_MINCHUNK = 16;   // half sweeps: 0.68 ms at 512 workgroups, 0.64 at 1024
-static thread_local int g_zm_blocks = -1, g_zm_minchunk = -1;    // examg_debug_zmarch (debug build): workgroup target, planes per chunk
+static thread_local int g_zm_blocks = -1, g_zm_minchunk = -1, g_zm_remap = -1;    // examg_debug_zmarch (debug build): workgroup target, planes per chunk, tile order
 
 // returns the number of waves of the grid (ZM_RESNORM: the number of partial sums written to dst)
 template <int MODE, int ORDER>
@@ -316,22 +323,30 @@ static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &
   g.ntx = (box.e0 - g.xo + 127) / 128;
   g.nty = (box.n1() + ZM_RY * ZM_WY - 1) / (ZM_RY * ZM_WY);
   const int xy = g.ntx * g.nty;
-  // Workgroup count = chunk length in z.  Up to 512^3 ~512 long-lived workgroups are best (1024 for the half sweeps); on larger blocks
-  // that makes every chunk a whole column and the front that sweeps memory as wide as the block -- from 1.5*10^8 points the chunks
-  // are 16 planes whatever the count (tools/sweep_big_others.py: Jacobi step 768^3 2.79 -> 2.22 ms, 1024^3 5.61 -> 4.89 ms = 0.66;
-  // half sweep 1024^3 5.58 -> 5.16).  The residual + norm mode writes one partial sum per wave into a fixed work buffer: 4096
-  // workgroups there (768^3 1.69 -> 1.53 ms).
-  int target = colour >= 0 ? ZM_BLOCKS_COL : ZM_BLOCKS;
+  // Workgroup count = chunk length in z, and the order of the tiles (tools/sweep_zmarch_order.py, sweep_big_others.py; all
+  // bit-identical).  Below 5*10^7 points: ~512 long-lived workgroups (1024 for the half sweeps), plain order.  From there: short
+  // chunks of 8 planes, as many workgroups as that takes, dealt to the XCDs in bands of y-adjacent tiles within every z layer
+  // (order 2 of kernels_twostage.hip: halo rows meet in one L2, all XCDs stay in the same planes) -- with ~512 workgroups every
+  // chunk of a large block is a whole column and the front that sweeps memory as wide as the block:
+  //   Jacobi step   384^3 0.299 -> 0.261 ms, 512^3 0.586 -> 0.580, 576^3 1.04 -> 0.90, 768^3 2.59 -> 2.10, 1024^3 5.86 -> 4.83 (0.665)
+  //   half sweep    384^3 0.335 -> 0.260,    512^3 0.645 -> 0.596, 576^3 1.06 -> 0.87, 768^3 2.74 -> 1.98, 1024^3 5.48 -> 4.70
+  // The residual + norm mode writes one partial sum per wave into a fixed work buffer and keeps few workgroups (4096 from 2*10^8
+  // points: 768^3 1.69 -> 1.53 ms).
+  int target = colour >= 0 ? ZM_BLOCKS_COL : ZM_BLOCKS, minchunk = ZM_MINCHUNK;
+  g.remap = 0;
   if (MODE == ZM_RESNORM) {
     if (box.count() >= 200000000LL) target = 4096;
-  } else if (box.count() >= 150000000LL) {     // 512^3 (1.3*10^8 points) is a tie: 0.625 / 0.630 ms; 576^3: 1.06 -> 0.97 ms
+  } else if (box.count() >= (even ? 150000000LL : 50000000LL)) {   // padded rows at 512^3: 0.563 ms with the long chunks, 0.585 with short ones
     target = 1 << 24;
+    minchunk = 8;
+    g.remap = 2;
   }
   if (g_zm_blocks > 0) target = g_zm_blocks;
+  if (g_zm_minchunk > 0) minchunk = g_zm_minchunk;
+  if (g_zm_remap >= 0) g.remap = g_zm_remap;
   int ntz = (target + xy - 1) / xy;
   if (ntz < 1) ntz = 1;
   int zc = (box.n2() + ntz - 1) / ntz;
-  const int minchunk = g_zm_minchunk > 0 ? g_zm_minchunk : ZM_MINCHUNK;
   if (zc < minchunk) zc = minchunk;
   if (zc > box.n2()) zc = box.n2();
   g.zc = zc;
@@ -358,9 +373,10 @@ using namespace examg;
 
 #ifdef EXAMG_DEBUG_HOOKS
 // Variant selection for the parity tests (debug build libexamg_dbg.so only; per host thread)
-extern "C" int examg_debug_zmarch(int blocks, int minchunk) {
+extern "C" int examg_debug_zmarch(int blocks, int minchunk, int remap) {
   g_zm_blocks = blocks;
   g_zm_minchunk = minchunk;
+  g_zm_remap = remap;
   return 0;
 }
 extern "C" int examg_debug_sf27(int unrolled) {

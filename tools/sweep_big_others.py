@@ -42,13 +42,13 @@ for n in [int(a) for a in sys.argv[1:]] or [1024, 768, 512]:
     for _ in range(30):
         ops.stencil_op(2, Ls, u, Fs, f, Ls, un, A, w, -1, b, e)
     for blocks, minchunk in ((-1, -1), (1024, 16), (2048, 16), (4096, 16), (8192, 16), (1 << 20, 16), (1 << 20, 32), (1 << 20, 64)):
-        L.examg_debug_zmarch(blocks, minchunk)
+        L.examg_debug_zmarch(blocks, minchunk, -1)
         tj = timed(lambda: ops.stencil_op(2, Ls, u, Fs, f, Ls, un, A, w, -1, b, e))
         th = timed(lambda: ops.stencil_op(2, Ls, u, Fs, f, Ls, u, A, w, 0, b, e))
         tn = timed(lambda: ops.residual_norm2(Ls, u, Fs, f, A, b, e, Ls, r))
         print("n=%d zmarch blocks=%8d minchunk=%3d  jacobi %.4f ms (frac %.3f)  half sweep %.4f  residual+norm %.4f (frac %.3f)"
               % (n, blocks, minchunk, tj, 24 * pts / tj / 1e6 / 8000, th, tn, 16 * pts / tn / 1e6 / 8000), flush=True)
-    L.examg_debug_zmarch(-1, -1)
+    L.examg_debug_zmarch(-1, -1, -1)
     for waves, minzc in ((24576, 8), (49152, 8), (98304, 8), (196608, 8), (1 << 22, 8), (1 << 22, 13), (1 << 22, 24)):
         L.examg_debug_residual_restrict(waves, minzc)
         t = timed(lambda: ops.residual_restrict(Ls, u, Fs, f, Ls, r, A, Cs, fc, 1.0, b, e, bc, ec))
