@@ -338,7 +338,7 @@ static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &
     if (box.count() >= 200000000LL) target = 4096;
   } else if (box.count() >= (even ? 150000000LL : 50000000LL)) {   // padded rows at 512^3: 0.563 ms with the long chunks, 0.585 with short ones
     target = 1 << 24;
-    minchunk = 8;
+    minchunk = box.count() >= 200000000LL ? 4 : 8;      // 4 .. 8 planes are within 2 % of each other; 768^3: 2.11 -> 2.02 ms with 4
     g.remap = 2;
   }
   if (g_zm_blocks > 0) target = g_zm_blocks;
