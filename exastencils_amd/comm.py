@@ -9,15 +9,21 @@ become valid with 6 neighbours only (comm_syncGhostData; ranges IR_PackInfoDupli
 IR_PackInfoGhost.scala:13-60); pack -> send / recv -> unpack (:194-219); MPI_Allreduce after reduction
 loops (parallelization/api/mpi/MPI_Reduction.scala:100-126).
 
-Transport, two forms behind one interface:
-  * "c": libexamg's own transport (include/examg.h: examg_exchange / examg_allreduce / examg_allgather,
-    exastencils_amd/csrc/examg_comm.hip) -- ncclSend / ncclRecv groups of RCCL between the axis neighbours (one process per
-    GPU; each pair of GPUs has its own xGMI link), pack / unpack kernels, all stream-ordered and capturable into a hipGraph.
-    This is the product path on GPUs and the one a generated C++ host shares; the 128-byte RCCL id of rank 0 travels through
-    torch.distributed (whatever backend the launcher initialised), which otherwise carries no data.
+Transport, three forms behind one interface:
+  * "peer" (default on GPUs): libexamg's peer-write transport (include/examg.h: examg_comm_create_peer; csrc/examg_peer.hip) --
+    every rank owns a region of uncached device memory that its neighbours map through HIP IPC (an xGMI peer mapping across the
+    GPUs of a node); the send kernel packs a box straight into the neighbour's receive slab and publishes a sequence number,
+    the receive kernel waits for it and unpacks; all-reduce and all-gather work the same way.  No communication library, no
+    host round trip, capturable into a hipGraph; also the only device-resident transport that runs several ranks on ONE GPU
+    (the 2- and 4-process tests of tests/test_gpu_peer.py).  torch.distributed, whatever backend the launcher initialised,
+    carries nothing but the 128-byte handles.
+  * "c": RCCL -- ncclSend / ncclRecv groups between the axis neighbours, pack / unpack kernels, stream-ordered
+    (csrc/examg_comm.hip); not for stream capture (RCCL point-to-point groups hang inside a capture on ROCm 7.2), one rank
+    per device only.  Selected with EXAMG_TRANSPORT=c.
   * "torch": torch.distributed point-to-point batches around `ops.pack/unpack` -- backend "gloo" with the CPU oracle ops in the
-    multi-process CPU tests, or "gloo" with device arrays staged through the host (several ranks rehearsing on ONE GPU, where
-    RCCL refuses two ranks on one device).
+    multi-process CPU tests (EXAMG_TRANSPORT=torch on GPUs: device arrays staged through the host under gloo).
+The choice is made collectively: if a library transport cannot be created on ANY rank, every rank raises (or, with
+EXAMG_TRANSPORT_FALLBACK=1, every rank switches to "torch" with a warning).
 """
 from __future__ import annotations
 
@@ -62,41 +68,159 @@ class Communicator:
                            and getattr(ops.device, "type", "cpu") != "cpu")
         self._bufs: Dict[Tuple, object] = {}
         self.stats = {"messages": 0, "bytes": 0}
-        # transport selection: the C transport whenever the kernel layer is libexamg on a GPU and messages need no host staging
+        # transport selection on GPUs: the library's own transports, chosen the same way on every rank
         on_gpu = hasattr(ops, "L") and hasattr(ops.L, "examg_exchange") and getattr(getattr(ops, "device", None), "type", "cpu") != "cpu"
         if transport == "auto":
             import os
 
-            forced = os.environ.get("EXAMG_TRANSPORT", "")       # "torch": keep every message on torch.distributed (diagnosis)
-            transport = forced if forced in ("c", "torch") else ("c" if (on_gpu and not self._stage) else "torch")
-        if transport == "c" and not on_gpu:
-            raise RuntimeError("the C transport needs the HIP kernel layer (HipOps)")
+            forced = os.environ.get("EXAMG_TRANSPORT", "")       # "peer" | "c" (RCCL) | "torch"
+            transport = forced if forced in ("peer", "c", "torch") else ("peer" if on_gpu else "torch")
+        if transport in ("c", "peer") and not on_gpu:
+            raise RuntimeError("the library transports need the HIP kernel layer (HipOps)")
+        if transport == "c" and self._stage:
+            raise RuntimeError("RCCL refuses several ranks on one device: use the peer-write transport (EXAMG_TRANSPORT=peer) or torch")
         self.transport = transport
+        if transport != "torch":
+            self._stage = False          # device buffers never pass through the host on the library transports
         self._c = None
         self._ws: Dict[Tuple, object] = {}
         self._nb = None
-        if transport == "c" and (self.dist is not None or any(domain.periodic)):
-            try:
+        if transport in ("c", "peer") and (self.dist is not None or any(domain.periodic)):
+            self._create_collectively()
+
+    # -- library transports (libexamg: peer writes through HIP IPC, or RCCL) ---------------------------------
+    def _host_tensor_device(self):
+        return self.ops.device if self.dist.get_backend(self.group) == "nccl" else "cpu"
+
+    def _create_collectively(self):
+        """Create the communicator; whether that worked is agreed on by ALL ranks (a rank that fell back alone would leave the
+        others blocked in a broadcast, or mix transports on the two ends of a message).  A failure raises on every rank unless
+        EXAMG_TRANSPORT_FALLBACK=1 allows torch.distributed point-to-point instead (never silently in a bench run)."""
+        import os
+
+        err = None
+        try:
+            if self.transport == "peer":
+                self._peer_create()
+            else:
                 self._c_create()
-            except Exception as ex:      # RCCL not loadable, id exchange failed: the torch.distributed path still works
-                import warnings
+        except Exception as ex:      # noqa: BLE001 -- the verdict is shared below, then raised or downgraded on every rank
+            err = ex
+        ok = 0.0 if err is not None else 1.0
+        if self.dist is not None:
+            t = self.ops.torch.tensor([ok], dtype=self.ops.torch.float64, device=self._host_tensor_device())
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+            ok = float(t.item())
+        if ok == 1.0:
+            return
+        if self._c is not None and not getattr(self, "_c_shared", False):
+            self.ops.L.examg_comm_destroy(self._c)
+        self._c = None
+        msg = "libexamg transport '%s' unavailable on at least one rank (this rank: %s)" % (self.transport, err if err is not None else "ok")
+        if os.environ.get("EXAMG_TRANSPORT_FALLBACK") == "1":
+            import warnings
 
-                warnings.warn("libexamg transport unavailable (%s); using torch.distributed point-to-point" % (ex,))
-                self._c, self.transport = None, "torch"
+            warnings.warn(msg + "; EXAMG_TRANSPORT_FALLBACK=1: using torch.distributed point-to-point")
+            self.transport = "torch"
+            self._stage = bool(self.dist is not None and self.dist.get_backend(self.group) == "gloo")
+            return
+        raise RuntimeError(msg + " -- set EXAMG_TRANSPORT=torch or EXAMG_TRANSPORT_FALLBACK=1 to run on torch.distributed point-to-point")
 
-    # -- C transport (libexamg / RCCL) -----------------------------------------------------------------
+    def _neighbors_struct(self):
+        from . import lib as _lib
+
+        dom = self.domain
+        nb = _lib.NeighborsC()
+        for d in range(3):
+            for s_, side in enumerate((-1, +1)):
+                r = dom.neighbor(d, side) if d < dom.nd else None
+                nb.rank[d][s_] = -1 if r is None else int(r)
+        return nb
+
+    def _peer_create(self):
+        """Peer-write transport (csrc/examg_peer.hip): every rank owns an uncached region that its neighbours map through HIP IPC;
+        torch.distributed (any backend) only carries the 128-byte handles."""
+        import ctypes as C
+
+        from . import lib as _lib
+
+        L, dom = self.ops.L, self.domain
+        self._nb = self._neighbors_struct()
+        key = (id(L), dom.world_size, dom.rank, "peer")
+        if self.dist is not None and self.group is None and key in _SHARED_C_COMMS:
+            self._c, self._c_shared = _SHARED_C_COMMS[key], True
+            return
+        self._c_shared = False
+        h = C.c_void_p()
+        _lib.check(L.examg_comm_create_peer(C.byref(h), dom.world_size, dom.rank), "examg_comm_create_peer")
+        self._c = h
+        if self.dist is not None and self.group is None:
+            _SHARED_C_COMMS[key] = h
+            self._c_shared = True
+
+    def _peer_ensure(self, slab_bytes: int = 0, gather_bytes: int = 0):
+        """Make the slabs of the peer-write communicator large enough for a message of slab_bytes / a gather piece of
+        gather_bytes.  Growing is collective (all blocks have the same layouts, so all ranks get here with the same sizes at
+        the same call): synchronise, barrier, re-allocate, all-gather the handles, map."""
+        import ctypes as C
+
+        from . import lib as _lib
+
+        L = self.ops.L
+        have_s, have_g = int(L.examg_comm_peer_slab_bytes(self._c)), int(L.examg_comm_peer_gather_bytes(self._c))
+        if have_s >= max(slab_bytes, 1) and have_g >= gather_bytes:
+            return
+        torch = self.ops.torch
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the peer-write communicator must grow (slab %d -> %d bytes) during a stream capture: run the cycle once before capturing"
+                               % (have_s, slab_bytes))
+        new_s, new_g = max(have_s, slab_bytes, 4096), max(have_g, gather_bytes)
+        self.ops.synchronize()
+        if self.dist is not None:
+            self.dist.barrier(group=self.group)
+        hbuf = (C.c_ubyte * _lib.PEER_HANDLE_BYTES)()
+        _lib.check(L.examg_comm_peer_alloc(self._c, new_s, new_g, hbuf), "examg_comm_peer_alloc")
+        n = self.domain.world_size
+        if self.dist is not None:
+            dev = self._host_tensor_device()
+            mine = torch.tensor(list(bytes(hbuf)), dtype=torch.uint8, device=dev)
+            outs = [torch.empty_like(mine) for _ in range(n)]
+            self.dist.all_gather(outs, mine, group=self.group)
+            allb = b"".join(bytes(o.cpu().tolist()) for o in outs)
+        else:
+            allb = bytes(hbuf)
+        allbuf = (C.c_ubyte * (n * _lib.PEER_HANDLE_BYTES)).from_buffer_copy(allb)
+        _lib.check(L.examg_comm_peer_connect(self._c, allbuf), "examg_comm_peer_connect")
+        if self.dist is not None:
+            self.dist.barrier(group=self.group)
+
+    @staticmethod
+    def _max_face_bytes(lay, nd: int) -> int:
+        """Largest halo message of a field of this layout: one ghost / duplicate slab with tangential extent GLB..GRE."""
+        best = 0
+        for d in range(nd):
+            n = max(lay.ghost[d], lay.dup[d], 1)
+            for t in range(nd):
+                if t != d:
+                    n *= lay.idx("GRE", t) - lay.idx("GLB", t)
+            best = max(best, n)
+        return 8 * best
+
+    def check(self):
+        """Raise if a wait of the peer-write transport has given up (lost neighbour, mismatched exchange sequences)."""
+        if self._c is not None and self.transport == "peer":
+            from . import lib as _lib
+
+            _lib.check(self.ops.L.examg_comm_status(self._c, self.ops._stream()), "examg_comm_status")
+
+    # -- RCCL transport ----------------------------------------------------------------------------------------
     def _c_create(self):
         import ctypes as C
 
         from . import lib as _lib
 
         L, dom = self.ops.L, self.domain
-        nb = _lib.NeighborsC()
-        for d in range(3):
-            for s_, side in enumerate((-1, +1)):
-                r = dom.neighbor(d, side) if d < dom.nd else None
-                nb.rank[d][s_] = -1 if r is None else int(r)
-        self._nb = nb
+        self._nb = self._neighbors_struct()
         key = (id(L), dom.world_size, dom.rank)
         if self.dist is not None and self.group is None and key in _SHARED_C_COMMS:
             self._c, self._c_shared = _SHARED_C_COMMS[key], True
@@ -105,12 +229,15 @@ class Communicator:
         idbuf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
         if self.dist is not None:
             torch = self.ops.torch
+            status = 1
             if dom.rank == 0:
-                _lib.check(L.examg_comm_unique_id(idbuf), "examg_comm_unique_id")
-            dev = self.ops.device if self.dist.get_backend(self.group) == "nccl" else "cpu"
-            t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=dev)
+                status = 1 if L.examg_comm_unique_id(idbuf) == 0 else 0       # a failure travels with the id: nobody blocks
+            t = torch.tensor([status] + list(bytes(idbuf)), dtype=torch.uint8, device=self._host_tensor_device())
             self.dist.broadcast(t, 0, group=self.group)
-            idbuf = (C.c_ubyte * _lib.COMM_ID_BYTES)(*t.cpu().tolist())
+            got = t.cpu().tolist()
+            if got[0] != 1:
+                raise RuntimeError("rank 0 could not obtain an RCCL id: %s" % (L.examg_last_error().decode() if dom.rank == 0 else "see rank 0"))
+            idbuf = (C.c_ubyte * _lib.COMM_ID_BYTES)(*got[1:])
             idp = C.cast(idbuf, C.c_void_p)
         else:
             idp = None
@@ -131,18 +258,28 @@ class Communicator:
             self.ops.L.examg_comm_destroy(self._c)
         self._c = None
 
+    def _workspace(self, lay_c, layout):
+        """(pointer, bytes) of the caller-owned pack scratch of the RCCL transport; the peer-write transport owns its slabs."""
+        import ctypes as C
+
+        if self.transport == "peer":
+            self._peer_ensure(self._max_face_bytes(layout, self.domain.nd))
+            return None, 0
+        key = (layout,)
+        ws = self._ws.get(key)
+        nbytes = int(self.ops.L.examg_exchange_workspace_bytes(C.byref(lay_c)))
+        if ws is None:
+            ws = self._ws[key] = self.ops.new_array(max(1, nbytes // 8))
+        return self.ops.ptr(ws), nbytes
+
     def _c_exchange(self, f: Field, x, what: int):
         import ctypes as C
 
         from . import lib as _lib
 
         L = self.ops.L
-        key = (f.layout,)
-        ws = self._ws.get(key)
-        nbytes = int(L.examg_exchange_workspace_bytes(C.byref(f.lc)))
-        if ws is None:
-            ws = self._ws[key] = self.ops.new_array(max(1, nbytes // 8))
-        _lib.check(L.examg_exchange(self._c, C.byref(f.lc), self.ops.ptr(x), C.byref(self._nb), int(what), self.ops.ptr(ws), nbytes,
+        wsp, nbytes = self._workspace(f.lc, f.layout)
+        _lib.check(L.examg_exchange(self._c, C.byref(f.lc), self.ops.ptr(x), C.byref(self._nb), int(what), wsp, nbytes,
                                     self.ops._stream()), "examg_exchange")
 
     # -- buffers -----------------------------------------------------------------------------------
@@ -293,22 +430,64 @@ class Communicator:
         from . import lib as _lib
 
         ops, L = self.ops, self.ops.L
-        key = (S.layout,)
-        ws = self._ws.get(key)
-        nbytes = int(L.examg_exchange_workspace_bytes(C.byref(S.lc)))
-        if ws is None:
-            ws = self._ws[key] = ops.new_array(max(1, nbytes // 8))
+        wsp, nbytes = self._workspace(S.lc, S.layout)
         flags = _lib.EXCH_CONCURRENT_AXES if (self.concurrent_ghost_axes and axis_only) else 0
         sc = A.c_struct(ops.ptr)
         if kind == "jacobi2":
             rc = L.examg_jacobi2_blocks(self._c, C.byref(self._nb), C.byref(S.lc), ops.ptr(u_in), ops.ptr(u_out), ops.ptr(tmp), C.byref(F.lc),
-                                        ops.ptr(F.data()), C.byref(sc), float(w), _lib.ivec(begin), _lib.ivec(end), flags, ops.ptr(ws), nbytes,
+                                        ops.ptr(F.data()), C.byref(sc), float(w), _lib.ivec(begin), _lib.ivec(end), flags, wsp, nbytes,
                                         1 if overlap else 0, ops._stream())
         else:
             rc = L.examg_rbgs_sweep_blocks(self._c, C.byref(self._nb), C.byref(S.lc), ops.ptr(u_in), ops.ptr(u_out), ops.ptr(tmp), C.byref(F.lc),
                                            ops.ptr(F.data()), C.byref(sc), float(w), int(first), _lib.ivec(begin), _lib.ivec(end), flags,
-                                           ops.ptr(ws), nbytes, 1 if overlap else 0, ops._stream())
+                                           wsp, nbytes, 1 if overlap else 0, ops._stream())
         _lib.check(rc, "examg_%s_blocks" % ("jacobi2" if kind == "jacobi2" else "rbgs_sweep"))
+        return True
+
+    def _dup_flag(self, lay) -> int:
+        from .lib import EXCH_DUP
+
+        return EXCH_DUP if (lay.communicates_dup and max(lay.dup) > 0 and not self.consistent_duplicates) else 0
+
+    def c_residual_restrict(self, S: Field, F: Field, R: Field, A, Fc: Field, scale: float, fb, fe, cb, ce, axis_only: bool, overlap: bool):
+        """`communicate Solution; Residual = RHS - A * Solution; communicate Residual; RHS@coarser = scale * R * Residual` on a block
+        with neighbours as ONE library call (examg_residual_restrict_blocks).  Only with a library transport; True if the call was made."""
+        if self._c is None or not (S.layout.communicates_ghost and max(S.layout.ghost) > 0 and R.layout.communicates_ghost and max(R.layout.ghost) > 0):
+            return False
+        import ctypes as C
+
+        from . import lib as _lib
+
+        ops, L = self.ops, self.ops.L
+        wsp, nbytes = self._workspace(S.lc, S.layout)
+        if self.transport != "peer":            # RCCL scratch: one array that fits both layouts
+            wsp2, nbytes2 = self._workspace(R.lc, R.layout)
+            if nbytes2 > nbytes:
+                wsp, nbytes = wsp2, nbytes2
+        else:
+            self._peer_ensure(self._max_face_bytes(R.layout, self.domain.nd))
+        flags = self._dup_flag(S.layout) | (_lib.EXCH_CONCURRENT_AXES if (self.concurrent_ghost_axes and axis_only) else 0)
+        sc = A.c_struct(ops.ptr)
+        rc = L.examg_residual_restrict_blocks(self._c, C.byref(self._nb), C.byref(S.lc), ops.ptr(S.data()), C.byref(F.lc), ops.ptr(F.data()),
+                                              C.byref(R.lc), ops.ptr(R.data()), C.byref(sc), C.byref(Fc.lc), ops.ptr(Fc.data()), float(scale),
+                                              _lib.ivec(fb), _lib.ivec(fe), _lib.ivec(cb), _lib.ivec(ce), flags, wsp, nbytes,
+                                              1 if overlap else 0, ops._stream())
+        _lib.check(rc, "examg_residual_restrict_blocks")
+        return True
+
+    def c_prolong_add(self, Sc: Field, S: Field, b, e, overlap: bool):
+        """`communicate Solution@coarser; Solution += P * Solution@coarser` as ONE library call (examg_prolong_add_blocks)."""
+        if self._c is None or not (Sc.layout.communicates_ghost and max(Sc.layout.ghost) > 0):
+            return False
+        import ctypes as C
+
+        from . import lib as _lib
+
+        ops, L = self.ops, self.ops.L
+        wsp, nbytes = self._workspace(Sc.lc, Sc.layout)
+        rc = L.examg_prolong_add_blocks(self._c, C.byref(self._nb), C.byref(Sc.lc), ops.ptr(Sc.data()), C.byref(S.lc), ops.ptr(S.data()),
+                                        _lib.ivec(b), _lib.ivec(e), self._dup_flag(Sc.layout), wsp, nbytes, 1 if overlap else 0, ops._stream())
+        _lib.check(rc, "examg_prolong_add_blocks")
         return True
 
     # -- reductions across blocks -------------------------------------------------------------------
@@ -338,6 +517,8 @@ class Communicator:
             from .lib import check
 
             n = int(t.numel())
+            if self.transport == "peer":
+                self._peer_ensure(0, 8 * n)
             base = outs[0]
             for r, o in enumerate(outs):
                 if o.data_ptr() != base.data_ptr() + 8 * n * r:

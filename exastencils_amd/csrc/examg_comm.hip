@@ -1,7 +1,9 @@
 // Block-to-block transport of libexamg over RCCL: `communicate <field>` (exch<Field>_<level>(slot)) and the scalar
 // all-reduce that follows a reduction loop, as C entry points a generated C++ host (or the Python mirror, through ctypes)
 // calls -- one process per GPU, ncclSend / ncclRecv groups between the axis neighbours (each GPU pair has its own xGMI link),
-// everything stream-ordered: no host synchronisation, capturable into a hipGraph.
+// everything stream-ordered: no host synchronisation.  (RCCL point-to-point groups hang inside a hipGraph capture on ROCm 7.2;
+// the second transport, examg_peer.hip -- peer writes through HIP IPC -- is the capturable one.  The entry points below serve
+// both: a communicator made by examg_comm_create_peer routes its phases there.)
 //
 // Replaces, in the generated program: IR_CommunicateFunction.compileBody
 // (Compiler/src/exastencils/communication/ir/IR_CommunicateFunction.scala:194-219,412-471: duplicate layers first -- per
@@ -15,10 +17,9 @@
 // RCCL is bound at run time (dlopen of librccl.so.1, or $EXAMG_RCCL_LIB): a single-GPU host never needs it, and inside a
 // PyTorch process the copy PyTorch has already loaded is the one that is used (same soname).
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <stdlib.h>
 
-#include "examg_common.h"
+#include "examg_comm_internal.h"
 
 using namespace examg;
 
@@ -80,14 +81,6 @@ int check_nccl(ncclResult_t r, const char *what) {
 
 }  // namespace
 
-struct examg_comm {
-  ncclComm_t nccl = nullptr;   // null for a one-rank communicator created without RCCL
-  int rank = 0, size = 1;
-  bool self_via_rccl = false;  // periodic self-exchange through ncclSend/ncclRecv to the own rank (one-GPU test of the transport)
-  hipStream_t side = nullptr;  // second stream and fork / join events of the overlapped smoother passes (created on first use)
-  hipEvent_t fork = nullptr, join = nullptr;
-};
-
 static_assert(sizeof(ncclUniqueId) == EXAMG_COMM_ID_BYTES, "EXAMG_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
 
 extern "C" int examg_comm_unique_id(void *id) {
@@ -122,6 +115,7 @@ extern "C" int examg_comm_destroy(examg_comm_t *comm) {
   if (!comm) return 0;
   int rc = 0;
   if (comm->nccl) rc = check_nccl(g_rccl.CommDestroy(comm->nccl), "ncclCommDestroy");
+  if (comm->peer) peer_destroy(comm);
   if (comm->fork) (void)hipEventDestroy(comm->fork);
   if (comm->join) (void)hipEventDestroy(comm->join);
   if (comm->side) (void)hipStreamDestroy(comm->side);
@@ -132,109 +126,30 @@ extern "C" int examg_comm_destroy(examg_comm_t *comm) {
 extern "C" int examg_comm_rank(const examg_comm_t *comm) { return comm ? comm->rank : -1; }
 extern "C" int examg_comm_size(const examg_comm_t *comm) { return comm ? comm->size : -1; }
 
-// ---- index ranges (iterator coordinates: 0 = lower duplicate node) -----------------------------------------------------------
 namespace {
-
-struct Marks {
-  int GLB, DLB, DLE, IB, IE, DRB, DRE, GRB, GRE;
-};
-Marks marks(const examg_layout_t *l, int d) {
-  Marks m;
-  m.GLB = -l->ghost_l[d];
-  m.DLB = 0;
-  m.DLE = l->dup_l[d];
-  m.IB = m.DLE;
-  m.IE = m.IB + l->inner[d];
-  m.DRB = m.IE;
-  m.DRE = m.DRB + l->dup_r[d];
-  m.GRB = m.DRE;
-  m.GRE = m.GRB + l->ghost_r[d];
-  return m;
-}
-
-struct Range {
-  int32_t b[3], e[3];
-  long long count() const {
-    long long n = 1;
-    for (int d = 0; d < 3; ++d) n *= (e[d] > b[d] ? e[d] - b[d] : 0);
-    return n;
-  }
-};
-
-// duplicate layers along axis d (IR_PackInfoDuplicate.scala:15-39): send DRB..DRE, receive into DLB..DLE, tangentially DLB..DRE
-void dup_ranges(const examg_layout_t *l, int d, Range &snd, Range &rcv) {
-  for (int t = 0; t < 3; ++t) {
-    snd.b[t] = rcv.b[t] = 0;
-    snd.e[t] = rcv.e[t] = 1;
-  }
-  for (int t = 0; t < l->nd; ++t) {
-    const Marks m = marks(l, t);
-    if (t == d) {
-      snd.b[t] = m.DRB; snd.e[t] = m.DRE;
-      rcv.b[t] = m.DLB; rcv.e[t] = m.DLE;
-    } else {
-      snd.b[t] = rcv.b[t] = m.DLB;
-      snd.e[t] = rcv.e[t] = m.DRE;
-    }
-  }
-}
-
-// ghost layers along axis d towards `side` (IR_PackInfoGhost.scala:13-60): send the first / last inner planes, receive into the
-// ghost planes of that side; tangentially GLB..GRE (ghosts of earlier axes travel along)
-void ghost_ranges(const examg_layout_t *l, int d, int side, Range &snd, Range &rcv) {
-  for (int t = 0; t < 3; ++t) {
-    snd.b[t] = rcv.b[t] = 0;
-    snd.e[t] = rcv.e[t] = 1;
-  }
-  for (int t = 0; t < l->nd; ++t) {
-    const Marks m = marks(l, t);
-    if (t == d) {
-      // what goes towards - fills the neighbour's + ghost layers (all blocks share the layout) and vice versa
-      if (side < 0) {
-        snd.b[t] = m.IB; snd.e[t] = m.IB + l->ghost_r[t];
-        rcv.b[t] = m.DLB - l->ghost_l[t]; rcv.e[t] = m.DLB;
-      } else {
-        snd.b[t] = m.IE - l->ghost_l[t]; snd.e[t] = m.IE;
-        rcv.b[t] = m.GRB; rcv.e[t] = m.GRB + l->ghost_r[t];
-      }
-    } else {
-      snd.b[t] = rcv.b[t] = m.GLB;
-      snd.e[t] = rcv.e[t] = m.GRE;
-    }
-  }
-}
-
-long long face_count(const examg_layout_t *l, int d) {   // points of the largest message of axis d (one ghost or duplicate slab)
-  long long n = 1;
-  for (int t = 0; t < l->nd; ++t) {
-    const Marks m = marks(l, t);
-    if (t == d) {
-      int w = l->ghost_l[t] > l->ghost_r[t] ? l->ghost_l[t] : l->ghost_r[t];
-      if (l->dup_r[t] > w) w = l->dup_r[t];
-      n *= w;
-    } else {
-      n *= (m.GRE - m.GLB);
-    }
-  }
-  return n;
-}
-
-// workspace: per axis d and side s (0 = minus, 1 = plus) one send and one receive slab
-long long slot_offset(const examg_layout_t *l, int d, int s, int recv) {
-  long long off = 0;
-  for (int t = 0; t < d; ++t) off += 4 * face_count(l, t);
-  return off + (2 * s + recv) * face_count(l, d);
-}
 
 struct Msg {
   int peer;
   Range box;
   double *buf;
+  int d, side;   // axis and side (0 = minus, 1 = plus) of this block the message leaves through / arrives at
 };
 
 // one phase: pack -> group(recv.., send..) -> unpack  (IR_CommunicateFunction.scala:194-219)
 int phase(examg_comm_t *c, const examg_layout_t *l, double *x, Msg *sends, int ns, Msg *recvs, int nr, hipStream_t s) {
   if (ns == 0 && nr == 0) return 0;
+  if (c->peer) {   // peer-write transport: the send kernel packs straight into the neighbour's receive slab
+    PeerMsg ps[6], pr[6];
+    for (int i = 0; i < ns; ++i) {
+      ps[i].peer = sends[i].peer; ps[i].d = sends[i].d; ps[i].side = sends[i].side;
+      for (int t = 0; t < 3; ++t) { ps[i].b[t] = sends[i].box.b[t]; ps[i].e[t] = sends[i].box.e[t]; }
+    }
+    for (int i = 0; i < nr; ++i) {
+      pr[i].peer = recvs[i].peer; pr[i].d = recvs[i].d; pr[i].side = recvs[i].side;
+      for (int t = 0; t < 3; ++t) { pr[i].b[t] = recvs[i].box.b[t]; pr[i].e[t] = recvs[i].box.e[t]; }
+    }
+    return peer_phase(c, l, x, ps, ns, pr, nr, s);
+  }
   for (int i = 0; i < ns; ++i)
     if (examg_pack(l, x, sends[i].buf, sends[i].box.b, sends[i].box.e, s)) return 1;
   bool any_remote = false;
@@ -248,11 +163,17 @@ int phase(examg_comm_t *c, const examg_layout_t *l, double *x, Msg *sends, int n
   // the message sent towards `side` pairs with the receive from `-side`; without RCCL the receive slab is the send slab
   for (int i = 0; i < nr; ++i) {
     if (recvs[i].peer == c->rank && !c->self_via_rccl) continue;
-    if (check_nccl(g_rccl.Recv(recvs[i].buf, (size_t)recvs[i].box.count(), ncclDouble, recvs[i].peer, c->nccl, s), "ncclRecv")) return 1;
+    if (check_nccl(g_rccl.Recv(recvs[i].buf, (size_t)recvs[i].box.count(), ncclDouble, recvs[i].peer, c->nccl, s), "ncclRecv")) {
+      (void)g_rccl.GroupEnd();
+      return 1;
+    }
   }
   for (int i = 0; i < ns; ++i) {
     if (sends[i].peer == c->rank && !c->self_via_rccl) continue;
-    if (check_nccl(g_rccl.Send(sends[i].buf, (size_t)sends[i].box.count(), ncclDouble, sends[i].peer, c->nccl, s), "ncclSend")) return 1;
+    if (check_nccl(g_rccl.Send(sends[i].buf, (size_t)sends[i].box.count(), ncclDouble, sends[i].peer, c->nccl, s), "ncclSend")) {
+      (void)g_rccl.GroupEnd();
+      return 1;
+    }
   }
   if (any_remote && check_nccl(g_rccl.GroupEnd(), "ncclGroupEnd")) return 1;
   for (int i = 0; i < nr; ++i) {
@@ -284,12 +205,12 @@ extern "C" int examg_exchange(examg_comm_t *comm, const examg_layout_t *l, doubl
   bool any = false;
   for (int d = 0; d < l->nd; ++d) any = any || nb->rank[d][0] >= 0 || nb->rank[d][1] >= 0;
   if (!any) return 0;   // no neighbours: the generated exch function is empty
-  if (!workspace || workspace_bytes < examg_exchange_workspace_bytes(l)) { set_error("examg_exchange: workspace too small"); return 1; }
+  if (!comm->peer && (!workspace || workspace_bytes < examg_exchange_workspace_bytes(l))) { set_error("examg_exchange: workspace too small"); return 1; }
   for (int d = 0; d < l->nd; ++d)
     for (int s = 0; s < 2; ++s)
       if (nb->rank[d][s] >= comm->size) { set_error("examg_exchange: neighbour rank %d outside the communicator", nb->rank[d][s]); return 1; }
   hipStream_t s = (hipStream_t)stream;
-  double *ws = (double *)workspace;
+  double *ws = comm->peer ? nullptr : (double *)workspace;   // the peer-write transport owns its slabs
   const int nd = l->nd;
   if (what & EXAMG_EXCH_DUP) {
     for (int d = 0; d < nd; ++d) {
@@ -298,8 +219,8 @@ extern "C" int examg_exchange(examg_comm_t *comm, const examg_layout_t *l, doubl
       int ns = 0, nr = 0;
       Range sb, rb;
       dup_ranges(l, d, sb, rb);
-      if (nb->rank[d][1] >= 0) snd[ns++] = Msg{nb->rank[d][1], sb, ws + slot_offset(l, d, 1, 0)};
-      if (nb->rank[d][0] >= 0) rcv[nr++] = Msg{nb->rank[d][0], rb, ws + slot_offset(l, d, 0, 1)};
+      if (nb->rank[d][1] >= 0) snd[ns++] = Msg{nb->rank[d][1], sb, ws ? ws + slot_offset(l, d, 1, 0) : nullptr, d, 1};
+      if (nb->rank[d][0] >= 0) rcv[nr++] = Msg{nb->rank[d][0], rb, ws ? ws + slot_offset(l, d, 0, 1) : nullptr, d, 0};
       if (phase(comm, l, x, snd, ns, rcv, nr, s)) return 1;
     }
   }
@@ -315,13 +236,13 @@ extern "C" int examg_exchange(examg_comm_t *comm, const examg_layout_t *l, doubl
         if (nb->rank[d][side] < 0) continue;
         Range sb, rb;
         ghost_ranges(l, d, side ? +1 : -1, sb, rb);
-        snd[ns++] = Msg{nb->rank[d][side], sb, ws + slot_offset(l, d, side, 0)};
+        snd[ns++] = Msg{nb->rank[d][side], sb, ws ? ws + slot_offset(l, d, side, 0) : nullptr, d, side};
       }
       for (int side = 1; side >= 0; --side) {
         if (nb->rank[d][side] < 0) continue;
         Range sb, rb;
         ghost_ranges(l, d, side ? +1 : -1, sb, rb);
-        rcv[nr++] = Msg{nb->rank[d][side], rb, ws + slot_offset(l, d, side, 1)};
+        rcv[nr++] = Msg{nb->rank[d][side], rb, ws ? ws + slot_offset(l, d, side, 1) : nullptr, d, side};
       }
       if (!(what & EXAMG_EXCH_CONCURRENT_AXES)) {
         if (phase(comm, l, x, snd + d_ns, ns - d_ns, rcv + d_nr, nr - d_nr, s)) return 1;
@@ -334,7 +255,7 @@ extern "C" int examg_exchange(examg_comm_t *comm, const examg_layout_t *l, doubl
       // phase() pairs self-messages by position within an axis, so the axes go through it one at a time when a block is its
       // own neighbour, and as ONE group otherwise
       bool self = false;
-      for (int i = 0; i < ns; ++i) self = self || snd[i].peer == comm->rank;
+      for (int i = 0; i < ns; ++i) self = self || (snd[i].peer == comm->rank && !comm->peer);
       if (!self) {
         if (phase(comm, l, x, snd, ns, rcv, nr, s)) return 1;
       } else {
@@ -357,6 +278,7 @@ extern "C" int examg_allreduce(examg_comm_t *comm, double *x, int n, int op, exa
   if (!comm || !x || n < 0) { set_error("examg_allreduce: bad argument"); return 1; }
   if (op < 0 || op > 2) { set_error("examg_allreduce: op must be 0 (sum), 1 (max) or 2 (min)"); return 1; }
   if (comm->size == 1 && !comm->self_via_rccl) return 0;
+  if (comm->peer) return peer_allreduce(comm, x, n, op, (hipStream_t)stream);
   if (!comm->nccl) { set_error("examg_allreduce: communicator has no RCCL handle"); return 1; }
   const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
   return check_nccl(g_rccl.AllReduce(x, x, (size_t)n, ncclDouble, rop, comm->nccl, (hipStream_t)stream), "ncclAllReduce");
@@ -368,6 +290,7 @@ extern "C" int examg_allgather(examg_comm_t *comm, const double *send, double *r
     if (send != recv) return check_hip(hipMemcpyAsync(recv, send, (size_t)n * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream), "examg_allgather");
     return 0;
   }
+  if (comm->peer) return peer_allgather(comm, send, recv, (long long)n, (hipStream_t)stream);
   if (!comm->nccl) { set_error("examg_allgather: communicator has no RCCL handle"); return 1; }
   return check_nccl(g_rccl.AllGather(send, recv, (size_t)n, ncclDouble, comm->nccl, (hipStream_t)stream), "ncclAllGather");
 }
@@ -532,4 +455,112 @@ extern "C" int examg_rbgs_sweep_blocks(examg_comm_t *comm, const examg_neighbors
   if (first != 0 && first != 1) { set_error("examg_rbgs_sweep_blocks: first colour must be 0 or 1"); return 1; }
   return pass_blocks<true>("examg_rbgs_sweep_blocks", comm, nb, lu, u_in, u_out, tmp, lf, rhs, st, w, first, begin, end, exchange_flags, workspace,
                            workspace_bytes, overlap, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Transfer operators on a block WITH neighbours, one C call each (the reference's core / boundary split,
+// baseExt/ir/IR_LoopOverPointsInOneFragment.scala:143-222, around the two `communicate` statements of mgCycle,
+// Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:215-237).
+//
+// examg_residual_restrict_blocks:  communicate Solution; Residual = RHS - A * Solution; communicate Residual;
+//                                  RHS@coarser = scale * Restriction * Residual
+//   launch stream   the one-pass residual + restriction kernel on the coarse box shrunk by one point at interior faces: its fine
+//                   footprint ends on the duplicate planes, so it reads no ghost value of Solution and never stores a residual
+//   side stream     1. exchange the ghost layers of Solution
+//                   2. residual on the two fine planes next to every interior face, into `res`        (thin launches)
+//                   3. exchange `res` (duplicate + ghost layers, axis by axis: the restriction reads edge / corner ghosts)
+//                   4. restriction of the one coarse plane on every interior face, from `res`          (thin launches, disjoint)
+//   The duplicate part of `communicate Solution` (EXAMG_EXCH_DUP in exchange_flags; the loops read those planes) runs first, in
+//   sequence.  `res` afterwards holds the residual on the two-plane shell only -- nothing reads the rest (mgCycle overwrites it).
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int examg_residual_restrict_blocks(examg_comm_t *comm, const examg_neighbors_t *nb, const examg_layout_t *lu, double *u,
+                                              const examg_layout_t *lf, const double *rhs, const examg_layout_t *lr, double *res,
+                                              const examg_stencil_t *st, const examg_layout_t *lc, double *fc, double scale,
+                                              const int32_t *fbegin, const int32_t *fend, const int32_t *cbegin, const int32_t *cend,
+                                              int exchange_flags, void *workspace, size_t workspace_bytes, int overlap, examg_stream_t stream) {
+  const char *who = "examg_residual_restrict_blocks";
+  if (!comm || !nb || !lu || !u || !lf || !rhs || !lr || !res || !st || !lc || !fc || !fbegin || !fend || !cbegin || !cend) { set_error("%s: null argument", who); return 1; }
+  hipStream_t main = (hipStream_t)stream;
+  const Faces f = interior_faces(lu, nb);
+  if (f.n == 0) return examg_residual_restrict(lu, u, lf, rhs, lr, res, st, lc, fc, scale, fbegin, fend, cbegin, cend, stream);
+  const int ghost_what = EXAMG_EXCH_GHOST | (exchange_flags & EXAMG_EXCH_CONCURRENT_AXES);
+  if ((exchange_flags & EXAMG_EXCH_DUP) && examg_exchange(comm, lu, u, nb, EXAMG_EXCH_DUP, workspace, workspace_bytes, main)) return 1;
+  int32_t cb1[3], ce1[3];
+  shrunk(f, cbegin, cend, 1, cb1, ce1);
+  bool has_interior = true;
+  for (int d = 0; d < lu->nd; ++d) has_interior = has_interior && ce1[d] > cb1[d];
+
+  auto shell = [&](hipStream_t s) -> int {
+    if (examg_exchange(comm, lu, u, nb, ghost_what, workspace, workspace_bytes, s)) return 1;
+    int32_t sb[3], se[3];
+    for (int i = 0; i < f.n; ++i) {
+      slab(fbegin, fend, f.d[i], f.side[i], 2, sb, se);
+      if (examg_residual(lu, u, lf, rhs, lr, res, st, sb, se, s)) return 1;
+    }
+    if (examg_exchange(comm, lr, res, nb, EXAMG_EXCH_GHOST | (exchange_flags & EXAMG_EXCH_DUP), workspace, workspace_bytes, s)) return 1;
+    int32_t lo[3], hi[3];
+    for (int t = 0; t < 3; ++t) { lo[t] = cbegin[t]; hi[t] = cend[t]; }
+    for (int d = 0; d < lu->nd; ++d) {           // disjoint coarse slabs: later axes exclude the planes earlier ones have done
+      for (int sd = 0; sd < 2; ++sd) {
+        if (nb->rank[d][sd] < 0) continue;
+        for (int t = 0; t < 3; ++t) { sb[t] = lo[t]; se[t] = hi[t]; }
+        if (sd == 0) se[d] = cbegin[d] + 1;
+        else sb[d] = cend[d] - 1;
+        if (se[d] <= sb[d]) continue;
+        if (examg_restrict(lr, res, lc, fc, scale, sb, se, s)) return 1;
+      }
+      lo[d] = cb1[d];
+      hi[d] = ce1[d];
+    }
+    return 0;
+  };
+  auto interior = [&](hipStream_t s) -> int {
+    if (!has_interior) return 0;
+    return examg_residual_restrict(lu, u, lf, rhs, lr, res, st, lc, fc, scale, fbegin, fend, cb1, ce1, s);
+  };
+  // the interior pass may fall back to residual + restriction THROUGH `res` (other stencils, short rows): then it must not run
+  // beside the shell work, which writes `res` too -- ask the same question the entry point asks
+  const bool one_pass = has_interior && examg_residual_restrict_one_pass(lu, lf, st, lc, fbegin, fend, cb1, ce1) == 1;
+  if (!(overlap && one_pass)) {
+    // in sequence: the whole residual first (the fallback stores it), then the exchange of `res`, then one restriction
+    if (examg_exchange(comm, lu, u, nb, ghost_what, workspace, workspace_bytes, main)) return 1;
+    if (examg_residual(lu, u, lf, rhs, lr, res, st, fbegin, fend, main)) return 1;
+    if (examg_exchange(comm, lr, res, nb, EXAMG_EXCH_GHOST | (exchange_flags & EXAMG_EXCH_DUP), workspace, workspace_bytes, main)) return 1;
+    return examg_restrict(lr, res, lc, fc, scale, cbegin, cend, main);
+  }
+  Overlap *o = overlap_of(comm);
+  if (!o) return 1;
+  if (check_hip(hipEventRecord(o->fork, main), who)) return 1;
+  if (check_hip(hipStreamWaitEvent(o->side, o->fork, 0), who)) return 1;
+  if (shell(o->side)) return 1;
+  if (interior(main)) return 1;
+  if (check_hip(hipEventRecord(o->join, o->side), who)) return 1;
+  return check_hip(hipStreamWaitEvent(main, o->join, 0), who);
+}
+
+// examg_prolong_add_blocks:  communicate Solution@coarser; Solution += Prolongation@coarser * Solution@coarser
+//   The interpolation of node values reads duplicate and inner coarse points only (fine node i lies between coarse nodes i / 2
+//   and (i + 1) / 2, both inside the block): the duplicate part of the exchange (EXAMG_EXCH_DUP in exchange_flags) runs first,
+//   the ghost part beside the kernel on the side stream.
+extern "C" int examg_prolong_add_blocks(examg_comm_t *comm, const examg_neighbors_t *nb, const examg_layout_t *lc, double *uc,
+                                        const examg_layout_t *lfine, double *uf, const int32_t *begin, const int32_t *end, int exchange_flags,
+                                        void *workspace, size_t workspace_bytes, int overlap, examg_stream_t stream) {
+  const char *who = "examg_prolong_add_blocks";
+  if (!comm || !nb || !lc || !uc || !lfine || !uf || !begin || !end) { set_error("%s: null argument", who); return 1; }
+  hipStream_t main = (hipStream_t)stream;
+  const Faces f = interior_faces(lc, nb);
+  if (f.n == 0) return examg_prolong_add(lc, uc, lfine, uf, begin, end, stream);
+  if ((exchange_flags & EXAMG_EXCH_DUP) && examg_exchange(comm, lc, uc, nb, EXAMG_EXCH_DUP, workspace, workspace_bytes, main)) return 1;
+  if (!overlap) {
+    if (examg_exchange(comm, lc, uc, nb, EXAMG_EXCH_GHOST, workspace, workspace_bytes, main)) return 1;
+    return examg_prolong_add(lc, uc, lfine, uf, begin, end, stream);
+  }
+  Overlap *o = overlap_of(comm);
+  if (!o) return 1;
+  if (check_hip(hipEventRecord(o->fork, main), who)) return 1;
+  if (check_hip(hipStreamWaitEvent(o->side, o->fork, 0), who)) return 1;
+  if (examg_exchange(comm, lc, uc, nb, EXAMG_EXCH_GHOST, workspace, workspace_bytes, o->side)) return 1;
+  if (examg_prolong_add(lc, uc, lfine, uf, begin, end, stream)) return 1;
+  if (check_hip(hipEventRecord(o->join, o->side), who)) return 1;
+  return check_hip(hipStreamWaitEvent(main, o->join, 0), who);
 }

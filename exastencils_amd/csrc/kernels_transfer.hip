@@ -399,20 +399,35 @@ extern "C" int examg_restrict(const examg_layout_t *lfine_, const double *rf, co
 // block without neighbours).  [fbegin,fend): the residual loop's box, [cbegin,cend): the restriction loop's box.
 // 3-D 7-point constant stencils on long rows take the fused kernel and never touch `res`; everything else runs the two
 // kernels through `res` (then required).  Bit-identical to examg_residual + examg_restrict either way.
-extern "C" int examg_residual_restrict(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
-                                       const examg_layout_t *lr_, double *res, const examg_stencil_t *st,
-                                       const examg_layout_t *lc_, double *fc, double scale, const int32_t *fbegin,
-                                       const int32_t *fend, const int32_t *cbegin, const int32_t *cend, examg_stream_t stream) {
-  if (!lu_ || !u || !lf_ || !rhs || !st || !lc_ || !fc || !fbegin || !fend || !cbegin || !cend) { set_error("examg_residual_restrict: null argument"); return 1; }
+// does examg_residual_restrict run its one-pass kernel (which never touches the residual array) for these arguments?
+static bool residual_restrict_one_pass(const examg_layout_t *lu_, const examg_layout_t *lf_, const examg_stencil_t *st, const examg_layout_t *lc_,
+                                       const int32_t *fbegin, const int32_t *fend, const int32_t *cbegin, const int32_t *cend) {
   const Box cb = make_box(cbegin, cend), fb = make_box(fbegin, fend);
-  if (cb.count() == 0) return 0;
+  if (cb.count() == 0) return false;
   const int ord = canonical_order7(st);
   // fine footprint of the restriction: [2*cb - 1, 2*(ce-1) + 1] must lie inside the residual loop's box
   const bool inside = 2 * cb.b0 - 1 >= fb.b0 && 2 * (cb.e0 - 1) + 1 < fb.e0 && 2 * cb.b1 - 1 >= fb.b1 && 2 * (cb.e1 - 1) + 1 < fb.e1 &&
                       2 * cb.b2 - 1 >= fb.b2 && 2 * (cb.e2 - 1) + 1 < fb.e2;
   const bool left_ok = 2 * (cb.b0 - 1) >= -(lu_->pad_l[0] + lu_->ghost_l[0]) && 2 * (cb.b0 - 1) >= -(lf_->pad_l[0] + lf_->ghost_l[0]);
-  if (g_restrict_wide && lu_->nd == 3 && ord >= 0 && cb.n0() >= 32 && inside && left_ok && box_inside(lu_, fb, 1) && box_inside(lf_, fb, 0) &&
-      box_inside(lc_, cb, 0)) {
+  return g_restrict_wide && lu_->nd == 3 && ord >= 0 && cb.n0() >= 32 && inside && left_ok && box_inside(lu_, fb, 1) && box_inside(lf_, fb, 0) &&
+         box_inside(lc_, cb, 0);
+}
+
+extern "C" int examg_residual_restrict_one_pass(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const examg_layout_t *lc,
+                                                const int32_t *fbegin, const int32_t *fend, const int32_t *cbegin, const int32_t *cend) {
+  if (!lu || !lf || !st || !lc || !fbegin || !fend || !cbegin || !cend) return 0;
+  return residual_restrict_one_pass(lu, lf, st, lc, fbegin, fend, cbegin, cend) ? 1 : 0;
+}
+
+extern "C" int examg_residual_restrict(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
+                                       const examg_layout_t *lr_, double *res, const examg_stencil_t *st,
+                                       const examg_layout_t *lc_, double *fc, double scale, const int32_t *fbegin,
+                                       const int32_t *fend, const int32_t *cbegin, const int32_t *cend, examg_stream_t stream) {
+  if (!lu_ || !u || !lf_ || !rhs || !st || !lc_ || !fc || !fbegin || !fend || !cbegin || !cend) { set_error("examg_residual_restrict: null argument"); return 1; }
+  const Box cb = make_box(cbegin, cend);
+  if (cb.count() == 0) return 0;
+  const int ord = canonical_order7(st);
+  if (residual_restrict_one_pass(lu_, lf_, st, lc_, fbegin, fend, cbegin, cend)) {
     const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_), lc = make_layout(lc_);
     Coef7 k;
     for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];

@@ -75,9 +75,13 @@ SYMBOLS = [
     "examg_comm_unique_id", "examg_comm_create", "examg_comm_destroy", "examg_comm_rank", "examg_comm_size",
     "examg_exchange_workspace_bytes", "examg_exchange", "examg_allreduce", "examg_allgather",
     "examg_jacobi2_blocks", "examg_rbgs_sweep_blocks", "examg_crand_seed", "examg_crand_draw_host",
+    "examg_residual_restrict_one_pass", "examg_residual_restrict_blocks", "examg_prolong_add_blocks",
+    "examg_comm_create_peer", "examg_comm_peer_alloc", "examg_comm_peer_connect", "examg_comm_peer_slab_bytes",
+    "examg_comm_peer_gather_bytes", "examg_comm_status",
 ]
 
 COMM_ID_BYTES = 128
+PEER_HANDLE_BYTES = 128
 EXCH_DUP, EXCH_GHOST, EXCH_ALL, EXCH_CONCURRENT_AXES = 1, 2, 3, 4
 CG_ALPHA_FROM_NORM, CG_NO_BC = 1, 2
 
@@ -162,9 +166,22 @@ def load(path=None):
     L.examg_jacobi2_blocks.argtypes = [vp, nbp, lp, vp, vp, vp, lp, vp, sp, C.c_double, ip, ip, C.c_int, vp, C.c_size_t, C.c_int, vp]
     L.examg_rbgs_sweep_blocks.argtypes = [vp, nbp, lp, vp, vp, vp, lp, vp, sp, C.c_double, C.c_int, ip, ip, C.c_int, vp, C.c_size_t, C.c_int, vp]
     L.examg_allgather.argtypes = [vp, vp, vp, C.c_int64, vp]
+    L.examg_residual_restrict_one_pass.argtypes = [lp, lp, sp, lp, ip, ip, ip, ip]
+    L.examg_residual_restrict_blocks.argtypes = [vp, nbp, lp, vp, lp, vp, lp, vp, sp, lp, vp, C.c_double, ip, ip, ip, ip, C.c_int, vp, C.c_size_t,
+                                                 C.c_int, vp]
+    L.examg_prolong_add_blocks.argtypes = [vp, nbp, lp, vp, lp, vp, ip, ip, C.c_int, vp, C.c_size_t, C.c_int, vp]
+    L.examg_comm_create_peer.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    L.examg_comm_peer_alloc.argtypes = [vp, C.c_size_t, C.c_size_t, vp]
+    L.examg_comm_peer_connect.argtypes = [vp, vp]
+    L.examg_comm_peer_slab_bytes.argtypes = [vp]
+    L.examg_comm_peer_slab_bytes.restype = C.c_size_t
+    L.examg_comm_peer_gather_bytes.argtypes = [vp]
+    L.examg_comm_peer_gather_bytes.restype = C.c_size_t
+    L.examg_comm_status.argtypes = [vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
-        if name not in ("examg_version", "examg_last_error", "examg_device_count", "examg_reduce_work_bytes", "examg_exchange_workspace_bytes"):
+        if name not in ("examg_version", "examg_last_error", "examg_device_count", "examg_reduce_work_bytes", "examg_exchange_workspace_bytes",
+                        "examg_comm_peer_slab_bytes", "examg_comm_peer_gather_bytes"):
             fn.restype = C.c_int
     if hasattr(L, "examg_debug_force_generic"):      # debug build only
         L.examg_debug_force_generic.argtypes = [C.c_int]

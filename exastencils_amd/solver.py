@@ -218,7 +218,8 @@ class SolverFromL4(_Program):
         b, e = A.bounds(AS)
         ops.set(AS.lc, AS.data(), 0.0, b, e)
         A.apply_bc(AS)
-        if "cycle" in A._graphs:
+        capturing = hasattr(ops, "torch") and ops.torch.cuda.is_available() and ops.torch.cuda.is_current_stream_capturing()
+        if "cycle" in A._graphs and not capturing:
             A.replay_cycle()      # the gathered levels are one block without communication: ~60 launches as one graph replay
         else:
             A.mgCycle(k)
@@ -423,6 +424,13 @@ class SolverFromL4(_Program):
             b, e = self.bounds(Fc)
             ops.residual_restrict(S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), R.lc, R.data(), self.Laplace[l], Fc.lc,
                                   Fc.data(), 1.0, fb, fe, b, e)
+        elif (self.cfg.fused_residual_restrict and self.cfg.overlap_transfers and not self._single_block() and
+              self._faces_only(self.Laplace[l]) and hasattr(self.comm, "c_residual_restrict") and
+              self.comm.c_residual_restrict(self.Solution[l], self.RHS[l], R, self.Laplace[l], Fc, 1.0, *self.bounds(R), *self.bounds(Fc),
+                                            axis_only=True, overlap=True)):
+            # blocks with neighbours, library transport: the four statements as ONE call (examg_residual_restrict_blocks) -- one-pass
+            # kernel on the coarse box shrunk by one point at interior faces, shell + both exchanges on the communicator's side stream
+            self.apply_bc(R)
         else:
             self._update_residual(l)
             b, e = self.bounds(Fc)
@@ -454,7 +462,9 @@ class SolverFromL4(_Program):
             self._smooth(l, correction_from=Sc)
             return
         side = ops.side_stream() if (self.cfg.overlap_transfers and not self._single_block() and hasattr(ops, "side_stream")) else None
-        if side is not None:
+        if side is not None and hasattr(self.comm, "c_prolong_add") and self.comm.c_prolong_add(Sc, S, b, e, overlap=True):
+            pass      # library transport: exchange + kernel as ONE call (examg_prolong_add_blocks), same split as below
+        elif side is not None:
             # `communicate Solution@coarser`: the interpolation of node values reads duplicate and inner points of the coarse
             # block only (fine node i lies between coarse nodes i/2 and (i+1)/2, both inside [0, n]) -- the ghost part of the
             # exchange runs beside the kernel, the duplicate part (which the kernel reads) before it
@@ -524,8 +534,16 @@ class SolverFromL4(_Program):
         neighbours are not captured: RCCL point-to-point groups inside a stream capture hung on this stack (ROCm 7.2, one-GPU
         self-exchange test, round 2) -- there the comm-free part, the agglomerated coarse levels, is what gets captured
         (_agg_cycle)."""
-        if not (self._single_block() and self.cfg.fused_coarse):
-            raise RuntimeError("graph capture needs a single block and the fused coarse solve")
+        if not self.cfg.fused_coarse:
+            raise RuntimeError("graph capture needs the fused coarse solve")
+        if not self._single_block():
+            # blocks with neighbours: the peer-write transport orders its messages with device-side flags and counters, so the
+            # exchanges are ordinary kernels that replay; every rank captures and replays the same cycle.  The coarsest levels must
+            # be the agglomerated ones (their CG is the persistent kernel; a distributed CG returns to the host twice per iteration)
+            if getattr(self.comm, "transport", None) != "peer":
+                raise RuntimeError("graph capture of a cycle with block neighbours needs the peer-write transport")
+            if self._agg is None:
+                raise RuntimeError("graph capture of a cycle with block neighbours needs agglomerated coarse levels (agglomerate_level)")
         torch = self.ops.torch
         hi = self.cfg.max_level
         n_swaps = self.cfg.n_smooth * 2 if self.cfg.fused_rbgs else 0

@@ -178,6 +178,9 @@ int examg_residual_restrict(const examg_layout_t *lu, const double *u, const exa
                             const examg_layout_t *lr, double *res, const examg_stencil_t *st, const examg_layout_t *lc,
                             double *fc, double scale, const int32_t *fbegin, const int32_t *fend, const int32_t *cbegin,
                             const int32_t *cend, examg_stream_t stream);
+/* 1 if examg_residual_restrict will run its one-pass kernel for these arguments (and leave `res` untouched), else 0 */
+int examg_residual_restrict_one_pass(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const examg_layout_t *lc,
+                                     const int32_t *fbegin, const int32_t *fend, const int32_t *cbegin, const int32_t *cend);
 
 /* ---- K4: RHS@coarser = scale * R * Residual, R = kron [1/4 1/2 1/4]
  * (operator/l4/L4_DefaultRestriction.scala:29-36,63-88; solver/ir/IR_ResolveIntergridIndices.scala);
@@ -326,8 +329,9 @@ int examg_copy_from_external(const examg_layout_t *l_ext, const double *src, con
  * naming IR_SetupCommunication.scala:119-147) and the MPI_Allreduce after a reduction loop
  * (parallelization/api/mpi/MPI_Reduction.scala:100-126).  The communicator stands where MPI_COMM_WORLD does; it is created
  * from a 128-byte id that rank 0 obtains and the host distributes by its own means (MPI_Bcast in a generated program, a
- * file, torch.distributed).  All calls are asynchronous on `stream` (ncclSend / ncclRecv groups, pack / unpack kernels) and
- * capturable into a hipGraph.  A communicator of one rank needs no RCCL (id may be NULL). */
+ * file, torch.distributed).  All calls are asynchronous on `stream` (ncclSend / ncclRecv groups, pack / unpack kernels).  NOT for
+ * stream capture: RCCL point-to-point groups hang inside a hipGraph capture on ROCm 7.2 -- the peer-write transport below is
+ * the capturable one.  A communicator of one rank needs no RCCL (id may be NULL). */
 typedef struct examg_comm examg_comm_t;
 #define EXAMG_COMM_ID_BYTES 128
 int examg_comm_unique_id(void *id /* EXAMG_COMM_ID_BYTES */);
@@ -372,10 +376,56 @@ int examg_rbgs_sweep_blocks(examg_comm_t *comm, const examg_neighbors_t *nb, con
                             double *tmp, const examg_layout_t *lf, const double *rhs, const examg_stencil_t *st, double w, int first,
                             const int32_t *begin, const int32_t *end, int exchange_flags, void *workspace, size_t workspace_bytes,
                             int overlap, examg_stream_t stream);
+/* The transfer operators of mgCycle on a block WITH neighbours, one call each (same split, around the `communicate` statements of
+ * Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:215-237):
+ *   examg_residual_restrict_blocks  `communicate Solution; Residual = RHS - A * Solution; communicate Residual; RHS@coarser = R * Residual`:
+ *       the one-pass residual + restriction kernel on the coarse box shrunk by one point at interior faces (reads no ghost value,
+ *       stores no residual) on `stream`; on the side stream the ghost exchange of u, the residual on the two fine planes next to
+ *       every interior face into `res`, the exchange of `res` and the restriction of the coarse planes on the interior faces.
+ *       `res` holds the residual on that two-plane shell only afterwards.  Bit-identical to the four statements.
+ *   examg_prolong_add_blocks        `communicate Solution@coarser; Solution += P * Solution@coarser`: the interpolation reads duplicate
+ *       and inner coarse points only, so the ghost part of the exchange runs beside the kernel.
+ * exchange_flags: EXAMG_EXCH_DUP -- also exchange the duplicate layers (first, in sequence; leave it out when both owners of a
+ * shared plane are known to hold the same bits); EXAMG_EXCH_CONCURRENT_AXES -- ghost layers of u in one batch (7-point stencil). */
+int examg_residual_restrict_blocks(examg_comm_t *comm, const examg_neighbors_t *nb, const examg_layout_t *lu, double *u,
+                                   const examg_layout_t *lf, const double *rhs, const examg_layout_t *lr, double *res,
+                                   const examg_stencil_t *st, const examg_layout_t *lc, double *fc, double scale, const int32_t *fbegin,
+                                   const int32_t *fend, const int32_t *cbegin, const int32_t *cend, int exchange_flags, void *workspace,
+                                   size_t workspace_bytes, int overlap, examg_stream_t stream);
+int examg_prolong_add_blocks(examg_comm_t *comm, const examg_neighbors_t *nb, const examg_layout_t *lc, double *uc,
+                             const examg_layout_t *lfine, double *uf, const int32_t *begin, const int32_t *end, int exchange_flags,
+                             void *workspace, size_t workspace_bytes, int overlap, examg_stream_t stream);
 /* MPI_Allreduce(MPI_IN_PLACE, x, n, MPI_DOUBLE, op): x is device memory; op 0 = sum, 1 = max, 2 = min */
 int examg_allreduce(examg_comm_t *comm, double *x, int n, int op, examg_stream_t stream);
 /* every rank's n doubles, in rank order (coarse-level agglomeration: fewer, larger collectives over xGMI) */
 int examg_allgather(examg_comm_t *comm, const double *send, double *recv, int64_t n, examg_stream_t stream);
+
+/* ---- a-13 / e, second transport: peer writes through HIP IPC (SURVEY.md section 5.8 "direct peer writes"; replaces the
+ * MPI_Isend / MPI_Irecv branch of communication/ir/IR_CommunicateFunction.scala:412-471, IR_RemoteSend.scala:48-58,
+ * IR_RemoteRecv.scala:50-65) -- no communication library: every rank owns a region of uncached device memory that its
+ * neighbours map (hipIpcOpenMemHandle: xGMI peer mapping across the GPUs of a node, a plain mapping when ranks share a device);
+ * the send kernel packs a field box straight into the neighbour's receive slab and publishes a sequence number, the receive
+ * kernel waits for it and unpacks.  Ordering is done by device-side flags whose counters live in device memory, so
+ * examg_exchange / examg_allreduce / examg_allgather / examg_*_blocks on such a communicator are stream-ordered, free of host
+ * round trips and CAPTURABLE INTO A hipGraph (replayed by all ranks alike).  Set-up, all collective:
+ *   examg_comm_create_peer(&c, nranks, rank);
+ *   examg_comm_peer_alloc(c, slab_bytes, gather_bytes, handle);    slab_bytes >= the largest halo message (one face slab,
+ *                                                                  examg_exchange_workspace_bytes(l) / 4 is always enough),
+ *                                                                  gather_bytes >= the largest examg_allgather piece (0: none)
+ *   <all-gather the EXAMG_PEER_HANDLE_BYTES of every rank by the host's own means: MPI_Allgather, torch.distributed, files>
+ *   examg_comm_peer_connect(c, all_handles);
+ * To grow the slabs later: synchronise the device on every rank, host barrier, then alloc / gather / connect again (sequence
+ * numbers restart).  The workspace arguments of examg_exchange / examg_*_blocks are ignored (may be NULL).  A wait that sees no
+ * progress for EXAMG_PEER_TIMEOUT_MS (default 20000) gives up, makes every later wait return at once and is reported by
+ * examg_comm_status() -- a lost neighbour never leaves a kernel spinning. */
+#define EXAMG_PEER_HANDLE_BYTES 128
+int examg_comm_create_peer(examg_comm_t **comm, int nranks, int rank);
+int examg_comm_peer_alloc(examg_comm_t *comm, size_t slab_bytes, size_t gather_bytes, void *handle_out /* EXAMG_PEER_HANDLE_BYTES */);
+int examg_comm_peer_connect(examg_comm_t *comm, const void *all_handles /* nranks x EXAMG_PEER_HANDLE_BYTES, rank order */);
+size_t examg_comm_peer_slab_bytes(const examg_comm_t *comm);
+size_t examg_comm_peer_gather_bytes(const examg_comm_t *comm);
+/* synchronises `stream`, then 0 if no wait of the peer-write transport has given up (always 0 for RCCL communicators) */
+int examg_comm_status(examg_comm_t *comm, examg_stream_t stream);
 
 /* Deterministic synthetic field (SplitMix64 of the linear index, U(-1,1)); same bits as the oracle's. */
 int examg_fill_random(double *x, int64_t n, uint64_t seed, examg_stream_t stream);

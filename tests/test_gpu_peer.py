@@ -1,0 +1,194 @@
+"""Multi-process, device-resident halo exchange on ONE GPU: the peer-write transport (csrc/examg_peer.hip, HIP IPC) with 2 and 4
+ranks started as fresh child processes (tests/peer_worker.py).  RCCL refuses several ranks on one device; this transport does
+not, and it is the one the N > 1 bench path uses.
+
+Checked per decomposition (1 x 1 x 2 and 1 x 2 x 2 blocks of a 128^3-cell grid):
+  * `communicate` (duplicate + ghost layers, axis by axis and as one batch) restores a scrambled halo of a consistent global field;
+  * k overlapped Jacobi pairs (examg_jacobi2_blocks), k overlapped red-black sweeps (examg_rbgs_sweep_blocks), residual +
+    restriction (examg_residual_restrict_blocks) and prolongation + correction (examg_prolong_add_blocks): BIT-IDENTICAL to the
+    single block running the same statements on the whole grid;
+  * all-reduce / all-gather;
+  * the V-cycle leg of bench.py (fused sweeps, fused residual + restriction, agglomerated coarse levels, duplicate exchange left
+    out): eager == replay from a hipGraph (bitwise), iteration counts and residual histories == the single block's and the
+    oracle's within 1e-10 (north_star tolerance), duplicate planes bit-identical on both owners afterwards."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+LEVEL, PAIRS, SWEEPS = 6, 3, 3          # frag_len 2 per dimension in total: 2 * 2^6 = 128 cells per dimension
+CYCLE = {"min_level": 2, "tol": 1e-8, "agglomerate_level": 3, "extra": 0}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def single_block():
+    """The whole grid as one block on the GPU: inputs (saved for the workers) and expected outputs."""
+    import torch
+
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.field import Field, laplace_fd
+    from exastencils_amd.layout import FieldLayout
+    from exastencils_amd.ops import HipOps
+    from exastencils_amd.solver import ConfigL4, SolverFromL4
+
+    ops = HipOps(0)
+    dom = RectDomain(3, (1, 1, 1), 0, (2, 2, 2))
+    L = LEVEL
+    nc, ncc = dom.ncells(L), dom.ncells(L - 1)
+    lay_u = FieldLayout.node(3, nc, 1, True, True, 0)
+    lay_f = FieldLayout.node(3, nc, 0, True, False, 0)
+    lay_c = FieldLayout.node(3, ncc, 1, True, True, 0)
+    lay_cf = FieldLayout.node(3, ncc, 0, True, False, 0)
+    rng = np.random.default_rng(20261004)
+    u = rng.uniform(-1.0, 1.0, lay_u.size)
+    f = rng.uniform(-1.0, 1.0, lay_f.size) * 1000.0
+    uc = rng.uniform(-1.0, 1.0, lay_c.size)
+    d = tempfile.mkdtemp(prefix="examg_peer_")
+    np.save(os.path.join(d, "u.npy"), u.reshape(lay_u.shape_zyx))
+    np.save(os.path.join(d, "f.npy"), f.reshape(lay_f.shape_zyx))
+    np.save(os.path.join(d, "uc.npy"), uc.reshape(lay_c.shape_zyx))
+    json.dump({"level": L, "pairs": PAIRS, "sweeps": SWEEPS, "cycle": CYCLE}, open(os.path.join(d, "spec.json"), "w"))
+
+    A = laplace_fd(3, dom.h(L), "mp")
+    w = 0.8 / A.diag
+    b, e = dom.loop_bounds(lay_u)
+    exp = {}
+
+    def owned(arr, lay, n):
+        a = ops.to_host(arr).reshape(lay.shape_zyx)
+        sl = tuple(slice(lay.ref(k), lay.ref(k) + n[k] + 1) for k in (2, 1, 0))
+        return a[sl].copy()
+
+    x, y, t = ops.from_host(u), ops.from_host(u), ops.from_host(u)
+    F = ops.from_host(f)
+    for _ in range(PAIRS):
+        ops.jacobi2_boxes(lay_u.c_struct(), x, y, t, lay_f.c_struct(), F, A, w, b, e, b, e)
+        x, y = y, x
+    exp["jacobi"] = owned(x, lay_u, nc)
+    x, y = ops.from_host(u), ops.from_host(u)
+    for _ in range(SWEEPS):
+        ops.rbgs_sweep_fused(lay_u.c_struct(), x, y, lay_f.c_struct(), F, A, w, 0, b, e)
+        x, y = y, x
+    exp["rbgs"] = owned(x, lay_u, nc)
+    r = ops.new_array(lay_u.size)
+    fc = ops.new_array(lay_cf.size)
+    cb, ce = dom.loop_bounds(lay_cf)
+    ops.residual_restrict(lay_u.c_struct(), x, lay_f.c_struct(), F, lay_u.c_struct(), r, A, lay_cf.c_struct(), fc, 1.0, b, e, cb, ce)
+    exp["coarse_rhs"] = owned(fc, lay_cf, ncc)
+    ops.prolong_add(lay_c.c_struct(), ops.from_host(uc), lay_u.c_struct(), x, b, e)
+    exp["prolong"] = owned(x, lay_u, nc)
+
+    cfg = ConfigL4(nd=3, min_level=CYCLE["min_level"], max_level=L, frag_len=(2, 2, 2), tol=CYCLE["tol"], fused_rbgs=True,
+                   fused_residual_restrict=True, fused_residual_norm=True)
+    P = SolverFromL4(cfg, ops, dom, Communicator(dom, ops))
+    P.setup()
+    its = P.Solve()
+    exp["cycle"] = owned(P.Solution[L].data(), P.Solution[L].layout, nc)
+    torch.cuda.synchronize()
+
+    from oracle import mg
+
+    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=CYCLE["min_level"], max_level=L, frag_len=(2, 2, 2), tol=CYCLE["tol"]))
+    O.setup()
+    O.Solve()
+    return {"dir": d, "exp": exp, "it": its, "res": list(P.res_history), "oracle_it": O.iterations, "oracle_res": list(O.res_history), "nc": nc, "ncc": ncc}
+
+
+def _run_ranks(blocks, d):
+    world = blocks[0] * blocks[1] * blocks[2]
+    port = _free_port()
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.pop("EXAMG_TRANSPORT", None)
+    env["EXAMG_PEER_TIMEOUT_MS"] = "30000"
+    for r in range(world):
+        for ext in ("npz", "json"):
+            try:
+                os.remove(os.path.join(d, "out_%d.%s" % (r, ext)))
+            except OSError:
+                pass
+    procs = []
+    for r in range(world):     # fresh child processes (never a re-exec of a process that has touched the GPU)
+        log = open(os.path.join(d, "log_%d_%d.txt" % (world, r)), "w")
+        procs.append((subprocess.Popen([sys.executable, os.path.join(HERE, "peer_worker.py"), str(r), str(world), ",".join(map(str, blocks)), str(port), d],
+                                       stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT), log))
+    rcs = []
+    for p, log in procs:
+        try:
+            rcs.append(p.wait(timeout=420))
+        except subprocess.TimeoutExpired:
+            for q, _ in procs:
+                q.kill()
+            rcs.append(-9)
+        log.close()
+    if any(rcs):
+        tails = []
+        for r in range(world):
+            with open(os.path.join(d, "log_%d_%d.txt" % (world, r))) as fh:
+                tails.append("---- rank %d (rc %s)\n%s" % (r, rcs[r], fh.read()[-3000:]))
+        pytest.fail("peer workers failed:\n" + "\n".join(tails))
+    return world
+
+
+@pytest.mark.parametrize("blocks", [(1, 1, 2), (1, 2, 2)])
+def test_peer_transport_multi_process_on_one_gpu(single_block, blocks):
+    sb = single_block
+    d = sb["dir"]
+    world = _run_ranks(blocks, d)
+    nc = tuple(sb["nc"][k] // blocks[k] for k in range(3))
+    ncc = tuple(sb["ncc"][k] // blocks[k] for k in range(3))
+    outs = [json.load(open(os.path.join(d, "out_%d.json" % r))) for r in range(world)]
+    arrs = [np.load(os.path.join(d, "out_%d.npz" % r)) for r in range(world)]
+    for r, o in enumerate(outs):
+        assert o["transport"] == "peer"
+        for k, v in o["checks"].items():
+            assert v, "rank %d: check %s failed" % (r, k)
+        assert o["dup_consistent"], "rank %d: duplicate planes differ between their two owners after the cycle" % r
+
+    def piece(glob, r, n):
+        pos = (r % blocks[0], (r // blocks[0]) % blocks[1], r // (blocks[0] * blocks[1]))
+        sl = tuple(slice(pos[k] * n[k], pos[k] * n[k] + n[k] + 1) for k in (2, 1, 0))
+        return glob[sl]
+
+    for name, n in (("jacobi", nc), ("rbgs", nc), ("coarse_rhs", ncc), ("prolong", nc)):
+        for r in range(world):
+            got, want = arrs[r][name], piece(sb["exp"][name], r, n)
+            assert got.shape == want.shape
+            assert np.array_equal(got, want), "%s: rank %d differs from the single block (max abs %.3e)" % (name, r, np.abs(got - want).max())
+
+    # V-cycle leg: every rank reports the same history; eager == graph replay bit for bit; history == single block == oracle (1e-10)
+    for r, o in enumerate(outs):
+        assert o["eager"]["res"] == outs[0]["eager"]["res"]
+        assert o["graph"]["res"] == o["eager"]["res"], "rank %d: graph replay differs from the eager cycle" % r
+        assert o["graph"]["it"] == o["eager"]["it"]
+        assert np.array_equal(arrs[r]["cycle_eager"], arrs[r]["cycle_graph"])
+    h = outs[0]["eager"]
+    assert h["it"] == sb["it"] == sb["oracle_it"]
+    for x, y, z in zip(h["res"], sb["res"], sb["oracle_res"]):
+        assert abs(x - y) <= 1e-10 * abs(y) + 64 * 2.2e-16 * sb["res"][0]
+        assert abs(x - z) <= 1e-10 * abs(z) + 64 * 2.2e-16 * sb["res"][0]
+    for r in range(world):
+        got, want = arrs[r]["cycle_eager"], piece(sb["exp"]["cycle"], r, nc)
+        assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
