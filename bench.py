@@ -60,9 +60,13 @@ def parse():
     ap.add_argument("--no-temporal-blocking", action="store_true", help="one kernel launch per smoother step")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--extras-timeout", type=float, default=240.0, help="seconds the extra measurements may take")
-    ap.add_argument("--check-duplicates", action="store_true",
-                    help="exchange the duplicate planes once and verify them bit for bit before leaving that exchange out")
-    ap.add_argument("--backend", default="nccl", help="'gloo': rehearsal with several ranks on ONE GPU (messages staged through the host)")
+    ap.add_argument("--no-check-duplicates", action="store_true",
+                    help="N > 1: skip the bit-for-bit comparison of the shared duplicate planes after the timed steps and after the Solve "
+                         "(what leaving their exchange out relies on; on by default)")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0,
+                    help="after the K timed steps: the same step for at least this long, reported as sustained_* beside the headline (0: skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend that carries the bootstrap / timing collectives; 'gloo': several ranks "
+                                                      "on ONE GPU (the halo traffic still moves device to device through the peer-write transport)")
     return ap.parse_args()
 
 
@@ -234,13 +238,16 @@ def main():
 
     dup_check = None
     if world > 1:
-        # make the synthetic field consistent across blocks (duplicate planes from the upstream block, ghosts from the
-        # neighbours) with the full exchange; --check-duplicates then verifies what `consistent_duplicates` relies on
+        # make the synthetic fields consistent across blocks with one full exchange: Solution's duplicate planes from the upstream
+        # block and its ghosts from the neighbours; RHS (a layout without communication) through a communicating alias of the same
+        # array -- both owners of a shared plane then compute the same bits in every step, which `consistent_duplicates` relies on
+        # and which is VERIFIED after the timed steps (duplicate_planes_bit_identical)
         full = Communicator(dom, ops)
         for s_ in (0, 1):
             full.exchange(Solution, s_, "all")
-        if args.check_duplicates:
-            dup_check = comm.check_duplicates(Solution, 0)
+        rhs_alias = Field("RHS", L, FieldLayout.node(nd, nc, 0, True, False, args.align), ops, 1, None)
+        rhs_alias.slots[0] = RHS.data()
+        full.exchange(rhs_alias, None, "dup")
 
     def step():
         # Function Smoother@finest: communicate ghost of Solution<active>; Jacobi loop; advance
@@ -315,6 +322,35 @@ def main():
         total_updates = int(t.item())
     else:
         total_updates = updates
+
+    if hasattr(comm, "check"):
+        comm.check()           # a wait of the peer-write transport that gave up is an error, not a number
+    # sustained leg: the same step for >= --sustained-seconds, reported beside the K-step value (the driver's SMI samples then
+    # see the device under load, and the settle-phase argument is a measurement: a K-step value near this one was taken at the
+    # steady-state clocks)
+    sustained = None
+    if args.sustained_seconds > 0:
+        # ~0.25 s of steps between looks at the clock; dt is the all-reduced maximum here, so every rank forms the same chunks
+        chunk = max(2, 2 * (int(0.25 / max(dt / args.steps, 1e-6)) // 2))
+        n_sus, t_sus = 0, 0.0
+        barrier()
+        t1 = time.perf_counter()
+        while True:
+            steps(chunk)
+            n_sus += chunk
+            torch.cuda.synchronize()
+            go = 1.0 if time.perf_counter() - t1 < args.sustained_seconds else 0.0
+            if world > 1:         # every rank runs the same number of chunks
+                tg = torch.tensor([go], dtype=torch.float64, device=ops.device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+                go = float(tg.item())
+            if go == 0.0:
+                break
+        barrier()
+        t_sus = time.perf_counter() - t1
+        sustained = (n_sus, t_sus)
+    if world > 1 and not args.no_check_duplicates:
+        dup_check = bool(comm.check_duplicates(Solution, Solution.active))
 
     # the two smoother kernels alone, events on the launch stream
     stream = torch.cuda.current_stream()
@@ -402,7 +438,15 @@ def main():
             },
         }
         if dup_check is not None:
-            out["duplicate_planes_bit_identical"] = dup_check
+            out["duplicate_planes_bit_identical"] = dup_check       # compared after the timed and sustained steps
+        if world > 1:
+            out["transport"] = getattr(comm, "transport", None)
+        if sustained is not None:
+            n_sus, t_sus = sustained
+            out["sustained_steps"] = n_sus
+            out["sustained_seconds"] = t_sus
+            out["sustained_ms_per_step"] = t_sus / n_sus * 1e3
+            out["sustained_value"] = total_updates * n_sus / t_sus
         out.update(extra)
 
     # Extra measurements (kernel table, 256^3 block of configs[1], V-cycle / Solve of config 3).  They run collectives at
@@ -432,7 +476,7 @@ def main():
         except Exception as ex:
             more["config1_error"] = repr(ex)[:300]
         try:
-            more.update(vcycle(ops, dom, comm, L, world, args.align))
+            more.update(vcycle(ops, dom, comm, L, world, args.align, check_dups=not args.no_check_duplicates))
         except Exception as ex:  # the headline number must not depend on the extra measurement
             more["vcycle_error"] = repr(ex)[:300]
         if world == 1:
@@ -536,7 +580,7 @@ def config1(ops, world):
     return out
 
 
-def vcycle(ops, dom, comm, L, world, align=0):
+def vcycle(ops, dom, comm, L, world, align=0, check_dups=True):
     """Config 3: one V(3,3) red-black cycle of Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4, 6 levels."""
     import torch
 
@@ -553,7 +597,10 @@ def vcycle(ops, dom, comm, L, world, align=0):
     P.setup()
     P._update_residual(L)
     r0 = P.ResNorm(L)
-    use_graph = world == 1       # N > 1: eager (RCCL groups inside a stream capture hang on this stack); the agglomerated levels replay from a graph
+    # N > 1: the peer-write transport's exchanges are ordinary kernels ordered by device-side flags -- the cycle with neighbours
+    # replays from a hipGraph on every rank alike; on RCCL / torch.distributed it is issued eagerly (RCCL groups inside a stream
+    # capture hang on this stack) and only the agglomerated levels replay from a graph
+    use_graph = world == 1 or getattr(comm, "transport", None) == "peer"
     if use_graph:
         P.capture_cycle()
         run = P.replay_cycle
@@ -580,6 +627,8 @@ def vcycle(ops, dom, comm, L, world, align=0):
     its = Q.Solve(use_graph=use_graph)
     torch.cuda.synchronize()
     solve_s = time.perf_counter() - t0
+    if hasattr(comm, "check"):
+        comm.check()
     # compulsory bytes of one cycle as the driver runs it, per level above the coarsest: 6 sweeps x 24 B per point (16 B for a first
     # sweep that takes the zero field as a constant), residual + restriction (16 B per point + 8 B per coarse point), zeroing the
     # coarse solution (8 B per coarse point, unless left to that sweep), prolongation + correction (16 B per point + 8 B per coarse
@@ -609,6 +658,7 @@ def vcycle(ops, dom, comm, L, world, align=0):
         "solve_iterations": its,
         "solve_residual_reduction": (Q.res_history[-1] / Q.res_history[0]) if Q.res_history and Q.res_history[0] else None,
         "vcycle_graph": use_graph,
+        "vcycle_duplicate_planes_bit_identical": (bool(comm.check_duplicates(Q.Solution[L])) if (world > 1 and check_dups) else None),
         "vcycle_fused_rbgs": True,
         "vcycle_agglomerate_level": agg,
     }

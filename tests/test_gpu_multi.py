@@ -25,7 +25,7 @@ def _bench(n, extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "10", "--warmup", "2", "--level", "7",
-           "--no-cpu-baseline", "--check-duplicates"] + extra
+           "--no-cpu-baseline", "--sustained-seconds", "0.5"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -43,3 +43,18 @@ def test_bench_two_gpus_over_rccl(extra):
     assert r.get("solve_iterations") in (5, 6, 7), r
     assert r["solve_residual_reduction"] < 1e-6
     assert r["scaling"] == ("strong" if "strong" in extra else "weak")
+
+
+@pytest.mark.parametrize("n,extra", [(2, []), (4, ["--scaling", "strong"])], ids=["n2_weak", "n4_strong"])
+def test_bench_ranks_sharing_one_gpu_over_the_peer_write_transport(n, extra):
+    """bench.py exactly as the driver launches it at N > 1, but with the ranks sharing ONE device (`--backend gloo` carries the
+    bootstrap and the timing collectives; every halo message moves device to device through HIP IPC): overlapped Jacobi pairs,
+    the V-cycle with neighbours replayed from a hipGraph, duplicate planes bit-identical on both owners afterwards."""
+    r = _bench(n, ["--backend", "gloo"] + extra)
+    assert r["n_gpus"] == n and r["value"] > 0
+    assert r["transport"] == "peer"
+    assert r["duplicate_planes_bit_identical"] is True
+    assert r["vcycle_graph"] is True and "vcycle_error" not in r, r.get("vcycle_error")
+    assert r["vcycle_duplicate_planes_bit_identical"] is True
+    assert r.get("solve_iterations") in (5, 6, 7), r
+    assert r["solve_residual_reduction"] < 1e-6
