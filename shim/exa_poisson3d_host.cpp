@@ -146,7 +146,10 @@ int main(int argc, char **argv) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::fprintf(stderr, "no HIP device\n"); return 2; }
     if (hipSetDevice(rank % ndev) != hipSuccess) { std::fprintf(stderr, "hipSetDevice failed\n"); return 2; }
-    if (nranks > 1) {   // MPI_Bcast of the communicator id in a generated program; a file here
+    if (nranks > 1 && argc >= 7 && std::string(argv[6]) == "peer") {
+      // peer-write transport: no id; initGlobals exchanges the IPC handles of the ranks through files <argv[5]>.<rank>
+      setenv("EXA_PEER_HANDLE_BASE", argv[5], 1);
+    } else if (nranks > 1) {   // MPI_Bcast of the communicator id in a generated program; a file here
       if (rank == 0) {
         if (examg_comm_unique_id(id)) { std::fprintf(stderr, "%s\n", examg_last_error()); return 1; }
         std::string tmp = std::string(argv[5]) + ".tmp";

@@ -9,6 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "exa_poisson3d.h"
 
@@ -122,7 +126,36 @@ void initGlobals(const int numBlocks[3], int mpiRank, const void *commId) {
       q[d] = g_pos[d];
     }
   }
-  check(examg_comm_create(&g_comm, commId, g_size, mpiRank), "examg_comm_create");
+  const char *peerBase = std::getenv("EXA_PEER_HANDLE_BASE");
+  if (g_size > 1 && !commId && peerBase) {
+    // peer-write transport (HIP IPC; also several ranks on ONE device): create, allocate the slabs for the finest level's faces,
+    // all-gather the handles -- MPI_Allgather in a generated program, files <base>.<rank> here -- and map the neighbours' regions
+    check(examg_comm_create_peer(&g_comm, g_size, mpiRank), "examg_comm_create_peer");
+    const examg_layout_t finest = nodeLayout(EXA_MAX_LEVEL, 1);
+    unsigned char mine[EXAMG_PEER_HANDLE_BYTES];
+    check(examg_comm_peer_alloc(g_comm, examg_exchange_workspace_bytes(&finest) / 4, 0, mine), "examg_comm_peer_alloc");
+    {
+      const std::string path = std::string(peerBase) + "." + std::to_string(mpiRank), tmp = path + ".tmp";
+      FILE *f = std::fopen(tmp.c_str(), "wb");
+      if (!f || std::fwrite(mine, 1, sizeof(mine), f) != sizeof(mine)) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); std::exit(1); }
+      std::fclose(f);
+      std::rename(tmp.c_str(), path.c_str());
+    }
+    std::vector<unsigned char> all((size_t)g_size * EXAMG_PEER_HANDLE_BYTES);
+    for (int r = 0; r < g_size; ++r) {
+      const std::string path = std::string(peerBase) + "." + std::to_string(r);
+      FILE *f = nullptr;
+      for (int tries = 0; tries < 600 && !(f = std::fopen(path.c_str(), "rb")); ++tries) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+      if (!f || std::fread(all.data() + (size_t)r * EXAMG_PEER_HANDLE_BYTES, 1, EXAMG_PEER_HANDLE_BYTES, f) != EXAMG_PEER_HANDLE_BYTES) {
+        std::fprintf(stderr, "cannot read %s\n", path.c_str());
+        std::exit(1);
+      }
+      std::fclose(f);
+    }
+    check(examg_comm_peer_connect(g_comm, all.data()), "examg_comm_peer_connect");
+  } else {
+    check(examg_comm_create(&g_comm, commId, g_size, mpiRank), "examg_comm_create");
+  }
   // boundary expressions as postfix programs (the generator inlines them into the boundary kernels)
   std::memset(&g_bcSolution, 0, sizeof(g_bcSolution));
   std::memset(&g_bcZero, 0, sizeof(g_bcZero));

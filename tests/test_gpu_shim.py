@@ -74,3 +74,25 @@ def test_shim_two_blocks_over_rccl(tmp_path):
     O.setup()
     O.Solve()
     _close(_history(outs[0][0]), O.res_history)
+
+
+@pytest.mark.parametrize("blocks", [(1, 1, 2), (1, 2, 2)])
+def test_shim_blocks_over_the_peer_write_transport_on_one_gpu(tmp_path, blocks):
+    """The generated-style C++ host as 2 / 4 processes that SHARE the one GPU: exch<Field>_<L> = examg_exchange on a communicator made
+    by examg_comm_create_peer (HIP IPC; handles through files where a generated program would call MPI_Allgather), reductions through
+    examg_allreduce on the same regions.  The root's history must be the oracle's for the same decomposition (1e-10)."""
+    import __graft_entry__ as ge
+
+    exe = ge.build_shim(2, 6)
+    n = blocks[0] * blocks[1] * blocks[2]
+    base = str(tmp_path / "peer.handle")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe] + [str(b) for b in blocks] + [str(r), base, "peer"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(n)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se
+    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=2, max_level=6, tol=1e-6, nfrag=blocks))
+    O.setup()
+    O.Solve()
+    _close(_history(outs[0][0]), O.res_history)
