@@ -133,6 +133,8 @@ struct ZMarchGeom {
   int ntx, nty, ntz;  // tiles per dim
   int zc;             // planes per march chunk
   int remap;          // 2: XCD-contiguous within every z layer of tiles (kernels_twostage.hip); 0: plain order
+  int store;          // 0: non-temporal stores; 1: lanes in the partial first / last cache line of the wave's window store cached
+                      // (the L2 merges the two halves of a line that two x-adjacent waves share); 2: all stores cached
 };
 
 template <bool ALIAS> struct Ptr { typedef double *__restrict__ out; typedef const double *__restrict__ in; };
@@ -169,6 +171,8 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
   const int rw = box.b1 + (ty * WY + wv) * RY;  // first row of this wave
   const int mb = box.b2 + tz * g.zc;
   const int me = min(mb + g.zc, box.e2);
+  const int rwu = __builtin_amdgcn_readfirstlane(rw);                       // the same value in a scalar register
+  const unsigned long long dst_lo = (unsigned long long)(uintptr_t)dst;   // only its low 7 bits matter
   // ZM_RESNORM: `dst` is the array of partial sums, one per wave of the grid (fixed geometry: reproducible run to run)
   double ssum = 0.0;
   if (rw >= box.e1) {        // wave-uniform
@@ -260,7 +264,18 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
         }
       } else if (rw + r < box.e1) {
         double *q = dr[r] + ld.s2 * m;
-        if (va && vb) store2_nt(q, o);
+        bool cached = g.store == 2;
+        if (g.store == 1) {
+          // byte offset of the window's first point within its 128-byte line: wave-uniform (row, plane, tile) -> scalar ALU
+          const unsigned a0 = (unsigned)(((unsigned long long)(ld.origin + g.xo + tx * 128 + ld.s1 * (long long)(rwu + r) + ld.s2 * (long long)m) * 8ull + dst_lo) & 127ull);
+          const int nh = (int)(((128u - a0) & 127u) + 15u) >> 4;   // lanes that start inside the partial head line
+          const int nt = (int)(a0 + 15u) >> 4;                      // lanes that end inside the partial tail line
+          cached = lane < nh || lane >= 64 - nt;
+        }
+        if (va && vb) {
+          if (cached) store2(q, o);
+          else store2_nt(q, o);
+        }
         else if (va) q[0] = o.x;
         else if (vb) q[1] = o.y;
       }
@@ -291,6 +306,196 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3-D 7-point constant-coefficient ROW-marching kernel: a wave owns WHOLE rows (up to 512 points: NSEG = 4 segments of 128, two
+// points per lane and segment), RY rows of them, and marches in z like the kernel above.  What that buys on the verbatim layout
+// (515-double rows, whose odd strides put every row and plane at another offset within its 128-byte line -- the 128-point
+// windows of the kernel above start and end in the middle of a line that the neighbouring window also writes):
+//   * every output row is in ONE wave, so it can be stored as whole, 128-byte-aligned lines: the outputs pass through a
+//     wave-private LDS strip (ds_write_b128, then ds_read2_b64 at the row's offset to the next line boundary -- no barrier,
+//     LDS operations of one wave execute in order) and leave as 16-byte-aligned non-temporal stores of full lines; only the
+//     two ends of a row are partial lines.  Measured in tools/stencil_lab.hip (stores moved to line boundaries, timing only):
+//     0.618 -> 0.590 ms at 512^3, the difference between the verbatim and the padded layout;
+//   * no window edges inside a row: x-neighbours across segments come from the neighbouring lane by a wave rotate (DPP
+//     wave_rol / wave_ror), edge loads only at the two ends of the row; no partial lines are fetched twice.
+// Loads per point are those of the kernel above (own rows once, two y-halo rows per wave through L2).  ~300 VGPRs with two
+// rows per wave: one wave per SIMD, the software pipeline (everything step m+1 needs is in flight during step m) hides the
+// latency instead of occupancy.  Arithmetic: conv7 / finish as above -- bit-identical.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_rotl(double v) {   // lane l receives lane l+1, lane 63 receives lane 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xF, 0xF, false);   // wave_rol:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_rotr(double v) {   // lane l receives lane l-1, lane 0 receives lane 63
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xF, 0xF, false);   // wave_ror:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+struct RowMarchGeom {
+  int nty, ntz;   // tiles of WY * RY rows, chunks of zc planes
+  int zc;
+  int remap;      // 2: bands of y-adjacent tiles per XCD within every z layer
+};
+
+constexpr int RM_NSEG = 4;                     // 4 x 128 points per row
+constexpr int RM_STRIP = RM_NSEG * 128 + 16;   // doubles of LDS per wave and row
+
+template <int MODE, int ORDER, int RY, int WY>
+__global__ void __launch_bounds__(64 * WY)
+k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev ld,
+                    double *__restrict__ dst, Coef7 k, double w, Box box, RowMarchGeom g) {
+  __shared__ __attribute__((aligned(16))) double strip[WY][RY][RM_STRIP];
+  const int lane = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  int t = blockIdx.x;
+  if (g.remap == 2) {
+    const int lz = t / g.nty, r = t - lz * g.nty;
+    const int per = g.nty >> 3;
+    t = lz * g.nty + (r < (per << 3) ? (r & 7) * per + (r >> 3) : r);
+  }
+  const int ty = t % g.nty;
+  const int tz = t / g.nty;
+  const int rw = box.b1 + (ty * WY + wv) * RY;   // first row of this wave
+  if (rw >= box.e1) return;                      // wave-uniform
+  const int mb = box.b2 + tz * g.zc;
+  const int me = min(mb + g.zc, box.e2);
+  const int n0 = box.n0();
+  const int x0 = box.b0 + 2 * lane;              // the lane's first point in segment 0; segment j: + 128 j
+
+  bool va[RM_NSEG], vb[RM_NSEG];
+  int xs[RM_NSEG];                               // column the lane loads from (idle lanes: a safe one, never stored)
+#pragma unroll
+  for (int j = 0; j < RM_NSEG; ++j) {
+    const int x = x0 + 128 * j;
+    va[j] = x < box.e0;
+    vb[j] = x + 1 < box.e0;
+    xs[j] = va[j] ? x : box.b0;
+  }
+  // the last pair of the row whose second point is inside the box needs u[x + 2] from memory when the next pair is outside
+  const bool has_r = (n0 & 1) == 0;
+  const int qr = (n0 - 2) >> 1, jr = qr >> 6, lr = qr & 63;
+
+  const double *ur[RY];
+  const double *fr[RY];
+  double *dr[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    const int row = min(rw + r, box.e1);   // clamped rows re-read the upper halo row (never stored)
+    ur[r] = u + lu.origin + lu.s1 * row;
+    fr[r] = rhs + lf.origin + lf.s1 * row;
+    dr[r] = dst + ld.origin + ld.s1 * row;
+  }
+  const double *uhm = u + lu.origin + lu.s1 * (rw - 1);
+  const double *uhp = u + lu.origin + lu.s1 * min(rw + RY, box.e1);
+
+  d2 um[RY][RM_NSEG], uc[RY][RM_NSEG];
+#pragma unroll
+  for (int r = 0; r < RY; ++r)
+#pragma unroll
+    for (int j = 0; j < RM_NSEG; ++j) {
+      um[r][j] = load2(ur[r] + xs[j] + lu.s2 * (mb - 1));
+      uc[r][j] = load2(ur[r] + xs[j] + lu.s2 * mb);
+    }
+  struct Stage {
+    d2 up[RY][RM_NSEG], f[RY][RM_NSEG], hm[RM_NSEG], hp[RM_NSEG];
+    double el[RY], er[RY];
+  };
+  auto load_stage = [&](Stage &st, int m) {
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+#pragma unroll
+      for (int j = 0; j < RM_NSEG; ++j) {
+        st.up[r][j] = load2(ur[r] + xs[j] + lu.s2 * (m + 1));
+        if (MODE != EXAMG_APPLY) st.f[r][j] = load2(fr[r] + xs[j] + lf.s2 * m);
+      }
+      st.el[r] = 0.0;
+      st.er[r] = 0.0;
+      if (lane == 0) st.el[r] = ur[r][box.b0 - 1 + lu.s2 * m];
+      if (has_r && lane == lr) st.er[r] = ur[r][box.b0 + 2 * qr + 2 + lu.s2 * m];
+    }
+#pragma unroll
+    for (int j = 0; j < RM_NSEG; ++j) {
+      st.hm[j] = load2(uhm + xs[j] + lu.s2 * m);
+      st.hp[j] = load2(uhp + xs[j] + lu.s2 * m);
+    }
+  };
+  auto compute = [&](const Stage &st, int m) {
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      d2 o[RM_NSEG];
+#pragma unroll
+      for (int j = 0; j < RM_NSEG; ++j) {
+        // x-neighbours: the adjacent lane; across segments the wave rotates (lane 63 of segment j <-> lane 0 of segment j + 1)
+        double xl = lane_below(uc[r][j].y);
+        double xr = lane_above(uc[r][j].x);
+        if (j > 0) {
+          const double t0 = lane_rotr(uc[r][j - 1].y);
+          if (lane == 0) xl = t0;
+        } else if (lane == 0) {
+          xl = st.el[r];
+        }
+        if (j < RM_NSEG - 1) {
+          const double t1 = lane_rotl(uc[r][j + 1].x);
+          if (lane == 63) xr = t1;
+        }
+        if (has_r && j == jr && lane == lr) xr = st.er[r];
+        const d2 tm_ = (r == 0) ? st.hm[j] : uc[r == 0 ? 0 : r - 1][j];
+        const d2 tp_ = (r == RY - 1) ? st.hp[j] : uc[r == RY - 1 ? r : r + 1][j];
+        const double acc_a = conv7<ORDER>(k, uc[r][j].x, xl, uc[r][j].y, tm_.x, tp_.x, um[r][j].x, st.up[r][j].x);
+        const double acc_b = conv7<ORDER>(k, uc[r][j].y, uc[r][j].x, xr, tm_.y, tp_.y, um[r][j].y, st.up[r][j].y);
+        o[j].x = finish<MODE>(uc[r][j].x, acc_a, st.f[r][j].x, w);
+        o[j].y = finish<MODE>(uc[r][j].y, acc_b, st.f[r][j].y, w);
+      }
+      if (rw + r < box.e1) {
+        double *row = dr[r] + box.b0 + ld.s2 * m;                       // &dst[x = b0] of this row and plane
+        // doubles from the row's first point to the next 128-byte boundary: wave-uniform
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)row);
+        const int hb = (int)(((128u - (lo & 127u)) & 127u) >> 3);
+        double *sb = strip[wv][r];
+#pragma unroll
+        for (int j = 0; j < RM_NSEG; ++j) *reinterpret_cast<d2 *>(sb + 128 * j + 2 * lane) = o[j];
+        // head of the row, up to the first line boundary: straight from the registers of segment 0 (a partial line)
+        if (2 * lane + 1 < hb) store2_nt(row + 2 * lane, o[0]);
+        else if (2 * lane < hb) row[2 * lane] = o[0].x;
+#pragma unroll
+        for (int j = 0; j < RM_NSEG; ++j) {
+          const int p = hb + 128 * j + 2 * lane;                        // first of the lane's two points, relative to b0
+          d2 v;
+          v.x = sb[p];
+          v.y = sb[p + 1];
+          // 16-byte aligned: whole lines per wave.  Rows have at least 400 points (dispatch): only the last segment can end early
+          if (j < RM_NSEG - 1 || p + 1 < n0) __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(row + p));
+          else if (p < n0) row[p] = v.x;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r)
+#pragma unroll
+      for (int j = 0; j < RM_NSEG; ++j) {
+        um[r][j] = uc[r][j];
+        uc[r][j] = st.up[r][j];
+      }
+  };
+  Stage st[2];
+  load_stage(st[0], mb);
+  int m = mb;
+  while (m < me) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (m < me) {
+        if (m + 1 < me) load_stage(st[j ^ 1], m + 1);
+        compute(st[j], m);
+        ++m;
+      }
+    }
+  }
+}
+
 static thread_local int g_force_generic = 0;  // test hook (debug build only): examg_debug_force_generic
 // workgroup cap of the unrolled stencil-field kernel: none.  One short-lived workgroup per 256 points, dispatched in order, keeps
 // the front that sweeps the 30 streams (27 coefficient planes, u, rhs, dst) narrow: 512^3, 27 entries: 7.8 ms with 16384
@@ -303,13 +508,48 @@ bool stencilfield7_ok(const examg_layout_t *lu, const examg_stencil_t *st, const
 int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
                          double *dst, const LayoutDev &lc, const double *cf, double w, const Box &box, hipStream_t s);
 
+static thread_local int g_rm_on = -1, g_rm_zc = -1, g_rm_remap = -1;   // examg_debug_rowmarch (debug build): row-marching kernel off / on, planes per chunk, order
+#ifndef EXAMG_RM_RY
+#define EXAMG_RM_RY 2
+#define EXAMG_RM_WY 4
+#endif
+constexpr int RM_RY = EXAMG_RM_RY, RM_WY = EXAMG_RM_WY;
+
+// the row-marching kernel takes boxes whose rows fit one wave (385 .. 512 points: level 9) and that are long enough in y and z
+template <int MODE>
+static bool rowmarch_wanted(const Box &box, int colour) {
+  if (MODE == ZM_RESNORM || colour >= 0) return false;
+  if (g_rm_on == 0) return false;
+  const bool fits = box.n0() >= 400 && box.n0() <= RM_NSEG * 128;
+  if (g_rm_on == 1) return fits;
+  return fits && box.n1() >= 64 && box.n2() >= 16;
+}
+
+template <int MODE, int ORDER>
+static int launch_rowmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld, double *dst,
+                           const Coef7 &k, double w, const Box &box, hipStream_t s) {
+  RowMarchGeom g;
+  g.nty = (box.n1() + RM_RY * RM_WY - 1) / (RM_RY * RM_WY);
+  int zc = g_rm_zc > 0 ? g_rm_zc : 32;   // 512^3: 8 .. 64 planes per chunk are within 2 % of each other (tools/sweep_rowmarch.py)
+  if (zc > box.n2()) zc = box.n2();
+  g.zc = zc;
+  g.ntz = (box.n2() + zc - 1) / zc;
+  g.remap = g_rm_remap >= 0 ? g_rm_remap : 2;
+  dim3 block(64, RM_WY, 1), grid(g.nty * g.ntz, 1, 1);
+  hipLaunchKernelGGL((k_stencil7_rowmarch<MODE, ORDER, RM_RY, RM_WY>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  return (int)grid.x * RM_WY;
+}
+
 constexpr int ZM_RY = 2, ZM_WY = 4, ZM_BLOCKS = 512, ZM_BLOCKS_COL = 1024, ZM_MINCHUNK = 16;   // half sweeps: 0.68 ms at 512 workgroups, 0.64 at 1024
-static thread_local int g_zm_blocks = -1, g_zm_minchunk = -1, g_zm_remap = -1;    // examg_debug_zmarch (debug build): workgroup target, planes per chunk, tile order
+static thread_local int g_zm_blocks = -1, g_zm_minchunk = -1, g_zm_remap = -1, g_zm_store = -1;    // examg_debug_zmarch (debug build): workgroup target, planes per chunk, tile order
 
 // returns the number of waves of the grid (ZM_RESNORM: the number of partial sums written to dst)
 template <int MODE, int ORDER>
 static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1, int max_waves = 0) {
+  if (rowmarch_wanted<MODE>(box, colour)) {
+    if (MODE != ZM_RESNORM) return launch_rowmarch<MODE == ZM_RESNORM ? EXAMG_RESIDUAL : MODE, ORDER>(lu, u, lf, rhs, ld, dst, k, w, box, s);
+  }
   ZMarchGeom g;
   // Padded layouts (`align`, field/ir/IR_AddPaddingToFieldLayouts.scala:36-41) have even row lengths and put the lower duplicate
   // point on an even index: starting the windows one point to the left of an odd box makes every 16-byte load and store of
@@ -352,6 +592,7 @@ static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &
   g.zc = zc;
   g.ntz = (box.n2() + zc - 1) / zc;
   g.colour = colour;
+  g.store = g_zm_store >= 0 ? g_zm_store : 0;
   dim3 block(64, ZM_WY, 1), grid(g.ntx * g.nty * g.ntz, 1, 1);
   if (max_waves > 0 && (long long)grid.x * ZM_WY > max_waves) return -1;     // nothing launched
   if (colour >= 0) {
@@ -377,6 +618,16 @@ extern "C" int examg_debug_zmarch(int blocks, int minchunk, int remap) {
   g_zm_blocks = blocks;
   g_zm_minchunk = minchunk;
   g_zm_remap = remap;
+  return 0;
+}
+extern "C" int examg_debug_rowmarch(int on, int zc, int remap) {
+  g_rm_on = on;
+  g_rm_zc = zc;
+  g_rm_remap = remap;
+  return 0;
+}
+extern "C" int examg_debug_zmarch_store(int mode) {
+  g_zm_store = mode;
   return 0;
 }
 extern "C" int examg_debug_sf27(int unrolled) {

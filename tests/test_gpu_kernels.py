@@ -109,6 +109,34 @@ def test_stencil7_fast_path_bit_exact(hip, orc, mode, order, n):
     assert_same(g, c, "stencil7 mode %d" % mode)
 
 
+@pytest.mark.parametrize("mode", [APPLY, RESIDUAL, SMOOTH])
+@pytest.mark.parametrize("case", [
+    # (cells per dim, begin, end, align): rows of 400 .. 512 points take the row-marching kernel (a wave owns whole rows and stores
+    # whole, 128-byte-aligned lines through its LDS strip); every row / plane starts at another offset within its line
+    ((512, 72, 20), [1, 1, 1], [512, 72, 20], 0),        # level-9 rows, odd count (511)
+    ((512, 72, 20), [0, 0, 0], [513, 73, 21], 0),        # interior faces on every side: 513 points -> the window kernel takes it
+    ((512, 66, 18), [0, 1, 1], [512, 66, 18], 0),        # 512 points, even count: the last pair needs its right neighbour from memory
+    ((420, 70, 17), [1, 1, 1], [420, 70, 17], 0),        # last segment mostly empty, ragged tiles in y and z
+    ((400, 64, 16), [0, 1, 0], [401, 64, 17], 0),        # 401 points
+    ((512, 72, 20), [1, 1, 1], [512, 72, 20], 16),       # padded rows (544 doubles)
+])
+def test_stencil7_row_marching_kernel_bit_exact(hip, hipd, orc, mode, case):
+    shape, b, e, align = case
+    for order in ("mp", "pm"):
+        st = laplace_fd(3, tuple(1.0 / n for n in shape), order)
+        g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, shape, st, mode, -1, b, e, align=align))
+        assert_same(g, c, "row-marching kernel, mode %d order %s" % (mode, order))
+    # the same box through the 128-point-window kernel (row-marching kernel switched off in the debug build): same bits
+    hipd.L.examg_debug_rowmarch(0, -1, -1)
+    try:
+        st = laplace_fd(3, tuple(1.0 / n for n in shape), "mp")
+        g2 = [hipd.to_host(t) for t in _stencil_case(hipd, 3, shape, st, mode, -1, b, e, align=align)]
+    finally:
+        hipd.L.examg_debug_rowmarch(-1, -1, -1)
+    g1 = [hip.to_host(t) for t in _stencil_case(hip, 3, shape, st, mode, -1, b, e, align=align)]
+    assert_same(g1, g2, "row-marching vs window kernel")
+
+
 def test_stencil7_anisotropic_box_and_interior_faces(hip, orc):
     """Non-cubic fragment, loop bounds of a block with neighbours on some faces (begin 0 / end n+1)."""
     shape = (160, 40, 24)

@@ -140,6 +140,11 @@ k_zm(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__r
         double *q_ = dr[r] + lu.s2 * m;
         if (ABL & 4) {
           if (o.x == 1.2345e300) q_[0] = o.y;   // keeps the arithmetic alive, never true
+        } else if (ABL & 16) {
+          // timing only: the wave's 1 KiB of output at the 128-byte boundary below its window -- what stores of whole, aligned
+          // lines would cost (wrong addresses: neighbouring windows overlap by up to 15 doubles)
+          double *qa = (double *)(((unsigned long long)(q_ - 2 * lane) & ~127ull)) + 2 * lane;
+          if (vb) __builtin_nontemporal_store(o, (d2 *)qa);
         } else if (vb) {
           __builtin_nontemporal_store(o.x, q_);
           __builtin_nontemporal_store(o.y, q_ + 1);
@@ -371,6 +376,8 @@ static void report(const Ctx &c, const char *name, float ms, bool check) {
   fflush(stdout);
 }
 
+static int g_minchunk = 16;
+
 template <int RY, int WY, int PF, bool EPF, int ABL, bool NTF = false, bool REMAP = false, int WX = 1>
 static void run_zm(const Ctx &c, int blocks, const char *tag) {
   Geo g;
@@ -380,7 +387,7 @@ static void run_zm(const Ctx &c, int blocks, const char *tag) {
   int ntz = (blocks + xy - 1) / xy;
   if (ntz < 1) ntz = 1;
   int zc = (c.box.n2() + ntz - 1) / ntz;
-  if (zc < 16) zc = 16;
+  if (zc < g_minchunk) zc = g_minchunk;
   if (zc > c.box.n2()) zc = c.box.n2();
   g.zc = zc;
   g.ntz = (c.box.n2() + zc - 1) / zc;
@@ -465,6 +472,57 @@ int main(int argc, char **argv) {
     run_zm<1, 4, 2, true, 0>(c, 512, "");
     run_zm<1, 8, 1, true, 0>(c, 256, "");
     run_zm<4, 4, 1, true, 0>(c, 1024, "");
+  }
+  if (want("r3")) {   // round 3: tile shapes in the short-chunk regime (XCD-banded order, as many workgroups as the chunks need)
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      for (int mc : {8, 16, 32}) {
+        g_minchunk = mc;
+        run_zm<2, 4, 1, true, 0, false, true, 1>(c, 1 << 24, "shipped shape");
+        run_zm<2, 8, 1, true, 0, false, true, 1>(c, 1 << 24, "");
+        run_zm<4, 4, 1, true, 0, false, true, 1>(c, 1 << 24, "");
+        run_zm<2, 4, 1, true, 0, false, true, 2>(c, 1 << 24, "");
+        run_zm<2, 2, 1, true, 0, false, true, 2>(c, 1 << 24, "");
+        run_zm<2, 2, 1, true, 0, false, true, 4>(c, 1 << 24, "");
+        run_zm<4, 2, 1, true, 0, false, true, 2>(c, 1 << 24, "");
+        run_zm<2, 4, 2, true, 0, false, true, 1>(c, 1 << 24, "pf2");
+        run_zm<2, 8, 2, true, 0, false, true, 1>(c, 1 << 24, "pf2");
+      }
+    }
+    g_minchunk = 16;
+  }
+  if (want("front")) {   // round 3: ONE thin front -- as many workgroups as xy tiles, whole columns, deep software pipeline instead of occupancy
+    g_minchunk = 16;
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      run_zm<2, 4, 1, true, 0, false, true, 1>(c, 256, "");
+      run_zm<2, 4, 2, true, 0, false, true, 1>(c, 256, "");
+      run_zm<2, 4, 3, true, 0, false, true, 1>(c, 256, "");
+      run_zm<2, 4, 4, true, 0, false, true, 1>(c, 256, "");
+      run_zm<2, 4, 6, true, 0, false, true, 1>(c, 256, "");
+      run_zm<1, 8, 2, true, 0, false, true, 1>(c, 256, "");
+      run_zm<1, 8, 4, true, 0, false, true, 1>(c, 256, "");
+      run_zm<1, 8, 6, true, 0, false, true, 1>(c, 256, "");
+      run_zm<2, 4, 2, true, 0, false, true, 1>(c, 512, "");
+      run_zm<2, 4, 3, true, 0, false, true, 1>(c, 512, "");
+      run_zm<2, 4, 4, true, 0, false, true, 1>(c, 512, "");
+      run_zm<1, 4, 4, true, 0, false, true, 1>(c, 512, "");
+      run_zm<1, 4, 6, true, 0, false, true, 1>(c, 512, "");
+      run_zm<2, 4, 3, true, 0, false, false, 1>(c, 256, "plain order");
+    }
+  }
+  if (want("sabl")) {   // round 3: ablations in the shipped short-chunk regime (run for align 0 and for align 16 with b0 = 0)
+    g_minchunk = 8;
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      run_zm<2, 4, 1, true, 0, false, true, 1>(c, 1 << 24, "full");
+      run_zm<2, 4, 1, true, 1, false, true, 1>(c, 1 << 24, "no halo rows");
+      run_zm<2, 4, 1, true, 2, false, true, 1>(c, 1 << 24, "no rhs");
+      run_zm<2, 4, 1, true, 4, false, true, 1>(c, 1 << 24, "no stores");
+      run_zm<2, 4, 1, true, 6, false, true, 1>(c, 1 << 24, "no rhs, no stores");
+      run_zm<2, 4, 1, true, 7, false, true, 1>(c, 1 << 24, "u rows only");
+      run_zm<2, 4, 1, true, 3, false, true, 1>(c, 1 << 24, "u rows + stores");
+      run_zm<2, 4, 1, true, 16, false, true, 1>(c, 1 << 24, "full, stores moved to line boundaries (timing only)");
+      run_zm<2, 4, 1, true, 19, false, true, 1>(c, 1 << 24, "u rows + stores at line boundaries (timing only)");
+    }
+    g_minchunk = 16;
   }
   if (want("abl")) {
     run_zm<2, 4, 1, false, 1>(c, 1024, "no halo rows");
