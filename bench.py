@@ -699,13 +699,15 @@ def helmholtz27_cycle(ops, L):
 
     from exastencils_amd.solver import ConfigL3, SolverFromL3
 
-    need = 33 * 8.0 * float((1 << L) + 3) ** 3 * 8.0 / 7.0      # 27 coefficient planes, 2 + 1 + 1 + 2 field arrays, all levels
+    need = 60 * 8.0 * float((1 << L) + 3) ** 3 * 8.0 / 7.0      # 27 coefficient planes (twice while they are re-laid out), 2 + 1 + 1 + 2 field arrays, all levels
     free = torch.cuda.mem_get_info(ops.device)[0]
     if need > 0.9 * free:
         return {"helmholtz27_skipped": "needs %.0f GB, %.0f GB free" % (need / 1e9, free / 1e9)}
     cfg = ConfigL3(nd=3, min_level=1, max_level=L - 1, frag_len=(2, 2, 2), smoother="jacobi", omega=0.8, stencil="helmholtz27",
                    restrict_scale=1.0, tol=1e-8, cg_max=512, bc_fn=0, sol_fn=9, coef_fn=7, kappa=10.0, ksq=2.0, rhs_from_solution=True,
-                   fused_coarse=True)
+                   fused_coarse=True,
+                   # LayoutTransformations { transform LaplaceCoeff with [x, y, z, i] => [i, x, y, z] }: the 27 entries of a point contiguous
+                   coef_entry_fastest=True)
     P = SolverFromL3(cfg, ops)
     P.setup()
     r0 = P._residual_and_norm(cfg.max_level)
@@ -731,6 +733,7 @@ def helmholtz27_cycle(ops, L):
         c = float((ce[0] - cb[0]) * (ce[1] - cb[1]) * (ce[2] - cb[2]))
         comp += 7 * 240.0 * p + (8.0 * p + 8.0 * c) + 8.0 * c + (16.0 * p + 8.0 * c)
     return {"helmholtz27_vcycle_ms": ms, "helmholtz27_levels": cfg.max_level - cfg.min_level + 1,
+            "helmholtz27_coefficient_layout": "entry-fastest (LayoutTransformations [x,y,z,i] => [i,x,y,z])",
             "helmholtz27_residual_reduction_6_cycles": r1 / r0 if r0 else None,
             "helmholtz27_vcycle_frac": comp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 

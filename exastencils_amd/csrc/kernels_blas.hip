@@ -272,6 +272,25 @@ k_init_varcoeff(LayoutDev lc, double *cf, Geom g, ExprEval a, Box box, int nd) {
   }
 }
 
+// ---- layout transformation of a stencil field's coefficients: entry-slowest planes <-> entry-fastest records ---------------
+// one workgroup moves a tile of 64 points x K entries through LDS so that both sides are accessed in runs of consecutive doubles
+template <bool TO_AOS>
+__global__ void __launch_bounds__(256) k_transform_sf(const double *__restrict__ src, double *__restrict__ dst, long long size, int K) {
+  __shared__ double tile[64 * EXAMG_MAX_ENTRIES];
+  const long long p0 = (long long)blockIdx.x * 64;
+  const int np = (int)(size - p0 < 64 ? size - p0 : 64);
+  const int n = np * K;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    if (TO_AOS) { const int k = t / np, i = t - k * np; tile[i * K + k] = src[(long long)k * size + p0 + i]; }
+    else tile[t] = src[p0 * K + t];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < n; t += 256) {
+    if (TO_AOS) dst[p0 * K + t] = tile[t];
+    else { const int k = t / np, i = t - k * np; dst[(long long)k * size + p0 + i] = tile[i * K + k]; }
+  }
+}
+
 // ---- halo pack / unpack ---------------------------------------------------------------------
 template <bool PACK>
 __global__ void __launch_bounds__(256) k_pack(LayoutDev l, double *x, double *buf, Box box) {
@@ -498,6 +517,19 @@ extern "C" int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, co
   if (!box_inside(lc, box, 0)) { set_error("examg_init_varcoeff7: box leaves the allocation"); return 1; }
   hipLaunchKernelGGL(k_init_varcoeff, grid_for(box.count()), dim3(256), 0, (hipStream_t)stream, make_layout(lc), cfield, make_geom(g), ExprEval{*a}, box, lc->nd);
   EXAMG_CHECK_LAUNCH("k_init_varcoeff");
+  return 0;
+}
+
+extern "C" int examg_transform_stencilfield(const examg_layout_t *lc, int nent, const double *src, double *dst, int to_entry_fastest,
+                                            examg_stream_t stream) {
+  if (!lc || !src || !dst || src == dst) { set_error("examg_transform_stencilfield: null argument, or src == dst"); return 1; }
+  if (nent < 1 || nent > EXAMG_MAX_ENTRIES) { set_error("examg_transform_stencilfield: nent %d out of range", nent); return 1; }
+  const long long size = make_layout(lc).size;
+  if (size <= 0) return 0;
+  const dim3 grid((unsigned)((size + 63) / 64));
+  if (to_entry_fastest) hipLaunchKernelGGL((k_transform_sf<true>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, size, nent);
+  else hipLaunchKernelGGL((k_transform_sf<false>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, size, nent);
+  EXAMG_CHECK_LAUNCH("k_transform_sf");
   return 0;
 }
 

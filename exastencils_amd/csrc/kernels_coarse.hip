@@ -20,7 +20,8 @@ struct StencilCG {
   long long uo[EXAMG_MAX_ENTRIES];
   double coef[EXAMG_MAX_ENTRIES];
   const double *cfield;
-  long long cplane;
+  long long cplane;   // stride between the entries of a point
+  long long cpt;      // stride between points (1: reference layout, nent: entry-fastest transformation)
 };
 
 __device__ __forceinline__ double cg_block_sum(double v, double *sm) {
@@ -49,8 +50,8 @@ __device__ __forceinline__ double cg_apply(const StencilCG &st, const LayoutDev 
   double acc;
   if (st.cfield) {
     const long long ic = lidx(lc, i0, i1, i2);
-    acc = st.cfield[ic] * u[iu + st.uo[0]];
-    for (int k = 1; k < st.nent; ++k) acc = acc + st.cfield[ic + k * st.cplane] * u[iu + st.uo[k]];
+    acc = st.cfield[ic * st.cpt] * u[iu + st.uo[0]];
+    for (int k = 1; k < st.nent; ++k) acc = acc + st.cfield[ic * st.cpt + k * st.cplane] * u[iu + st.uo[k]];
   } else {
     acc = st.coef[0] * u[iu + st.uo[0]];
     for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * u[iu + st.uo[k]];
@@ -367,10 +368,12 @@ extern "C" int examg_cg_coarse_variant(const examg_layout_t *lu_, double *sol, c
   }
   sd.cfield = st->cfield;
   sd.cplane = 0;
+  sd.cpt = 1;
   LayoutDev lc = lu;
   if (st->cfield) {
     lc = make_layout(&st->clayout);
     sd.cplane = lc.size;
+    if (st->ctransform == EXAMG_CLAYOUT_ENTRY_FASTEST) { sd.cplane = 1; sd.cpt = st->nent; }
   }
   const long long ldx = box.n0() + 2, ldxy = ldx * (box.n1() + 2), ldtot = ldxy * (box.n2() + 2);
   // the LDS copy of cgTmp0 has a zero halo: right when the box is the whole interior, so that its neighbours are exactly the

@@ -20,7 +20,8 @@ struct StencilDev {
   long long uo[EXAMG_MAX_ENTRIES];  // linear offsets in the u layout
   double coef[EXAMG_MAX_ENTRIES];
   const double *cfield;
-  long long cplane;  // doubles per coefficient plane
+  long long cplane;  // stride between the entries of a point: doubles per coefficient plane, or 1 under the entry-fastest transformation
+  long long cpt;     // stride between points: 1, or nent under the entry-fastest transformation
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -49,7 +50,7 @@ k_stencil_generic(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
     const long long iu = lidx(lu, i0, i1, i2);
     double acc;
     if (st.cfield) {
-      const long long ic = lidx(lc, i0, i1, i2);
+      const long long ic = lidx(lc, i0, i1, i2) * st.cpt;
       acc = st.cfield[ic] * u[iu + st.uo[0]];
       for (int k = 1; k < st.nent; ++k) acc = acc + st.cfield[ic + k * st.cplane] * u[iu + st.uo[k]];
       if (MODE == EXAMG_SMOOTH) {
@@ -105,6 +106,90 @@ k_stencilfield_unrolled(LayoutDev lu, const double *__restrict__ u, LayoutDev lf
     }
     if (MODE == EXAMG_RESIDUAL) acc = rhs[lidx(lf, i0, i1, i2)] - acc;
     dst[lidx(ld, i0, i1, i2)] = acc;
+  }
+}
+
+// 27-entry stencil fields under the layout transformation `[x, y, z, i] => [i, x, y, z]` (EXAMG_CLAYOUT_ENTRY_FASTEST): the 27
+// coefficients of a point are one 216-byte record, a row of the box one contiguous run of records.  A wave takes 64 consecutive
+// points: their 13.5 KiB of coefficients arrive as ONE stream of 16-byte loads (lane l takes doubles 2 (64 i + l), ..: whole
+// cache lines per wave), pass through a wave-private LDS strip (no barrier: the LDS operations of one wave execute in order) and
+// come back as the lane's own 27 values (stride 27 doubles: 54 dwords, gcd with the 64 banks is 2 -- an 8-byte read of 32 lanes
+// covers all banks once).  u: the point's 27 neighbours through L1 / L2 as in the unrolled kernel; same products in the same order.
+constexpr int SF27_WAVES = 4;
+static thread_local int g_sf27_run = -1;   // examg_debug_sf27_run (debug build): tiles per wave
+
+struct SF27Tile {
+  int x, nv, i1, i2;
+  long long rec0;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(64 * SF27_WAVES)
+k_stencilfield27_rec(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev ld,
+                     double *__restrict__ dst, LayoutDev lc, const double *__restrict__ cf, UOffsets uo, double w, Box box, int tiles_x,
+                     long long ntiles, int run) {
+  __shared__ __attribute__((aligned(16))) double strip[SF27_WAVES][64 * 27];
+  const int lane = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  // a wave takes `run` consecutive tiles; the coefficient loads of tile j + 1 are in flight while tile j is transposed and summed
+  const long long t0 = ((long long)blockIdx.x * SF27_WAVES + wv) * run;
+  if (t0 >= ntiles) return;
+  const long long t1 = min(t0 + run, ntiles);
+  const long long cend = lc.size * 27 - 2;                    // last position a 16-byte load may start at
+  auto tile_of = [&](long long tile) {
+    SF27Tile t;
+    const long long row = tile / tiles_x;
+    const int tx = (int)(tile - row * tiles_x);
+    t.i1 = box.b1 + (int)(row % box.n1());
+    t.i2 = box.b2 + (int)(row / box.n1());
+    t.x = box.b0 + tx * 64;
+    t.nv = min(64, box.e0 - t.x);
+    t.rec0 = lidx(lc, t.x, t.i1, t.i2) * 27;
+    return t;
+  };
+  auto load_raw = [&](d2 (&raw)[14], const SF27Tile &t) {
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      long long off = t.rec0 + 2 * (64 * i + lane);
+      off = off < cend ? off : cend;                          // past the tile's records: some in-bounds value nobody reads
+      raw[i] = load2(cf + off);
+    }
+  };
+  double *sb = strip[wv];
+  auto work = [&](const d2 (&raw)[14], const SF27Tile &t) {
+    const int x = t.x + (lane < t.nv ? lane : 0);
+    const long long iu = lidx(lu, x, t.i1, t.i2);
+    double v[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) v[k] = u[iu + uo.o[k]];
+    double f = 0.0;
+    if (MODE != EXAMG_APPLY) f = rhs[lidx(lf, x, t.i1, t.i2)];
+#pragma unroll
+    for (int i = 0; i < 14; ++i)
+      if (i < 13 || lane < 32) *reinterpret_cast<d2 *>(sb + 2 * (64 * i + lane)) = raw[i];
+    double c[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) c[k] = sb[27 * lane + k];
+    double acc = c[0] * v[0];
+#pragma unroll
+    for (int k = 1; k < 27; ++k) acc = acc + c[k] * v[k];
+    if (MODE == EXAMG_SMOOTH) {
+      const double ww = (1.0 / c[0]) * w;      // the centre entry comes first (dispatch condition)
+      acc = v[0] + ww * (f - acc);
+    }
+    if (MODE == EXAMG_RESIDUAL) acc = f - acc;
+    if (lane < t.nv) dst[lidx(ld, x, t.i1, t.i2)] = acc;
+  };
+  d2 ra[14], rb[14];
+  SF27Tile ta = tile_of(t0), tb = ta;
+  load_raw(ra, ta);
+  for (long long t = t0; t < t1; t += 2) {
+    if (t + 1 < t1) { tb = tile_of(t + 1); load_raw(rb, tb); }
+    work(ra, ta);
+    if (t + 1 < t1) {
+      if (t + 2 < t1) { ta = tile_of(t + 2); load_raw(ra, ta); }
+      work(rb, tb);
+    }
   }
 }
 
@@ -634,6 +719,10 @@ extern "C" int examg_debug_sf27(int unrolled) {
   g_sf27_unrolled = unrolled;
   return 0;
 }
+extern "C" int examg_debug_sf27_run(int run) {
+  g_sf27_run = run;
+  return 0;
+}
 extern "C" int examg_debug_sf27_blocks(int blocks) {
   g_sf27_blocks = blocks > 0 ? blocks : (1 << 30);
   return 0;
@@ -693,7 +782,27 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   }
 
   if (!g_force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
-      st->off[0][1] == 0 && st->off[0][2] == 0) {
+      st->off[0][1] == 0 && st->off[0][2] == 0 && st->ctransform == EXAMG_CLAYOUT_ENTRY_FASTEST && lu_->nd == 3) {
+    // transformed coefficient layout: ONE coefficient stream, transposed through LDS (k_stencilfield27_rec)
+    const LayoutDev lc27 = make_layout(&st->clayout);
+    UOffsets uo;
+    for (int k = 0; k < 27; ++k) uo.o[k] = st->off[k][0] + lu.s1 * st->off[k][1] + lu.s2 * st->off[k][2];
+    const int tiles_x = (box.n0() + 63) / 64;
+    const long long ntiles = (long long)tiles_x * box.n1() * box.n2();
+    const int run = g_sf27_run > 0 ? g_sf27_run : 2;   // 512^3: 1 tile 6.06 ms, 2 tiles 5.71, 4 tiles 5.93, 8 tiles 5.95 (tools/sf27_layouts.py)
+    const long long nwaves = (ntiles + run - 1) / run;
+    dim3 gridr((unsigned)((nwaves + SF27_WAVES - 1) / SF27_WAVES)), blockr(64, SF27_WAVES);
+#define EXAMG_SF27R(M) hipLaunchKernelGGL((k_stencilfield27_rec<M>), gridr, blockr, 0, s, lu, u, lf, rhs, ld, dst, lc27, st->cfield, uo, w, box, tiles_x, ntiles, run)
+    if (mode == EXAMG_APPLY) EXAMG_SF27R(EXAMG_APPLY);
+    else if (mode == EXAMG_RESIDUAL) EXAMG_SF27R(EXAMG_RESIDUAL);
+    else EXAMG_SF27R(EXAMG_SMOOTH);
+#undef EXAMG_SF27R
+    EXAMG_CHECK_LAUNCH("k_stencilfield27_rec");
+    return 0;
+  }
+
+  if (!g_force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
+      st->off[0][1] == 0 && st->off[0][2] == 0 && st->ctransform == EXAMG_CLAYOUT_PLANES) {
     const LayoutDev lc27 = make_layout(&st->clayout);
     UOffsets uo;
     for (int k = 0; k < 27; ++k) uo.o[k] = st->off[k][0] + lu.s1 * st->off[k][1] + lu.s2 * st->off[k][2];
@@ -719,9 +828,11 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   sd.cfield = st->cfield;
   LayoutDev lc = lu;
   sd.cplane = 0;
+  sd.cpt = 1;
   if (st->cfield) {
     lc = make_layout(&st->clayout);
     sd.cplane = lc.size;
+    if (st->ctransform == EXAMG_CLAYOUT_ENTRY_FASTEST) { sd.cplane = 1; sd.cpt = st->nent; }
   }
   const int row_w = colour >= 0 ? (box.n0() + 1) / 2 : box.n0();
   const long long total = (long long)row_w * box.n1() * box.n2();

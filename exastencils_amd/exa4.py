@@ -281,8 +281,72 @@ class Exa4Program:
                 if getattr(cf, "vec_len", 1) != len(offs):
                     raise Exa4SyntaxError("stencil field %s: %d entries but %d coefficients per point" % (sf.name, len(offs), getattr(cf, "vec_len", 1)))
                 self.stencils[(sf.name, lvl)] = Stencil(offs, [], cf.slots[0], cf.layout)
+        self._apply_layout_transformations()
+
+    def _apply_layout_transformations(self):
+        """`LayoutTransformations { transform <field>@<levels> with [x, y, z, i] => [i, x, y, z] }` on the coefficient field of a
+        stencil field (Compiler/src/exastencils/layoutTransformation/l4/L4_LayoutSection.scala; Testing/LayoutTrafo/*.exa4): the
+        entries of a point become contiguous -- APPLIED: loops read the coefficients through the transformed index
+        (EXAMG_CLAYOUT_ENTRY_FASTEST), one stream instead of one per entry.  The other directives of the reference's test programs
+        (colour splits, axis permutations, concat / rename of scalar fields) change no value either and stay recorded only: scalar
+        fields keep the reference layout, the library's contract with its callers."""
+        import re
+
+        self._sf_entry_fastest, self._sf_rec, self._sf_dirty = set(), {}, {}
+        nd = self.nd
+        src = ",".join("xyz"[:nd]) + ",i"
+        dst = "i," + ",".join("xyz"[:nd])
+        coef_of = {}
+        for sf in self.ast.sfields:
+            coef_of.setdefault(sf.field, []).append(sf)
+        for text in getattr(self.ast, "layout_transformations", []):
+            m = re.match(r"^transform (.+?) with \[(.+?)\] => \[(.+?)\]$", text.strip())
+            if not m or m.group(2).replace(" ", "") != src or m.group(3).replace(" ", "") != dst:
+                continue
+            items, depth, cur = [], 0, []
+            for tok in m.group(1).split(" "):          # items are separated by commas outside level lists
+                depth += tok == "("
+                depth -= tok == ")"
+                if tok == "," and depth == 0:
+                    items.append(cur)
+                    cur = []
+                else:
+                    cur.append(tok)
+            items.append(cur)
+            for it in items:
+                if not it:
+                    continue
+                fname, spec = it[0], " ".join(it[2:]) if len(it) > 2 and it[1] == "@" else "all"
+                for sf in coef_of.get(fname, []):
+                    lvls = self.levels_of(self._parse_level_text(spec))
+                    for lvl in lvls:
+                        if (sf.name, lvl) in self.stencils:
+                            self._sf_entry_fastest.add((sf.name, lvl))
+
+    def _parse_level_text(self, spec: str):
+        """Level specification of a LayoutTransformations item (`all`, `finest`, `4`, `(4 to finest)`) as the parser's level node."""
+        from .exa4_parser import Parser
+
+        return Parser("@ " + spec).decl_levels()
 
     def stencil(self, name: str, lvl: int) -> Stencil:
+        """The stencil as loops use it: a stencil field whose coefficient field is under the entry-fastest layout transformation is
+        handed out in that layout (re-laid out from the planes the initialisation statements write, when they have changed)."""
+        s = self._stencil_planes(name, lvl)
+        key = (name, lvl)
+        if key in getattr(self, "_sf_entry_fastest", ()) and s.cfield is not None and hasattr(self.ops, "transform_stencilfield"):
+            t = self._sf_rec.get(key)
+            if t is None:
+                t = self._sf_rec[key] = s.entry_fastest(self.ops)
+                self.launches += 1
+            elif self._sf_dirty.get(key, False):
+                self.ops.transform_stencilfield(s.clayout.c_struct(), len(s.offsets), s.cfield, t.cfield, True)
+                self.launches += 1
+            self._sf_dirty[key] = False
+            return t
+        return s
+
+    def _stencil_planes(self, name: str, lvl: int) -> Stencil:
         s = self.stencils.get((name, lvl))
         if s is None:
             sd = self._stencil_decls.get(name)
@@ -1649,9 +1713,11 @@ class Exa4Program:
         """`A:[o] = expr` for every entry of a 7/5-entry stencil field: -div(a grad) with a at the half points."""
         name = body[0][2][1]
         lvl = self._level_of(body[0][2][2], fr)
-        A = self.stencil(name, lvl)
+        A = self._stencil_planes(name, lvl)       # initialisation statements write the planes; loops get the transformed copy
         if A.cfield is None:
             raise Exa4Unsupported("%s is not a stencil field" % name)
+        if hasattr(self, "_sf_dirty"):
+            self._sf_dirty[(name, lvl)] = True
         nd = self.nd
         want = [(0, 0, 0)]
         for d in range(nd):

@@ -57,6 +57,21 @@ class Stencil:
     coefs: List[float] = _dc_field(default_factory=list)
     cfield: object = None                 # device array with len(offsets) coefficient planes, or None
     clayout: Optional[FieldLayout] = None
+    # coefficient field under the layout transformation `[x, y, z, i] => [i, x, y, z]` (EXAMG_CLAYOUT_ENTRY_FASTEST: the entries
+    # of a point contiguous -- one stream instead of len(offsets)); 0: the reference layout (entry index slowest)
+    ctransform: int = 0
+
+    def entry_fastest(self, ops) -> "Stencil":
+        """This stencil field with its coefficients re-laid out by `transform <field> with [x, y, z, i] => [i, x, y, z]`
+        (Compiler/src/exastencils/layoutTransformation/; Testing/LayoutTrafo/*.exa4): a new array, the old one is released by the
+        caller dropping this object.  Values do not change; kernels read them through the transformed index."""
+        if self.cfield is None or self.ctransform == 1:
+            return self
+        if not hasattr(ops, "transform_stencilfield"):
+            return self           # kernel layers without transformed layouts keep the reference layout (same results)
+        out = ops.new_array(len(self.offsets) * self.clayout.size)
+        ops.transform_stencilfield(self.clayout.c_struct(), len(self.offsets), self.cfield, out, True)
+        return Stencil(self.offsets, self.coefs, out, self.clayout, 1)
 
     @property
     def diag_index(self) -> int:
@@ -77,6 +92,8 @@ class Stencil:
         if self.cfield is not None:
             s.cfield = ptr_of(self.cfield)
             s.clayout = self.clayout.c_struct()
+            if hasattr(s, "ctransform"):
+                s.ctransform = int(self.ctransform)
         else:
             s.cfield = None
         return s

@@ -27,6 +27,7 @@ class StencilC(C.Structure):
         ("coef", C.c_double * MAXE),
         ("cfield", C.c_void_p),
         ("clayout", LayoutC),
+        ("ctransform", C.c_int32),
     ]
 
 
@@ -75,7 +76,7 @@ SYMBOLS = [
     "examg_comm_unique_id", "examg_comm_create", "examg_comm_destroy", "examg_comm_rank", "examg_comm_size",
     "examg_exchange_workspace_bytes", "examg_exchange", "examg_allreduce", "examg_allgather",
     "examg_jacobi2_blocks", "examg_rbgs_sweep_blocks", "examg_crand_seed", "examg_crand_draw_host",
-    "examg_residual_restrict_one_pass", "examg_residual_restrict_blocks", "examg_prolong_add_blocks",
+    "examg_transform_stencilfield", "examg_residual_restrict_one_pass", "examg_residual_restrict_blocks", "examg_prolong_add_blocks",
     "examg_comm_create_peer", "examg_comm_peer_alloc", "examg_comm_peer_connect", "examg_comm_peer_slab_bytes",
     "examg_comm_peer_gather_bytes", "examg_comm_status",
 ]
@@ -143,6 +144,7 @@ def load(path=None):
     L.examg_max_err_expr.argtypes = [lp, vp, gp, ep, ip, ip, vp, vp, vp]
     L.examg_init_varcoeff7.argtypes = [lp, vp, gp, ep, ip, ip, vp]
     L.examg_init_helmholtz27.argtypes = [lp, vp, gp, ep, C.c_double, ip, ip, vp]
+    L.examg_transform_stencilfield.argtypes = [lp, C.c_int, vp, vp, C.c_int, vp]
     L.examg_pack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_unpack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_cg_coarse.argtypes = [lp, vp, lp, vp, lp, vp, lp, vp, lp, vp, sp, gp, C.c_uint32, C.c_int, C.c_double, ip, ip, vp, vp]

@@ -195,6 +195,11 @@ class HipOps:
         check(self.L.examg_init_helmholtz27(C.byref(lc), self.ptr(cf), C.byref(geom), C.byref(fn_expr(coef_fn, params)), float(prm[1]),
                                             ivec(begin), ivec(end), self._stream()), "examg_init_helmholtz27")
 
+    def transform_stencilfield(self, lc, nent: int, src, dst, to_entry_fastest: bool):
+        """`transform <coefficient field> with [x, y, z, i] => [i, x, y, z]` (or its inverse) applied to the data."""
+        check(self.L.examg_transform_stencilfield(C.byref(lc), int(nent), self.ptr(src), self.ptr(dst), 1 if to_entry_fastest else 0,
+                                                  self._stream()), "examg_transform_stencilfield")
+
     # -- halo ------------------------------------------------------------------------------------------
     def pack(self, l, x, buf, begin, end):
         check(self.L.examg_pack(C.byref(l), self.ptr(x), self.ptr(buf), ivec(begin), ivec(end), self._stream()), "examg_pack")

@@ -600,6 +600,9 @@ class ConfigL3:
     fused_residual_norm: bool = False # single block + fused_residual_restrict: UpResidual@finest + NormResidual of the Solve loop in one pass (ConfigL4)
     fused_coarse: bool = False        # single block: VCycle_0@coarsest as one persistent kernel (examg_cg_coarse_variant)
     ksq: float = 0.0                  # stencil 'helmholtz27': shift k^2 of  -div(a grad u) - k^2 u  (config 4)
+    # stencil fields: the coefficient field under `LayoutTransformations { transform LaplaceCoeff with [x, y, z, i] => [i, x, y, z] }`
+    # (layoutTransformation/, Testing/LayoutTrafo/*.exa4): entries of a point contiguous -- ONE coefficient stream per sweep
+    coef_entry_fastest: bool = False
     rhs_from_solution: bool = False   # RHS = A * sol_fn (discrete manufactured solution)
     # InitSolution of Testing/Opts/base.exa4:166-170: Solution@finest = (double)std::rand()/RAND_MAX, drawn by every process of the
     # reference's process grid after std::srand(mpiRank) (exastencils_amd/crand.py); None: Solution starts at zero
@@ -636,11 +639,17 @@ class SolverFromL3(_Program):
                 b, e = dom.loop_bounds(nocomm)
                 ops.init_helmholtz27(nocomm.c_struct(), cf, dom.geom(l), cfg.coef_fn, (cfg.kappa, cfg.ksq), b, e)
                 self.Laplace[l] = Stencil(helmholtz27_offsets(), [], cf, nocomm)
+                if cfg.coef_entry_fastest:
+                    self.Laplace[l] = self.Laplace[l].entry_fastest(ops)
+                    del cf
             else:   # InitLaplace@l (Testing/SISC/3D_VarCoeff.exa4:206-217)
                 cf = ops.new_array((2 * nd + 1) * nocomm.size)
                 b, e = dom.loop_bounds(nocomm)
                 ops.init_varcoeff7(nocomm.c_struct(), cf, dom.geom(l), cfg.coef_fn, prm, b, e)
                 self.Laplace[l] = Stencil(stencil_field_offsets(nd), [], cf, nocomm)
+                if cfg.coef_entry_fastest:
+                    self.Laplace[l] = self.Laplace[l].entry_fastest(ops)
+                    del cf
         nc = dom.ncells(lo)
         self._func_dir: Dict[int, bool] = {}       # level -> its boundary planes hold SetFuncDir's values (FMG start), not the field's bc
         self._rb_alt, self._rb_tmp, self._one_pass = {}, {}, {}

@@ -51,7 +51,12 @@ typedef struct examg_layout {
 
 /* operator/ir/IR_Stencil.scala:34-211 (constant coefficients, entry order significant) or a
  * stencil field whose entry index is the slowest array dimension
- * (stencil/ir/IR_StencilConvolution.scala:73-95): cfield[k * size(clayout) + linear(clayout, i)]. */
+ * (stencil/ir/IR_StencilConvolution.scala:73-95): cfield[k * size(clayout) + linear(clayout, i)].
+ * ctransform: the coefficient field under a layout transformation (layoutTransformation/, the `LayoutTransformations` block of an
+ * ExaSlang-4 program, Testing/LayoutTrafo/{rbgs,opts}.exa4) -- EXAMG_CLAYOUT_ENTRY_FASTEST is `transform <field> with [x, y, z, i] => [i, x, y, z]`:
+ * the entries of a point are contiguous, cfield[linear(clayout, i) * nent + k]: ONE stream of 8 * nent bytes per point instead of
+ * nent streams (27-entry fields: 30 -> 4 streams per sweep).  A transformation changes where values live, never a value. */
+enum { EXAMG_CLAYOUT_PLANES = 0, EXAMG_CLAYOUT_ENTRY_FASTEST = 1 };
 typedef struct examg_stencil {
   int32_t nent;
   int32_t diag; /* index of the (0,0,0) entry, `diag(A)` */
@@ -59,6 +64,7 @@ typedef struct examg_stencil {
   double coef[EXAMG_MAX_ENTRIES];
   const double *cfield; /* device pointer or NULL */
   examg_layout_t clayout;
+  int32_t ctransform;   /* EXAMG_CLAYOUT_* */
 } examg_stencil_t;
 
 /* Uniform node grid of one fragment at one level: position = index * h + pos_begin
@@ -284,6 +290,11 @@ int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_g
  * (stencil/ir/IR_StencilConvolution.scala:73-95); the reference itself ships 2d+1-entry fields only. */
 int examg_init_helmholtz27(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, const examg_expr_t *a, double ksq,
                            const int32_t *begin, const int32_t *end, examg_stream_t stream);
+
+/* Apply (to_entry_fastest = 1) or undo (0) the layout transformation `[x, y, z, i] => [i, x, y, z]` of a stencil field's
+ * coefficient array: dst[linear * nent + k] <-> src[k * size(lc) + linear] over the whole allocation; src != dst. */
+int examg_transform_stencilfield(const examg_layout_t *lc, int nent, const double *src, double *dst, int to_entry_fastest,
+                                 examg_stream_t stream);
 
 /* ---- K9: halo pack / unpack (communication/ir/IR_NoInterpPacking.scala:53-83): box <-> contiguous
  * buffer, x fastest; ranges from IR_PackInfoDuplicate.scala:15-39 / IR_PackInfoGhost.scala:13-60. */

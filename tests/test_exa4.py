@@ -204,6 +204,30 @@ def test_example_jacobi_program_matches_oracle_bitwise():
     assert P.out == O.log
 
 
+TRANSFORMED = ("LayoutTransformations {\n  transform coeff@(coarsest to finest), g@finest with [x, y, z, i] => [i, x, y, z]\n"
+               "  transform r with [x, y, z] => [z, y, x]\n}\n\n")
+
+
+def transformed_varcoeff(lo, hi, ops=None):
+    """examples/exa4/varcoeff3d.exa4 under a LayoutTransformations block that puts the entries of the coefficient field first."""
+    with open(os.path.join(EX, "varcoeff3d.exa4")) as f:
+        return exa4.Exa4Program(TRANSFORMED + f.read(), dict(dimensionality=3, minLevel=lo, maxLevel=hi), ops=ops or OracleOps())
+
+
+def test_layout_transformation_of_a_coefficient_field_is_recognised():
+    """`transform coeff@.. with [x, y, z, i] => [i, x, y, z]` selects the stencil field built on that coefficient field on every level
+    named; the scalar-field directives stay recorded only.  (The CPU kernel layer has no transformed layouts: same results either way;
+    the transformation is applied on the GPU, tests/test_gpu_exa4.py.)"""
+    P = transformed_varcoeff(1, 4)
+    assert len(P.ast.layout_transformations) == 2
+    names = {n for n, _ in P._sf_entry_fastest}
+    assert len(names) == 1 and {l for _, l in P._sf_entry_fastest} == {1, 2, 3, 4}
+    P.run()
+    Q = example("varcoeff3d.exa4", 1, 4)
+    Q.run()
+    assert P.printed_values == Q.printed_values
+
+
 def test_example_varcoeff_program_matches_oracle_bitwise():
     P = example("varcoeff3d.exa4", 0, 4)
     P.run()

@@ -179,6 +179,21 @@ def test_stencil_field_entries_as_programs_equal_the_dedicated_kernel(hip, monke
     assert P.printed_values == ref.printed_values
 
 
+def test_layout_transformation_is_applied_to_the_coefficient_field(hip):
+    """SURVEY.md f-2, the reference's `LayoutTransformations` mechanism (Compiler/src/exastencils/layoutTransformation/,
+    Testing/LayoutTrafo/*.exa4): `transform coeff with [x, y, z, i] => [i, x, y, z]` re-lays the stencil field's coefficients out
+    with the entries of a point contiguous and every loop reads them through the transformed index -- the program prints what the
+    untransformed program prints, bit for bit (the reference tests its transformed programs against the same .results files)."""
+    from test_exa4 import example, transformed_varcoeff
+
+    P = transformed_varcoeff(1, 5, ops=hip)
+    P.run()
+    assert P._sf_rec and all(t.ctransform == 1 for t in P._sf_rec.values()) and len(P._sf_rec) == 5
+    Q = example("varcoeff3d.exa4", 1, 5, ops=hip)
+    Q.run()
+    assert P.printed_values == Q.printed_values
+
+
 def test_field_io_round_trip_on_gpu(hip, tmp_path):
     """examples/exa4/iotest3d.exa4 (shape of the reference's Testing/IOTest/3D_Scalar_CheckEquality_ReadAfterWrite.exa4)
     through the interpreter on device fields: ascii write / read with ghost layers, raw-double write / read, printField --
@@ -187,6 +202,23 @@ def test_field_io_round_trip_on_gpu(hip, tmp_path):
 
     P = _iotest(hip, tmp_path, level=4)
     assert P.launches >= 6
+
+
+def test_field_io_files_equal_the_cpu_run_byte_for_byte(hip, tmp_path):
+    """What writeField / printField put on disk from DEVICE fields against the files the same program writes with the oracle's loops
+    as kernel layer: ascii with ghost layers (`lock` interface), raw doubles (file per process) and the printField table -- byte for
+    byte (the field is a polynomial of the node position: the device fill is bit-exact).  Not a round trip: two independent writers."""
+    from oracle_ops import OracleOps
+    from test_exa4 import _iotest
+
+    (tmp_path / "gpu").mkdir()
+    (tmp_path / "cpu").mkdir()
+    _iotest(hip, tmp_path / "gpu", level=4)
+    _iotest(OracleOps(), tmp_path / "cpu", level=4)
+    for name in ("src_lock.txt", "src_fpp_0.bin", "src_vis.csv"):
+        a = (tmp_path / "gpu" / "data" / name).read_bytes()
+        b = (tmp_path / "cpu" / "data" / name).read_bytes()
+        assert len(a) > 0 and a == b, "%s differs between the device run and the CPU run" % name
 
 
 def test_contracting_loop_on_gpu(hip):

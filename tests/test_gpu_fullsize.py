@@ -108,8 +108,9 @@ def test_config5_512_fmg_history_vs_own_oracle(hip, fused):
     _check_solution(hip, P.Solution[kw["max_level"]], rec)
 
 
+@pytest.mark.parametrize("entry_fastest", [False, True], ids=["planes", "entry_fastest"])
 @pytest.mark.parametrize("name", ["config4_256", "config4_512"])
-def test_config4_helmholtz27_history_vs_own_oracle(hip, name):
+def test_config4_helmholtz27_history_vs_own_oracle(hip, name, entry_fastest):
     """BASELINE configs[3]'s operator at full per-GPU size: 27-entry variable-coefficient Helmholtz stencil field, Jacobi
     V(3,3) cycles to 1e-8 (parity unpinned by the reference; the oracle itself is pinned on the 7-entry stencil-field
     program Testing/SISC/3D_VarCoeff).  The coefficient profile and the manufactured solution pass through exp / sin of the
@@ -120,7 +121,10 @@ def test_config4_helmholtz27_history_vs_own_oracle(hip, name):
     rec = _fixture(name)
     kw = dict(rec["config"])
     kw["frag_len"] = tuple(kw["frag_len"])
-    P = SolverFromL3(ConfigL3(**kw), hip)
+    # entry_fastest: the coefficient fields under `transform LaplaceCoeff with [x, y, z, i] => [i, x, y, z]` (what bench.py runs):
+    # where the coefficients live changes, no value does -- the same fixture
+    P = SolverFromL3(ConfigL3(**kw, coef_entry_fastest=entry_fastest), hip)
+    assert all(A.ctransform == (1 if entry_fastest else 0) for A in P.Laplace.values())
     P.setup()
     P.Solve()
     assert P.iterations == rec["iterations"]

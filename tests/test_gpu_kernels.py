@@ -77,7 +77,7 @@ def test_fill_random_same_bits(hip, orc):
     assert -1.0 <= g[0].min() and g[0].max() < 1.0
 
 
-def _stencil_case(ops, nd, shape, st, mode, colour, b, e, ghost=1, align=0, cfn=None):
+def _stencil_case(ops, nd, shape, st, mode, colour, b, e, ghost=1, align=0, cfn=None, entry_fastest=False):
     lu = FieldLayout.node(nd, shape, ghost, align=align)
     lf = FieldLayout.node(nd, shape, 0, align=align)
     u, f, dst = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size)
@@ -89,6 +89,10 @@ def _stencil_case(ops, nd, shape, st, mode, colour, b, e, ghost=1, align=0, cfn=
         ops.fill_random(cf, 99)
         cf += 3.0       # keep the diagonal away from zero
         st = Stencil(st.offsets, [], cf, lf)
+        if entry_fastest:
+            # `transform <coefficients> with [x, y, z, i] => [i, x, y, z]`: same values, entries of a point contiguous (the oracle's
+            # kernel layer has no transformed layouts and keeps the planes -- the results must not depend on where values live)
+            st = st.entry_fastest(ops)
     w = 0.8 / st.diag if cfn is None else 0.8
     if colour >= 0:
         ops.stencil_op(mode, lu.c_struct(), u, lf.c_struct(), f, lu.c_struct(), u, st, w, colour, b, e)
@@ -479,6 +483,46 @@ def test_stencil_field_27_entries_long_rows(hip, orc, mode, n):
     b, e = [0, 1, 0], [n + 1, n, n + 1]
     g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, (n, n, n), st, mode, -1, b, e, cfn=True))
     assert_same(g, c, "27-entry stencil field fast path, interior faces")
+
+
+@pytest.mark.parametrize("mode", [APPLY, RESIDUAL, SMOOTH])
+@pytest.mark.parametrize("case", [((66, 66, 66), [1, 1, 1], [66, 66, 66]), ((130, 40, 20), [0, 1, 0], [131, 40, 21]),
+                                  ((200, 24, 12), [1, 1, 1], [200, 24, 12])])
+def test_stencil_field_27_entries_under_the_entry_fastest_layout_transformation(hip, orc, mode, case):
+    """Config 4's operator with its coefficient field transformed by `[x, y, z, i] => [i, x, y, z]` (the reference's
+    LayoutTransformations mechanism, Compiler/src/exastencils/layoutTransformation/): one 216-byte record per point, read as ONE
+    stream and transposed through LDS (k_stencilfield27_rec).  Bit-identical to the oracle on the untransformed planes."""
+    from exastencils_amd.field import helmholtz27_offsets
+
+    shape, b, e = case
+    st = Stencil(helmholtz27_offsets(), [])
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, 3, shape, st, mode, -1, b, e, cfn=True, entry_fastest=True))
+    assert_same(g, c, "27-entry stencil field, entry-fastest coefficients")
+
+
+@pytest.mark.parametrize("nd,shape", [(3, (70, 20, 12)), (3, (24, 10, 9)), (2, (80, 33, 0))])
+def test_stencil_field_entry_fastest_transformation_other_entry_counts(hip, orc, nd, shape):
+    """2d+1-entry stencil fields under the same transformation (generic kernel), all three loop kinds and a coloured half sweep."""
+    st = Stencil(stencil_field_offsets(nd), [])
+    b = [1 if d < nd else 0 for d in range(3)]
+    e = [shape[d] if d < nd else 1 for d in range(3)]
+    for mode in (APPLY, RESIDUAL, SMOOTH):
+        g, c = both(hip, orc, lambda ops: _stencil_case(ops, nd, shape, st, mode, -1, b, e, cfn=True, entry_fastest=True))
+        assert_same(g, c, "%d-entry stencil field, entry-fastest, mode %d" % (2 * nd + 1, mode))
+    g, c = both(hip, orc, lambda ops: _stencil_case(ops, nd, shape, st, SMOOTH, 1, b, e, cfn=True, entry_fastest=True))
+    assert_same(g, c, "entry-fastest, half sweep")
+
+
+def test_stencil_field_transformation_round_trip(hip):
+    l = FieldLayout.node(3, (37, 11, 6), 0)
+    for K in (7, 27):
+        a = hip.new_array(K * l.size)
+        hip.fill_random(a, 5)
+        b_, c_ = hip.new_array(K * l.size), hip.new_array(K * l.size)
+        hip.transform_stencilfield(l.c_struct(), K, a, b_, True)
+        hip.transform_stencilfield(l.c_struct(), K, b_, c_, False)
+        ah, bh = hip.to_host(a).reshape(K, l.size), hip.to_host(b_).reshape(l.size, K)
+        assert np.array_equal(bh, ah.T) and np.array_equal(hip.to_host(c_), hip.to_host(a))
 
 
 def test_empty_iteration_space_is_a_noop(hip, orc):

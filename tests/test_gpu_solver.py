@@ -50,6 +50,25 @@ def test_golden_histories_on_gpu(hip, name):
         assert abs(x - y) <= 1e-9 * abs(y) + 1e-12, (P.err_history, O.err_history)
 
 
+def test_config0_2d_poisson_at_256_squared_on_gpu(hip):
+    """BASELINE.json configs[0] at its own size: Examples/Poisson/2D_FD_Poisson_fromL4.exa4 on ONE 256 x 256-cell patch (levels 0..8,
+    5-point stencil, red-black V(3,3), CG on the coarsest level, stop at 1e-10) -- the reference ships a golden for this program on
+    4 x 4 fragments only (1024^2, above); at 256^2 the oracle's history is the yardstick: printed text identical, every residual
+    within 1e-10, max-norm errors within 1e-9."""
+    P = product_program("Poisson_2D_FD_Poisson_fromL4", hip, frag_len=(1, 1, 1))
+    assert P.domain.ncells(8)[:2] == (256, 256)
+    P.setup()
+    P.Solve()
+    O = oracle_program("Poisson_2D_FD_Poisson_fromL4", single_len=(1, 1, 1))
+    O.setup()
+    O.Solve()
+    assert P.iterations == O.iterations and P.iterations >= 5
+    assert mg.compare_with_golden(P.log, "\n".join(O.log)) == [], (P.log, O.log)
+    _close(P.res_history, O.res_history)
+    for x, y in zip(P.err_history, O.err_history):
+        assert abs(x - y) <= 1e-9 * abs(y) + 1e-12, (P.err_history, O.err_history)
+
+
 @pytest.mark.parametrize("name", ["Opts_seq", "Misc_inlining", "Opts_par"])
 def test_golden_random_start_on_gpu(hip, name):
     """The reference's random-start goldens (Testing/Opts/{seq,par}.results, Testing/Misc/inlining.results; 64^3, 512^3 and 256^3):

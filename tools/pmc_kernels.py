@@ -41,8 +41,9 @@ def cases(ops, level, with27=True, align=0):
     out = ops.new_scalar()
     # name, launch, kernel-name pattern, compulsory bytes per launch, lattice updates per launch
     cs = [
-        ("jacobi_1step", lambda: ops.stencil_op(2, L, u, F, f, L, un, A, w, -1, b, e), "k_stencil7_zmarch<2", 24 * pts, pts),
-        ("residual", lambda: ops.stencil_op(1, L, u, F, f, L, r, A, 0.0, -1, b, e), "k_stencil7_zmarch<1", 24 * pts, pts),
+        # rows of 400 .. 512 points (level 9) run the row-marching kernel, others the 128-point-window kernel
+        ("jacobi_1step", lambda: ops.stencil_op(2, L, u, F, f, L, un, A, w, -1, b, e), "k_stencil7_rowmarch<2" if 400 <= n - 1 <= 512 else "k_stencil7_zmarch<2", 24 * pts, pts),
+        ("residual", lambda: ops.stencil_op(1, L, u, F, f, L, r, A, 0.0, -1, b, e), "k_stencil7_rowmarch<1" if 400 <= n - 1 <= 512 else "k_stencil7_zmarch<1", 24 * pts, pts),
         ("rbgs_half_sweep", lambda: ops.stencil_op(2, L, u, F, f, L, u, A, w, 0, b, e), "k_stencil7_zmarch<2", 24 * pts, pts // 2),
         ("jacobi_2step", lambda: ops.jacobi2(L, u, un, None, F, f, A, w, b, e), "k_two_stage7_lds<0, false, 8, true, 1, 0", 24 * pts, 2 * pts),
         ("rbgs_fused_sweep", lambda: ops.rbgs_sweep_fused(L, u, un, F, f, A, w, 0, b, e), "k_two_stage7_lds<0, true, 8, true, 1, 0", 24 * pts, pts),
@@ -64,8 +65,8 @@ def cases(ops, level, with27=True, align=0):
         ops.fill_random(up, 201)
         ops.fill_random(fp, 202)
         Lp, Fp = lup.c_struct(), lfp.c_struct()
-        cs.insert(1, ("jacobi_1step_padded_rows", lambda: ops.stencil_op(2, Lp, up, Fp, fp, Lp, unp, A, w, -1, b, e), "k_stencil7_zmarch<2",
-                      24 * pts, pts))
+        cs.insert(1, ("jacobi_1step_padded_rows", lambda: ops.stencil_op(2, Lp, up, Fp, fp, Lp, unp, A, w, -1, b, e),
+                      "k_stencil7_rowmarch<2" if 400 <= n - 1 <= 512 else "k_stencil7_zmarch<2", 24 * pts, pts))
     if with27:
         nocomm = FieldLayout.node(3, nc, 0, False, False, align)
         cf = ops.new_array(27 * nocomm.size)
@@ -79,6 +80,10 @@ def cases(ops, level, with27=True, align=0):
         ops.fill_random(f27, 7)
         cs.append(("jacobi_27entry_field", lambda: ops.stencil_op(2, L, u, Fn, f27, L, un, A27, 0.8, -1, b, e),
                    "k_stencilfield_unrolled<2, 27>", (24 + 8 * 27) * pts, pts))
+        # the same field under `LayoutTransformations { transform <coefficients> with [x, y, z, i] => [i, x, y, z] }`: one coefficient stream
+        A27t = A27.entry_fastest(ops)
+        cs.append(("jacobi_27entry_field_entry_fastest", lambda: ops.stencil_op(2, L, u, Fn, f27, L, un, A27t, 0.8, -1, b, e),
+                   "k_stencilfield27_rec<2>", (24 + 8 * 27) * pts, pts))
     return cs, dict(u=u)
 
 
