@@ -22,6 +22,7 @@ struct StencilDev {
   const double *cfield;
   long long cplane;  // stride between the entries of a point: doubles per coefficient plane, or 1 under the entry-fastest transformation
   long long cpt;     // stride between points: 1, or nent under the entry-fastest transformation
+  int wdiv;          // smoother weight of a stencil field: 0 (1.0 / diag) * w, 1 w / diag (EXAMG_WEIGHT_*)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -54,7 +55,8 @@ k_stencil_generic(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
       acc = st.cfield[ic] * u[iu + st.uo[0]];
       for (int k = 1; k < st.nent; ++k) acc = acc + st.cfield[ic + k * st.cplane] * u[iu + st.uo[k]];
       if (MODE == EXAMG_SMOOTH) {
-        const double ww = (1.0 / st.cfield[ic + st.diag * st.cplane]) * w;
+        const double dg = st.cfield[ic + st.diag * st.cplane];
+        const double ww = st.wdiv ? w / dg : (1.0 / dg) * w;
         acc = u[iu] + ww * (rhs[lidx(lf, i0, i1, i2)] - acc);
       }
     } else {
@@ -782,7 +784,8 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   }
 
   if (!g_force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
-      st->off[0][1] == 0 && st->off[0][2] == 0 && st->ctransform == EXAMG_CLAYOUT_ENTRY_FASTEST && lu_->nd == 3) {
+      st->off[0][1] == 0 && st->off[0][2] == 0 && st->ctransform == EXAMG_CLAYOUT_ENTRY_FASTEST && lu_->nd == 3 &&
+      (mode != EXAMG_SMOOTH || st->wform == EXAMG_WEIGHT_INV_TIMES)) {
     // transformed coefficient layout: ONE coefficient stream, transposed through LDS (k_stencilfield27_rec)
     const LayoutDev lc27 = make_layout(&st->clayout);
     UOffsets uo;
@@ -802,7 +805,8 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   }
 
   if (!g_force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
-      st->off[0][1] == 0 && st->off[0][2] == 0 && st->ctransform == EXAMG_CLAYOUT_PLANES) {
+      st->off[0][1] == 0 && st->off[0][2] == 0 && st->ctransform == EXAMG_CLAYOUT_PLANES &&
+      (mode != EXAMG_SMOOTH || st->wform == EXAMG_WEIGHT_INV_TIMES)) {
     const LayoutDev lc27 = make_layout(&st->clayout);
     UOffsets uo;
     for (int k = 0; k < 27; ++k) uo.o[k] = st->off[k][0] + lu.s1 * st->off[k][1] + lu.s2 * st->off[k][2];
@@ -834,6 +838,7 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
     sd.cplane = lc.size;
     if (st->ctransform == EXAMG_CLAYOUT_ENTRY_FASTEST) { sd.cplane = 1; sd.cpt = st->nent; }
   }
+  sd.wdiv = st->wform == EXAMG_WEIGHT_DIVIDE ? 1 : 0;
   const int row_w = colour >= 0 ? (box.n0() + 1) / 2 : box.n0();
   const long long total = (long long)row_w * box.n1() * box.n2();
   long long nb = (total + 255) / 256;

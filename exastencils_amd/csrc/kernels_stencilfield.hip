@@ -190,6 +190,7 @@ bool stencilfield7_ok(const examg_layout_t *lu, const examg_stencil_t *st, const
   static const int o1[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
   if (g_sf_variant < 0 || lu->nd != 3 || st->nent != 7 || !st->cfield || st->diag != 0 || colour >= 0 || box.n0() < 64) return false;
   if (st->ctransform != EXAMG_CLAYOUT_PLANES) return false;     // transformed coefficient layouts: generic kernel
+  if (st->wform != EXAMG_WEIGHT_INV_TIMES) return false;       // `omega / diag(A)`: generic kernel
   for (int k = 0; k < 7; ++k)
     for (int d = 0; d < 3; ++d)
       if (st->off[k][d] != o1[k][d]) return false;

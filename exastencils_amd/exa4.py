@@ -113,6 +113,9 @@ _FN_ANY_DIM = {0, 16}
 _N_FN = 17
 
 
+from .exa4_fusion import LazyFusions  # noqa: E402
+
+
 # =====================================================================================================================
 # interpreter
 # =====================================================================================================================
@@ -129,7 +132,7 @@ class _Frame:
     contract: Optional[tuple] = None     # (extent, posExt, negExt) inside `repeat .. with contraction`: loops widen at interior faces
 
 
-class Exa4Program:
+class Exa4Program(LazyFusions):
     """One ExaSlang-4 program bound to a kernel layer (`ops`: HipOps on the GPU), a block decomposition and a
     communicator.  `run()` executes `Function Application`; printed lines are collected in `self.out`."""
 
@@ -187,6 +190,7 @@ class Exa4Program:
         self._bc_epoch: Dict[Tuple[str, int], int] = {}
         self._pair_tmp: Dict[Tuple[str, int], Field] = {}
         self._bc_valid = set()      # (field, level, slot) whose physical-boundary planes hold the field's Dirichlet values
+        self._lazy_init()           # pending loops of the cross-statement fusions (exastencils_amd/exa4_fusion.py)
         self._declare()
 
     # -- declarations -> objects --------------------------------------------------------------------------------------
@@ -670,15 +674,19 @@ class Exa4Program:
         if self.fuse_coarse_solver and fn.levels is not None and lvl == self.min_level and not fn.params:
             plan = self._coarse_cg_plan(fn, lvl)
             if plan is not None:
+                self._flush_pending()
                 return self._run_coarse_cg(plan)
         fr = _Frame(lvl if fn.levels is not None else None, dict(zip(fn.params, args)))
         if caller is not None and "__x" in caller.vars:      # point expression: coordinates stay visible in callees
             for c in ("__x", "__y", "__z"):
                 fr.vars.setdefault(c, caller.vars[c])
         try:
-            self._exec_block(fn.body, fr)
+            self._exec_block(fn.body, fr, fn=True)
         except _Return as r:
             return r.value
+        finally:
+            if not self._cont:
+                self._flush_pending()     # back at the caller of the interpreter: every field holds what the program says
         return None
 
     # -- hipGraph capture of a function call ----------------------------------------------------------------------------------
@@ -729,11 +737,19 @@ class Exa4Program:
         self._cg_limit_seen = n
 
     # -- statements -----------------------------------------------------------------------------------------------------
-    def _exec_block(self, body: list, fr: _Frame):
-        i = 0
-        while i < len(body):
-            self._exec(body[i], fr)
-            i += 1
+    def _exec_block(self, body: list, fr: _Frame, loop: bool = False, fn: bool = False):
+        """loop: the list is a loop body that may run again; fn: a function body (a `return` ends here).  The stack of active lists
+        is what the liveness scan of the cross-statement fusions walks (exa4_fusion.py: _dead_after)."""
+        entry = [body, 0, fr, loop, fn]
+        self._cont.append(entry)
+        try:
+            i = 0
+            while i < len(body):
+                entry[1] = i
+                self._exec(body[i], fr)
+                i += 1
+        finally:
+            self._cont.pop()
 
     def _field(self, e, fr: _Frame) -> Tuple[Field, int]:
         if e[0] != "fld":
@@ -755,6 +771,8 @@ class Exa4Program:
 
     def _exec(self, s, fr: _Frame):
         k = s[0]
+        if self._pending is not None and self._gate(s, fr):
+            return
         if k == "decl":
             fr.vars[s[1]] = self._eval(s[2], fr) if s[2] is not None else 0
         elif k == "assign":
@@ -786,14 +804,14 @@ class Exa4Program:
             for it in range(n):
                 if s[2]:
                     fr.vars[s[2]] = it
-                self._exec_block(s[3], fr)
+                self._exec_block(s[3], fr, loop=True)
             if s[2]:
                 fr.vars[s[2]] = n
         elif k == "contract":
             self._exec_contract(s, fr)
         elif k == "until":
             while not self._eval(s[1], fr):
-                self._exec_block(s[2], fr)
+                self._exec_block(s[2], fr, loop=True)
         elif k == "if":
             self._exec_block(s[2] if self._eval(s[1], fr) else s[3], fr)
         elif k == "color":
@@ -833,13 +851,14 @@ class Exa4Program:
         D, ds = self._field(lhs, fr)
         U, us = self._field(src, fr)
         F, fs = self._field(r[0], fr)
-        return D, ds, U, us, F, fs, r[1], self._smoother_weight(wexpr, r[1], fr)
+        wv, A = self._smoother_weight(wexpr, r[1], fr)
+        return D, ds, U, us, F, fs, A, wv
 
     @staticmethod
     def _canonical7(A: Stencil, nd: int) -> bool:
         return nd == 3 and A.cfield is None and len(A.offsets) == 7 and all(sum(1 for c in o if c) <= 1 for o in A.offsets)
 
-    def _try_fused_sweep(self, body, first: int, fr: _Frame) -> bool:
+    def _try_fused_sweep(self, body, first: int, fr: _Frame, only_field=None, zero_input: bool = False, correction_from=None) -> bool:
         """`color with { (i0+i1+i2) % 2, [communicate u] loop over u { u += w (f - A u) } [apply bc to u] }` on one block:
         both half sweeps in one pass (examg_rbgs_sweep_fused), out of place into a second array that carries the same
         boundary shell, then the two arrays change roles.  `apply bc` re-writes position-only Dirichlet values the sweep
@@ -858,6 +877,10 @@ class Exa4Program:
             return False
         D, ds, U, us, F, fs, A, w = m
         if D is not U or ds != us or not self._canonical7(A, self.nd) or U.layout.inner[0] < self.fuse_min_row:
+            return False
+        if only_field is not None and U is not only_field:
+            return False        # a pending `u = 0` / `u += P * uc` rides along with the sweep of the same field only
+        if (zero_input or correction_from is not None) and multi:
             return False
         if multi and U.num_slots != 1:
             return False
@@ -892,7 +915,15 @@ class Exa4Program:
                 tmp = self._pair_tmp[(U.name, U.level)] = Field(U.name + "Tmp", U.level, U.layout, self.ops, 1, None)
             self._alt[key] = rbgs_sweep(self.ops, self.comm, self.domain, U, F, A, w, alt, tmp, first)
             return True
-        self.ops.rbgs_sweep_fused(U.lc, U.data(us), alt, F.lc, F.data(fs), A, w, first, b, e)
+        if zero_input:
+            # `u = 0.0` just before: the sweep takes the zero field as a constant, the zeroing loop never runs (examg_rbgs_sweep_fused_zero)
+            self.ops.rbgs_sweep_fused_zero(U.lc, alt, F.lc, F.data(fs), A, w, first, b, e)
+        elif correction_from is not None:
+            # `u += P@coarser * u@coarser` just before: interpolated while u is loaded (examg_rbgs_sweep_fused_prolong)
+            X, xs = correction_from
+            self.ops.rbgs_sweep_fused_prolong(U.lc, U.data(us), alt, F.lc, F.data(fs), A, w, first, b, e, X.lc, X.data(xs))
+        else:
+            self.ops.rbgs_sweep_fused(U.lc, U.data(us), alt, F.lc, F.data(fs), A, w, first, b, e)
         self._alt[key], U.slots[us] = U.slots[us], alt
         return True
 
@@ -1245,6 +1276,10 @@ class Exa4Program:
     def _apply_bc(self, f: Field, slot: int):
         if f.bc_fn is None:
             return
+        if self.fuse and (f.name, f.level, slot) in self._bc_valid:
+            # Dirichlet values are functions of the position: the planes already hold exactly what this statement would write (every
+            # writer of boundary planes -- `loop over .. only ..`, readField -- takes the entry out of _bc_valid) -- no launch, no bit changes
+            return
         self._bc_valid.add((f.name, f.level, slot))
         mask = self.domain.face_mask()
         if mask:
@@ -1336,6 +1371,9 @@ class Exa4Program:
             return self._exec_compare_loop(cmp_, boxes, fr)
         if colour is None and self._is_check_loop(body):
             return self._exec_check_loop(body, boxes, fr)
+        if (len(body) == 1 and len(boxes) == 1 and colour is None and only is None and where is None and fr.contract is None
+                and self._try_defer(body[0], f, boxes[0], fr)):
+            return      # absorbed by a one-pass form later, or run when the next statement could tell the difference
         for st in body:
             if st[0] != "assign":
                 raise Exa4Unsupported("statement %r inside a loop body" % st[0])
@@ -1583,14 +1621,20 @@ class Exa4Program:
             return None
         return e[2], m[2], m[4]
 
-    def _smoother_weight(self, w, A: Stencil, fr: _Frame) -> float:
+    def _smoother_weight(self, w, A: Stencil, fr: _Frame):
+        """(omega, stencil as the kernel needs it): a stencil field carries the FORM of the weight -- the kernels evaluate per point
+        what the statement says, `(1.0 / diag(A)) * omega` (Testing/SISC/3D_VarCoeff.exa4:145) or `omega / diag(A)`
+        (Testing/PolyExpl/RBGS3Dvc.exa4:52); the two round differently."""
         if A.cfield is None:
-            return float(self._eval(w, fr))
-        # stencil field: the kernel forms ((1.0 / diag) * omega) per point (Testing/SISC/3D_VarCoeff.exa4:145)
+            return float(self._eval(w, fr)), A
         if (w[0] == "bin" and w[1] == "*" and w[2][0] == "bin" and w[2][1] == "/" and w[2][2] == ("num", 1.0)
                 and w[2][3][0] == "call" and w[2][3][1] == "diag" and self._is_scalar(w[3])):
-            return float(self._eval(w[3], fr))
-        raise Exa4Unsupported("smoother weight on a stencil field must read ((1.0 / diag(A)) * omega)")
+            return float(self._eval(w[3], fr)), A
+        if w[0] == "bin" and w[1] == "/" and w[3][0] == "call" and w[3][1] == "diag" and self._is_scalar(w[2]):
+            import dataclasses
+
+            return float(self._eval(w[2], fr)), dataclasses.replace(A, wform=1)
+        raise Exa4Unsupported("smoother weight on a stencil field must read ((1.0 / diag(A)) * omega) or (omega / diag(A))")
 
     def _exec_point_assign(self, st, b, e, colour, fr: _Frame):
         op, lhs, rhs = st[1], st[2], st[3]
@@ -1659,7 +1703,7 @@ class Exa4Program:
         F, fs = self._field(r[0], fr)
         U, us = self._field(src, fr)
         A = r[1]
-        wv = self._smoother_weight(w, A, fr)
+        wv, A = self._smoother_weight(w, A, fr)
         in_place = D is U and ds == us
         if in_place and colour is None:
             raise Exa4Unsupported("in-place smoother update without colouring (lexicographic Gauss-Seidel)")

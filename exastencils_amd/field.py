@@ -60,6 +60,8 @@ class Stencil:
     # coefficient field under the layout transformation `[x, y, z, i] => [i, x, y, z]` (EXAMG_CLAYOUT_ENTRY_FASTEST: the entries
     # of a point contiguous -- one stream instead of len(offsets)); 0: the reference layout (entry index slowest)
     ctransform: int = 0
+    # smoother weight of a stencil field as the statement writes it: 0 `(1.0 / diag(A)) * omega`, 1 `omega / diag(A)` (EXAMG_WEIGHT_*)
+    wform: int = 0
 
     def entry_fastest(self, ops) -> "Stencil":
         """This stencil field with its coefficients re-laid out by `transform <field> with [x, y, z, i] => [i, x, y, z]`
@@ -71,7 +73,7 @@ class Stencil:
             return self           # kernel layers without transformed layouts keep the reference layout (same results)
         out = ops.new_array(len(self.offsets) * self.clayout.size)
         ops.transform_stencilfield(self.clayout.c_struct(), len(self.offsets), self.cfield, out, True)
-        return Stencil(self.offsets, self.coefs, out, self.clayout, 1)
+        return Stencil(self.offsets, self.coefs, out, self.clayout, 1, self.wform)
 
     @property
     def diag_index(self) -> int:
@@ -94,6 +96,8 @@ class Stencil:
             s.clayout = self.clayout.c_struct()
             if hasattr(s, "ctransform"):
                 s.ctransform = int(self.ctransform)
+            if hasattr(s, "wform"):
+                s.wform = int(self.wform)
         else:
             s.cfield = None
         return s

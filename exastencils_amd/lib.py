@@ -28,6 +28,7 @@ class StencilC(C.Structure):
         ("cfield", C.c_void_p),
         ("clayout", LayoutC),
         ("ctransform", C.c_int32),
+        ("wform", C.c_int32),
     ]
 
 

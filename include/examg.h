@@ -65,7 +65,13 @@ typedef struct examg_stencil {
   const double *cfield; /* device pointer or NULL */
   examg_layout_t clayout;
   int32_t ctransform;   /* EXAMG_CLAYOUT_* */
+  /* smoother weight of a stencil FIELD (EXAMG_SMOOTH with cfield): how the statement writes it.  EXAMG_WEIGHT_INV_TIMES:
+   * `((1.0 / diag(A)) * omega)` (Testing/SISC/3D_VarCoeff.exa4:145) -- per point (1.0 / c_diag) * w;  EXAMG_WEIGHT_DIVIDE:
+   * `(omega / diag(A))` (Testing/PolyExpl/RBGS3Dvc.exa4:52) -- per point w / c_diag.  Both round differently; the kernels evaluate
+   * what the program says.  Constant stencils take the folded literal in `w` and ignore this. */
+  int32_t wform;
 } examg_stencil_t;
+enum { EXAMG_WEIGHT_INV_TIMES = 0, EXAMG_WEIGHT_DIVIDE = 1 };
 
 /* Uniform node grid of one fragment at one level: position = index * h + pos_begin
  * (grid/ir/IR_VF_NodePosition.scala:109-111, domain/ir/IR_DomainFromAABB.scala:31-40). */

@@ -47,6 +47,8 @@ typedef struct {
   double coef[ORC_MAX_ENTRIES];
   const double *cfield;               /* NULL => constant coefficients */
   orc_layout_t clayout;
+  int32_t wform;                      /* stencil field, smoother weight as written: 0 ((1.0 / diag) * omega), 1 (omega / diag)
+                                         (Testing/SISC/3D_VarCoeff.exa4:145; Testing/PolyExpl/RBGS3Dvc.exa4:52) */
 } orc_stencil_t;
 
 static inline int lay_tot(const orc_layout_t *l, int d) {
@@ -96,7 +98,8 @@ enum { ORC_APPLY = 0, ORC_RESIDUAL = 1, ORC_SMOOTH = 2 };
     else {                                                                                               \
       /* const: w is the folded constant omega/diag; stencil field:                                      \
        * ((1.0 / diag) * omega) as written in Testing/SISC/3D_VarCoeff.exa4 Smoother */                 \
-      const double ww = cf ? ((1.0 / cf[cbase + i0 + (ptrdiff_t)st->diag * cplane]) * w) : w;            \
+      const double dg_ = cf ? cf[cbase + i0 + (ptrdiff_t)st->diag * cplane] : 1.0;                       \
+      const double ww = cf ? (st->wform ? (w / dg_) : ((1.0 / dg_) * w)) : w;                            \
       out = u[iu] + ww * (rhs[fbase + i0] - acc);                                                        \
     }                                                                                                    \
     dst[dbase + i0] = out;                                                                               \

@@ -50,6 +50,7 @@ class StencilC(C.Structure):
         ("coef", C.c_double * MAXE),
         ("cfield", C.c_void_p),
         ("clayout", LayoutC),
+        ("wform", C.c_int32),
     ]
 
 

@@ -70,6 +70,7 @@ class OracleOps:
             C.memmove(C.byref(s.clayout), C.byref(lc), C.sizeof(mg.LayoutC))
         else:
             s.cfield = None
+        s.wform = int(getattr(st, "wform", 0))
         return s
 
     def stencil_op(self, mode, lu, u, lf, rhs, ld, dst, st, w, colour, begin, end):

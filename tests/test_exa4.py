@@ -551,6 +551,65 @@ def test_reference_contracting_loop_programs(prog, know):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_reference_rbgs3dvc_program_runs():
+    """Testing/PolyExpl/RBGS3Dvc.exa4 as it is, on a 32^3 array (its 256^3 takes minutes on the CPU): a 7-entry stencil FIELD with two
+    ghost layers, coloured `where` loops in place under `repeat 2 times with contraction`, and the smoother weight written as
+    `0.8 / diag(Laplace)` -- evaluated per point as w / c_diag (EXAMG_WEIGHT_DIVIDE; Testing/SISC/3D_VarCoeff writes (1.0 / diag) * w,
+    which rounds differently).  The program puts a 256^3 array on level 0 of a unit cube (grid width 1): its coefficient function
+    exp(kappa (x - x^2)(y - y^2)(z - z^2)) underflows to 0 away from the first planes, so the sweep divides by zero by the program's
+    own arithmetic and its CheckSolution loop reports that; what is pinned here: every statement is inside the subset, the lines of
+    Testing/PolyExpl/all.results appear in order, and `fuse=False` prints the same."""
+    base = os.path.join(REF, "Testing", "PolyExpl")
+    k = knowledge.parse_file(os.path.join(base, "3D_f0.knowledge"))
+    k["testing_enabled"] = True
+    with open(os.path.join(base, "RBGS3Dvc.exa4")) as f:
+        src = f.read().replace("innerPoints = [ 256, 256, 256 ]", "innerPoints = [ 32, 32, 32 ]")
+    outs = []
+    for fuse in (True, False):
+        P = exa4.Exa4Program(src, k, ops=OracleOps(), fuse=fuse)
+        outs.append(P.run())
+    with open(os.path.join(base, "all.results")) as f:
+        want = [l for l in f.read().splitlines() if l.strip()]
+    assert [l for l in outs[0] if not l.startswith("ERROR")] == want
+    assert outs[0] == outs[1]
+
+
+LIVE_RESIDUAL = """  loop over f@coarser {
+    f@coarser = R * r
+  }
+  Var chk : Real = 0.0
+  loop over r with reduction ( + : chk ) {
+    chk += r * r
+  }
+"""
+
+
+def test_cross_statement_fusions_of_the_interpreter():
+    """exastencils_amd/exa4_fusion.py: residual + restriction, residual + norm (never-stored residual, proven dead by the liveness
+    scan), `u@coarser = 0` absorbed by the first sweep, correction folded into the first post-smoothing sweep -- reached from
+    examples/exa4/poisson3d_rbgs.exa4, whose statements are spread over Cycle / Sweeps / Defect / Norm.  Same printed values bit for
+    bit as one launch per statement; fewer launches.  With a statement that READS the residual after the restriction the residual
+    is stored again (no residual + restriction fusion), and the values stay the same."""
+    P = example("poisson3d_rbgs.exa4", 2, 6)
+    P.fuse_min_row, P.fused_prolong_min_points, P.fuse_residual_norm = 16, 0, True
+    P.run()
+    Q = example("poisson3d_rbgs.exa4", 2, 6, fuse=False)
+    Q.run()
+    assert P.printed_values == Q.printed_values and len(P.printed_values) >= 5
+    assert all(P.fusions[k] > 0 for k in ("residual_restrict", "residual_norm", "zero_start", "folded_correction")), P.fusions
+    assert P.launches < Q.launches
+    with open(os.path.join(EX, "poisson3d_rbgs.exa4")) as f:
+        src = f.read()
+    assert "  loop over f@coarser {\n    f@coarser = R * r\n  }\n" in src
+    live = src.replace("  loop over f@coarser {\n    f@coarser = R * r\n  }\n", LIVE_RESIDUAL)
+    L = exa4.Exa4Program(live, dict(dimensionality=3, minLevel=2, maxLevel=6), ops=OracleOps())
+    L.fuse_min_row, L.fused_prolong_min_points, L.fuse_residual_norm = 16, 0, True
+    L.run()
+    assert L.fusions["residual_restrict"] == 0 and L.fusions["residual_norm"] > 0
+    assert L.printed_values == Q.printed_values
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
 @pytest.mark.parametrize("name", ["3D_Scalar", "2D_Scalar", "2D_LayoutTrafo"])
 def test_reference_io_programs_pass_their_round_trips(name, tmp_path, monkeypatch):
     """Testing/IOTest/<name>_CheckEquality_ReadAfterWrite.{exa4,knowledge}, as they are: write, read back and compare through the

@@ -39,8 +39,16 @@ def test_rbgs_program_on_gpu(hip):
     assert P.launches > 300
     plain = example("poisson3d_rbgs.exa4", 2, 7, ops=hip, fuse=False)
     plain.run()
-    assert plain.printed_values == P.printed_values              # fused sweeps change no bit
+    assert plain.printed_values == P.printed_values              # fused sweeps / cross-statement fusions change no bit
     assert plain.launches > P.launches
+    assert P.fusions["residual_restrict"] > 0
+    # opt-in: residual + norm in one pass -- the squares are summed in the residual kernel's order: same fields, norms to rounding
+    N = example("poisson3d_rbgs.exa4", 2, 7, ops=hip)
+    N.fuse_residual_norm = True
+    N.run()
+    assert N.fusions["residual_norm"] > 0
+    _close(N.printed_values, P.printed_values, P.printed_values[0])
+    assert np.array_equal(hip.to_host(N.fields[("u", 7)].data()), hip.to_host(P.fields[("u", 7)].data()))
 
 
 def test_native_rand_fill_on_gpu(hip):

@@ -40,8 +40,19 @@ t_graph = timed(g.replay)
 S = SolverFromL4(ConfigL4(nd=3, min_level=lo, max_level=hi, tol=1e-6, fused_coarse=False), ops)
 S.setup()
 t_drv = timed(lambda: S.mgCycle(hi))
-S2 = SolverFromL4(ConfigL4(nd=3, min_level=lo, max_level=hi, tol=1e-6, fused_coarse=True, fused_rbgs=True), ops)
+S2 = SolverFromL4(ConfigL4(nd=3, min_level=lo, max_level=hi, tol=1e-6, fused_coarse=True, fused_rbgs=True, fused_residual_restrict=True,
+                           fused_prolong_min_points=50_000_000, fused_zero_start=True, fused_residual_norm=True), ops)
 S2.setup()
-t_fused = timed(lambda: S2.mgCycle(hi))
-print(json.dumps({"levels": [lo, hi], "interpreted_cycle_ms": t_int, "launches_per_cycle": per_cycle, "interpreted_cycle_graph_replay_ms": t_graph, "driver_cycle_ms": t_drv,
-                  "driver_fused_cycle_ms": t_fused}))
+S2.capture_cycle()
+t_fused = timed(S2.replay_cycle)
+# the same program, one launch per statement (no peepholes, no cross-statement fusions): printed values must agree bit for bit
+Q = exa4.Exa4Program(open(os.path.join(ROOT, "examples", "exa4", "poisson3d_rbgs.exa4")).read(),
+                     dict(dimensionality=3, minLevel=lo, maxLevel=hi), ops=ops, fuse=False, fuse_coarse_solver=True)
+R = exa4.Exa4Program(open(os.path.join(ROOT, "examples", "exa4", "poisson3d_rbgs.exa4")).read(),
+                     dict(dimensionality=3, minLevel=lo, maxLevel=hi), ops=ops)
+Q.run()
+R.run()
+print(json.dumps({"levels": [lo, hi], "interpreted_cycle_ms": t_int, "launches_per_cycle": per_cycle, "interpreted_cycle_graph_replay_ms": t_graph,
+                  "driver_cycle_ms": t_drv, "driver_all_fusions_graph_replay_ms": t_fused, "fusions": P.fusions,
+                  "printed_values_equal_unfused": Q.printed_values == R.printed_values, "solve_iterations": len(R.printed_values) - 1,
+                  "launches_whole_solve_fused": R.launches, "launches_whole_solve_unfused": Q.launches}))
