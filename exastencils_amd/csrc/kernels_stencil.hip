@@ -611,6 +611,12 @@ static bool rowmarch_wanted(const Box &box, int colour) {
   if (g_rm_on == 1) return fits;
   return fits && box.n1() >= 64 && box.n2() >= 16;
 }
+// padded layouts (even strides) keep the window kernel: it starts its windows on a 16-byte boundary there and every access is
+// aligned already (512^3, 544-double rows: 0.570 ms against 0.589 for the row-marching kernel)
+static bool rowmarch_layout(const LayoutDev &lu, const LayoutDev &lf, const LayoutDev &ld) {
+  const bool even = !(lu.s1 & 1) && !(lu.s2 & 1) && !(lf.s1 & 1) && !(lf.s2 & 1) && !(ld.s1 & 1) && !(ld.s2 & 1);
+  return g_rm_on == 1 || !even;
+}
 
 template <int MODE, int ORDER>
 static int launch_rowmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld, double *dst,
@@ -634,7 +640,7 @@ static thread_local int g_zm_blocks = -1, g_zm_minchunk = -1, g_zm_remap = -1, g
 template <int MODE, int ORDER>
 static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1, int max_waves = 0) {
-  if (rowmarch_wanted<MODE>(box, colour)) {
+  if (rowmarch_wanted<MODE>(box, colour) && rowmarch_layout(lu, lf, ld)) {
     if (MODE != ZM_RESNORM) return launch_rowmarch<MODE == ZM_RESNORM ? EXAMG_RESIDUAL : MODE, ORDER>(lu, u, lf, rhs, ld, dst, k, w, box, s);
   }
   ZMarchGeom g;

@@ -61,78 +61,13 @@ from .layout import FieldLayout
 from .exa4_parser import (Exa4SyntaxError, Exa4Unsupported, FunctionDecl, Parser, _COORD, _GRIDW, _MATH, _arith,  # noqa: F401
                           _colour_cond, _conjuncts, _const_value, _contains, _find_calls, _has_coord, _lower_cond, _parity_expr, _walk)
 
-APPLY, RESIDUAL, SMOOTH = 0, 1, 2
-
-
-# =====================================================================================================================
-# analytic point functions: python mirror of eval_fn (exastencils_amd/csrc/examg_common.h), used for recognition only
-# =====================================================================================================================
-def fn_eval(fn: int, p: Sequence[float], x: float, y: float, z: float) -> float:
-    PI = math.pi
-    k = p[0] if p else 0.0
-    if fn == 0:
-        return 0.0
-    if fn == 1:
-        return ((x * x) - ((0.5 * y) * y)) - ((0.5 * z) * z)
-    if fn == 2:
-        return math.cos(PI * x) - math.sin((2.0 * PI) * y)
-    if fn == 3:
-        return (PI * PI) * math.cos(PI * x) - ((4.0 * (PI * PI)) * math.sin((2.0 * PI) * y))
-    if fn == 4:
-        return k * (((x - (x * x)) * (y - (y * y))) * (z - (z * z)))
-    if fn == 5:
-        return (2.0 * k) * ((((x - (x * x)) * (y - (y * y))) + ((x - (x * x)) * (z - (z * z)))) + ((y - (y * y)) * (z - (z * z))))
-    if fn == 6:
-        return 1.0 - math.exp((-1.0 * k) * (((x - (x * x)) * (y - (y * y))) * (z - (z * z))))
-    if fn == 7:
-        return math.exp(k * (((x - (x * x)) * (y - (y * y))) * (z - (z * z))))
-    if fn == 8:
-        return (math.sin(PI * x) * math.sin(PI * y)) * math.sinh((math.sqrt(2.0) * PI) * z)
-    if fn == 9:
-        return (math.sin(PI * x) * math.sin(PI * y)) * math.sin(PI * z)
-    if fn == 10:
-        return k * ((x - (x * x)) * (y - (y * y)))
-    if fn == 11:
-        return (2.0 * k) * ((x - (x * x)) + (y - (y * y)))
-    if fn == 12:
-        return 1.0 - math.exp((-1.0 * k) * ((x - (x * x)) * (y - (y * y))))
-    if fn == 13:
-        return math.exp(k * ((x - (x * x)) * (y - (y * y))))
-    if fn == 14:
-        return (x * x) - (y * y)
-    if fn == 15:
-        return math.sin(PI * x) * math.sinh(PI * y)
-    if fn == 16:
-        return x * x
-    raise ValueError("function id %d" % fn)
-
-
-_FN_WITH_PARAM = {4, 5, 6, 7, 10, 11, 12, 13}
-_FN_2D_ONLY = {2, 3, 10, 11, 12, 13, 14, 15}     # ignore z
-_FN_ANY_DIM = {0, 16}
-_N_FN = 17
-
-
+from .exa4_common import (APPLY, RESIDUAL, SMOOTH, _FN_2D_ONLY, _FN_ANY_DIM, _FN_WITH_PARAM, _N_FN, _Frame, _Return, fn_eval)  # noqa: E402,F401
+from .exa4_builtins import Builtins  # noqa: E402
 from .exa4_fusion import LazyFusions  # noqa: E402
+from .exa4_peepholes import Peepholes  # noqa: E402
 
 
-# =====================================================================================================================
-# interpreter
-# =====================================================================================================================
-class _Return(Exception):
-    def __init__(self, value):
-        self.value = value
-
-
-@dataclass
-class _Frame:
-    level: Optional[int]
-    vars: Dict[str, object]
-    colour: Optional[int] = None
-    contract: Optional[tuple] = None     # (extent, posExt, negExt) inside `repeat .. with contraction`: loops widen at interior faces
-
-
-class Exa4Program(LazyFusions):
+class Exa4Program(LazyFusions, Peepholes, Builtins):
     """One ExaSlang-4 program bound to a kernel layer (`ops`: HipOps on the GPU), a block decomposition and a
     communicator.  `run()` executes `Function Application`; printed lines are collected in `self.out`."""
 
@@ -516,150 +451,6 @@ class Exa4Program(LazyFusions):
             return self.call(name, lvl if lvl is not None else fr.level, [self._eval(a, fr) for a in args], fr)
         return self._builtin(name, [self._eval(a, fr) for a in args], fr)
 
-    # -- field I/O ---------------------------------------------------------------------------------------
-    def _field_io(self, name: str, args: list, fr: _Frame):
-        """printField / writeField / readField [ _lock | _fpp ] ( "file", field [, includeGhost [, binary [, condition [, separator ]]]] )
-        (Compiler/src/exastencils/field/ir/IR_PrintField.scala:38-110, IR_ReadField / IR_WriteField; argument order as in
-        Testing/IOTest/3D_Scalar_CheckEquality_ReadAfterWrite.exa4:78-100).  "$blockId" in the file name becomes the rank.
-        Blocks of a decomposition write one after the other into the same file (the reference's MPI_Sequential, "lock"
-        interface); the data leave / enter the device through the kernel layer's to_host / from_host."""
-        from . import io as xio
-
-        base, iface = (name.split("_") + ["lock"])[:2]
-        pos = [i for i, a in enumerate(args) if a[0] == "fld"]
-        if not pos:
-            raise Exa4Unsupported("%s without a field argument" % name)
-        f, slot = self._field(args[pos[0]], fr)
-        fname = str(self._eval(args[0], fr)).replace("$blockId", str(self.domain.rank))
-        rest = [self._eval(a, fr) for a in args[pos[0] + 1:]]
-        if iface in ("hdf5", "nc", "mpiio", "sion"):
-            # write/readField_hdf5 ( file, dataset, field ), _nc ( file, variable, field [, includeGhost] ), _mpiio ( file, field ),
-            # _sion ( file, field [, includeGhost [, condition]] ) (IOTest:115-168).  Those libraries are not part of this image: the
-            # values go to `file` as the raw doubles of the lock / fpp interfaces -- the same round trip, not those file formats
-            if base == "printField":
-                raise Exa4Unsupported("%s: visualisation output of the %s interface" % (name, iface))
-            include_ghost = bool(rest[0]) if rest and iface in ("nc", "sion") else False
-            binary, condition, separator = True, (rest[1] if len(rest) > 1 and iface == "sion" else True), " "
-        else:
-            include_ghost = bool(rest[0]) if len(rest) > 0 else False
-            binary = bool(rest[1]) if len(rest) > 1 else (base != "printField" and iface != "lock")
-            condition = rest[2] if len(rest) > 2 else True
-            separator = str(rest[3]) if len(rest) > 3 else " "
-        if not isinstance(condition, bool):
-            raise Exa4Unsupported("%s: only constant conditions" % name)
-        d = os.path.dirname(fname)
-        if d and self.domain.rank == 0:
-            os.makedirs(d, exist_ok=True)
-        dist = getattr(self.comm, "dist", None)
-        shared = dist is not None and "$blockId" not in str(self._eval(args[0], fr))
-        self.ops.synchronize()
-        for turn in range(self.domain.world_size if shared else 1):
-            if not shared or turn == self.domain.rank:
-                if not condition:
-                    if base != "readField" and turn == 0:
-                        open(fname, "w").close()
-                elif base == "readField":
-                    if shared and self.domain.world_size > 1:
-                        raise Exa4Unsupported("readField from one file shared by several blocks")
-                    if binary:
-                        xio.read_field(fname, f, self.ops, slot, include_ghost)
-                    else:
-                        xio.read_field_ascii(fname, f, self.ops, slot, include_ghost, separator)
-                elif binary:
-                    if shared and self.domain.world_size > 1:
-                        raise Exa4Unsupported("binary writeField into one file shared by several blocks")
-                    xio.write_field(fname, f, self.ops, slot, include_ghost)
-                else:
-                    xio.print_field(fname, f, self.ops, self.domain, slot, include_ghost, separator, None, append=shared and turn > 0,
-                                    precision=int(self.k.get("field_printFieldPrecision", -1)))
-            if shared:
-                dist.barrier()
-        if base == "readField":
-            self._bc_valid.discard((f.name, f.level, slot))       # whatever the boundary planes held, the file's values replace it
-            self._bc_epoch[(f.name, f.level)] = self._bc_epoch.get((f.name, f.level), 0) + 1
-        return None
-
-    def _range(self, name: str, push: bool):
-        torch = getattr(self.ops, "torch", None)
-        if torch is None or getattr(getattr(self.ops, "device", None), "type", "cpu") == "cpu":
-            return
-        try:
-            if push:
-                torch.cuda.nvtx.range_push(name)
-            else:
-                torch.cuda.nvtx.range_pop()
-        except Exception:       # profiler ranges are an aid, never a reason to stop a program
-            pass
-
-    # -- built-in statements ----------------------------------------------------------------------------------------------
-    def _emit(self, line: str):
-        self.out.append(line)
-        if self.echo and self.domain.rank == 0:
-            print(line, flush=True)
-
-    def _fmt(self, v) -> str:
-        if isinstance(v, bool):
-            return "true" if v else "false"
-        if isinstance(v, float):
-            return "%.*g" % (self._precision, v)
-        return str(v)
-
-    def _builtin(self, name: str, args: list, fr: _Frame):
-        from .solver import reduced_prec
-
-        if name == "print":
-            self.printed_values += [a for a in args if isinstance(a, float)]
-            self._emit(" ".join(self._fmt(a) for a in args))
-        elif name == "printWithReducedPrec":
-            self.printed_values.append(float(args[0]))
-            self._emit(reduced_prec(float(args[0])))
-        elif name == "native" and re.fullmatch(r"\s*std::srand\s*\(\s*(\d+)\s*\)\s*;?\s*", str(args[0])):
-            from .crand import CRand
-
-            seed = int(re.search(r"\d+", str(args[0])).group(0))      # native('std::srand(42)') (Testing/PolyExpl/Jac3Dcc.exa4:33)
-            if getattr(self, "_crand", None) is None:
-                self._crand = CRand(seed)
-            else:
-                self._crand.seed(seed)
-        elif name == "native":
-            m = re.search(r"cout\.precision\((\w+)\)", str(args[0]))
-            if m and "oldPrec =" not in str(args[0]):
-                self._precision = int(m.group(1)) if m.group(1).isdigit() else 6
-        elif name == "startTimer":
-            # IR_Stopwatch (Compiler/src/exastencils/timing/ir/IR_Stopwatch.scala:31-84): wall-clock timer; on the GPU also a
-            # profiler range of the same name (roctx, through torch.cuda.nvtx), so rocprofv3 --marker-trace shows the program's
-            # own timers around the kernels they enclose
-            self.ops.synchronize()
-            self._range(str(args[0]), True)
-            self._timer_start[args[0]] = time.perf_counter()
-        elif name == "stopTimer":
-            self.ops.synchronize()
-            self._range(str(args[0]), False)
-            self.timers[args[0]] = self.timers.get(args[0], 0.0) + time.perf_counter() - self._timer_start.pop(args[0])
-        elif name == "printAllTimers":
-            for key, val in self.timers.items():
-                self._emit("Mean mean total time for Timer %s: %g" % (key, val * 1e3))
-        elif name == "getTotalTime" or name == "getTotalFromTimer":
-            return self.timers.get(args[0], 0.0) * 1e3
-        elif name == "exit":
-            raise SystemExit(int(args[0]) if args else 0)
-        elif name in ("initGlobals", "initDomain", "initGeometry", "destroyGlobals", "initFieldsWithZero"):
-            pass        # fields are allocated zeroed at declaration (initFieldsWithZero)
-        elif name in ("benchmarkStart", "benchmarkStop"):
-            pass        # likwid / time markers of Benchmark/run_benchmark.py: the timers around them carry the numbers
-        elif name == "printJSON":
-            # printJSON ( "file", 'key', value, ... ) (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:273-276)
-            doc = {str(args[i]): args[i + 1] for i in range(1, len(args) - 1, 2)}
-            self.json_results[str(args[0])] = doc
-            if self.json_dir is not None and self.domain.rank == 0:
-                import json
-
-                with open(os.path.join(self.json_dir, str(args[0])), "w") as fh:
-                    json.dump(doc, fh)
-        else:
-            raise Exa4Unsupported("function %s" % name)
-        return None
-
     # -- functions ------------------------------------------------------------------------------------------------------
     def _resolve(self, name: str, lvl: Optional[int]) -> FunctionDecl:
         for fn in self.functions[name]:
@@ -835,444 +626,6 @@ class Exa4Program(LazyFusions):
         else:
             raise Exa4SyntaxError("statement %r" % (k,))
 
-    # -- peepholes: same results bit for bit, fewer passes over HBM ---------------------------------------------------------
-    def _match_smoother(self, st, fr: _Frame):
-        """(D, dslot, U, uslot, F, fslot, A, w) if `st` is a damped-residual update  D = U + w * (F - A * U)."""
-        if st[0] != "assign" or st[2][0] != "fld":
-            return None
-        op, lhs, rhs = st[1], st[2], st[3]
-        src = wexpr = r = None
-        if op == "+=" and rhs[0] == "bin" and rhs[1] == "*":
-            src, wexpr, r = lhs, rhs[2], self._residual_form(rhs[3], fr)
-        elif op == "=" and rhs[0] == "bin" and rhs[1] == "+" and rhs[2][0] == "fld" and rhs[3][0] == "bin" and rhs[3][1] == "*":
-            src, wexpr, r = rhs[2], rhs[3][2], self._residual_form(rhs[3][3], fr)
-        if r is None or not self._same_access(src, r[2], fr):
-            return None
-        D, ds = self._field(lhs, fr)
-        U, us = self._field(src, fr)
-        F, fs = self._field(r[0], fr)
-        wv, A = self._smoother_weight(wexpr, r[1], fr)
-        return D, ds, U, us, F, fs, A, wv
-
-    @staticmethod
-    def _canonical7(A: Stencil, nd: int) -> bool:
-        return nd == 3 and A.cfield is None and len(A.offsets) == 7 and all(sum(1 for c in o if c) <= 1 for o in A.offsets)
-
-    def _try_fused_sweep(self, body, first: int, fr: _Frame, only_field=None, zero_input: bool = False, correction_from=None) -> bool:
-        """`color with { (i0+i1+i2) % 2, [communicate u] loop over u { u += w (f - A u) } [apply bc to u] }` on one block:
-        both half sweeps in one pass (examg_rbgs_sweep_fused), out of place into a second array that carries the same
-        boundary shell, then the two arrays change roles.  `apply bc` re-writes position-only Dirichlet values the sweep
-        never touches, so it is a no-op here."""
-        multi = self.domain.world_size != 1
-        if multi and not any(st[0] == "comm" and st[2] in ("all", "ghost") for st in body):
-            return False        # blocks with neighbours: the fused form contains the exchanges of the statement list
-        loops = [st for st in body if st[0] == "loop"]
-        if len(loops) != 1 or any(st[0] not in ("loop", "comm", "applybc") for st in body):
-            return False
-        lp = loops[0]
-        if lp[2] is not None or lp[3] is not None or lp[4] is not None or len(lp[5]) != 1:
-            return False
-        m = self._match_smoother(lp[5][0], fr)
-        if m is None:
-            return False
-        D, ds, U, us, F, fs, A, w = m
-        if D is not U or ds != us or not self._canonical7(A, self.nd) or U.layout.inner[0] < self.fuse_min_row:
-            return False
-        if only_field is not None and U is not only_field:
-            return False        # a pending `u = 0` / `u += P * uc` rides along with the sweep of the same field only
-        if (zero_input or correction_from is not None) and multi:
-            return False
-        if multi and U.num_slots != 1:
-            return False
-        for st in body:
-            if st[0] in ("comm", "applybc") and self._field(st[-1], fr)[0] is not U:
-                return False
-        if U.bc_fn is not None and (U.name, U.level, us) not in self._bc_valid:
-            return False        # boundary planes not known to hold the Dirichlet values yet: the plain path applies them
-        b, e = self.domain.loop_bounds(self._field(lp[1], fr)[0].layout)
-        key = (U.name, U.level, us)
-        alt = self._alt.get(key)
-        if alt is None:
-            alt = self._alt[key] = self.ops.new_array(U.layout.size)
-        if self._alt_shell.get(key) != self._bc_epoch.get((U.name, U.level), 0):
-            lay = U.layout      # the shell (everything outside the loop's box) comes from the field itself
-            gb = [lay.idx("GLB", d) if d < self.nd else 0 for d in range(3)]
-            ge = [lay.idx("GRE", d) if d < self.nd else 1 for d in range(3)]
-            self.ops.axpby(U.lc, U.data(us), U.lc, alt, 1.0, 0.0, gb, ge)
-            self._alt_shell[key] = self._bc_epoch.get((U.name, U.level), 0)
-            self.launches += 1
-        self.launches += 1
-        if multi:
-            # fused deep interior + two-point shell with its exchanges on a side stream (exastencils_amd/smoothers.py): rbgs_sweep
-            # exchanges ghost layers only -- a `communicate u` (duplicate + ghost) in the body keeps its duplicate part here
-            from .smoothers import rbgs_sweep
-
-            if any(st[0] == "comm" and st[2] == "all" for st in body):
-                self.comm.exchange(U, us, "dup")
-
-            tmp = self._pair_tmp.get((U.name, U.level))
-            if tmp is None:
-                tmp = self._pair_tmp[(U.name, U.level)] = Field(U.name + "Tmp", U.level, U.layout, self.ops, 1, None)
-            self._alt[key] = rbgs_sweep(self.ops, self.comm, self.domain, U, F, A, w, alt, tmp, first)
-            return True
-        if zero_input:
-            # `u = 0.0` just before: the sweep takes the zero field as a constant, the zeroing loop never runs (examg_rbgs_sweep_fused_zero)
-            self.ops.rbgs_sweep_fused_zero(U.lc, alt, F.lc, F.data(fs), A, w, first, b, e)
-        elif correction_from is not None:
-            # `u += P@coarser * u@coarser` just before: interpolated while u is loaded (examg_rbgs_sweep_fused_prolong)
-            X, xs = correction_from
-            self.ops.rbgs_sweep_fused_prolong(U.lc, U.data(us), alt, F.lc, F.data(fs), A, w, first, b, e, X.lc, X.data(xs))
-        else:
-            self.ops.rbgs_sweep_fused(U.lc, U.data(us), alt, F.lc, F.data(fs), A, w, first, b, e)
-        self._alt[key], U.slots[us] = U.slots[us], alt
-        return True
-
-    def _try_jacobi_pairs(self, body, n: int, fr: _Frame) -> bool:
-        """`repeat n times { Smoother ( ) }` with Smoother = [communicate ghost of u<active>; loop over u { u<next> =
-        u<active> + w (f - A u<active>) }; advance u]: consecutive pairs as one pass over HBM (exastencils_amd/smoothers.py)."""
-        if len(body) != 1 or body[0][0] != "callstmt":
-            return False
-        c = body[0][1]
-        if c[1] not in self.functions or c[3]:
-            return False
-        lvl = self._level_of(c[2], fr) if c[2] is not None else fr.level
-        fn = self._resolve(c[1], lvl)
-        fb = fn.body
-        if len(fb) != 3 or fb[0][0] != "comm" or fb[1][0] != "loop" or fb[2][0] != "advance":
-            return False
-        if fb[0][2] != "ghost":
-            return False        # jacobi_pair exchanges ghost layers only: `communicate u` / `communicate dup of u` keep the plain path
-        cfr = _Frame(lvl if fn.levels is not None else None, {})
-        lp = fb[1]
-        if lp[2] is not None or lp[3] is not None or lp[4] is not None or len(lp[5]) != 1:
-            return False
-        m = self._match_smoother(lp[5][0], cfr)
-        if m is None:
-            return False
-        D, ds, U, us, F, fs, A, w = m
-        if D is not U or U.num_slots != 2 or us != U.active or ds != U.next or A.cfield is not None:
-            return False
-        if self._field(fb[0][3], cfr) != (U, us) or self._field(fb[2][1], cfr)[0] is not U or self._field(lp[1], cfr)[0] is not U:
-            return False
-        # the pair reads the boundary planes of <active> in both steps; the two plain steps read those of <next> in the
-        # second: only equal when both slots are known to hold the same boundary values
-        if U.bc_fn is not None:
-            if not all((U.name, U.level, sl) in self._bc_valid for sl in range(2)):
-                return False
-        elif self._bc_epoch.get((U.name, U.level), 0) != 0:
-            return False
-        from .smoothers import jacobi_pair
-
-        key = (U.name, U.level)
-        tmp = self._pair_tmp.get(key)
-        if tmp is None:
-            tmp = self._pair_tmp[key] = Field(U.name + "Tmp", U.level, U.layout, self.ops, 1, None)
-        k = n
-        while k >= 2:
-            self.launches += 1
-            jacobi_pair(self.ops, self.comm, self.domain, U, F, A, w, tmp)
-            k -= 2
-        if k:
-            self._exec_block(body, fr)
-        return True
-
-    # -- `repeat n times with contraction [..] { loop ..; advance .. }` (temporal blocking with deep ghost layers) ------------
-    def _exec_contract(self, s, fr: _Frame):
-        """IR_ContractingLoop.expandSpecial (baseExt/ir/IR_ContractingLoop.scala:130-196): the loop is unrolled; the k-th
-        `loop over` of the unrolled sequence runs on bounds widened by (total - 1 - k) x the contraction at interior faces, so
-        that no exchange is needed inside.  Slotted Jacobi bodies run as two-step passes (examg_jacobi2_boxes: first step on
-        the box widened by e, second on the box widened by e - 1) -- the reference's own use of the construct
-        (Testing/PolyExpl/Jac3Dcc.exa4:27: 5 ghost layers, 5 steps)."""
-        _, nexpr, counter, pos, neg, body = s
-        n = int(self._eval(nexpr, fr))
-        if any(st[0] not in ("loop", "advance") for st in body):
-            raise Exa4Unsupported("repeat ... with contraction: body may hold `loop over` and `advance` statements only")
-        nloops = sum(1 for st in body if st[0] == "loop")
-        expand = n * nloops - 1
-        it = 0
-        if self.fuse and counter is None and nloops == 1 and len(body) == 2 and body[0][0] == "loop" and body[1][0] == "advance":
-            m = self._contract_pair_plan(body, fr)
-            while m is not None and n - it >= 2:
-                U, F, A, w, tmp = m
-                lb, le = self.domain.loop_bounds(U.layout)
-                b1, e1 = self._contract_bounds(U.layout, lb, le, expand, pos, neg)
-                b2, e2 = self._contract_bounds(U.layout, lb, le, expand - 1, pos, neg)
-                self.launches += 1
-                self.ops.jacobi2_boxes(U.lc, U.data(U.active), U.data(U.next), tmp.data(), F.lc, F.data(), A, w, b1, e1, b2, e2)
-                U.advance()
-                expand -= 2
-                it += 2
-        saved = fr.contract
-        try:
-            for k in range(it, n):
-                if counter:
-                    fr.vars[counter] = k
-                for st in body:
-                    if st[0] == "loop":
-                        fr.contract = (expand, pos, neg)
-                        self._exec_loop(st, fr)
-                        expand -= 1
-                    else:
-                        self._exec(st, fr)
-        finally:
-            fr.contract = saved
-        if counter:
-            fr.vars[counter] = n
-
-    def _contract_pair_plan(self, body, fr: _Frame):
-        """(U, F, A, w, scratch) if body is `loop over U { U<next> = U<active> + w (F - A U<active>) }; advance U` on a two-slot
-        field with constant coefficients whose two slots hold the same boundary values (same condition as _try_jacobi_pairs)."""
-        lp = body[0]
-        if lp[2] is not None or lp[3] is not None or lp[4] is not None or len(lp[5]) != 1:
-            return None
-        m = self._match_smoother(lp[5][0], fr)
-        if m is None:
-            return None
-        D, ds, U, us, F, fs, A, w = m
-        if D is not U or U.num_slots != 2 or us != U.active or ds != U.next or A.cfield is not None:
-            return None
-        if self._field(body[1][1], fr)[0] is not U or self._field(lp[1], fr)[0] is not U:
-            return None
-        # both slots must carry the same values on the physical boundary planes (the pass reads <active>'s in both steps):
-        # either `apply bc` put the field's Dirichlet values into both, or nothing has written them since the zero fill
-        valid = [(U.name, U.level, sl) in self._bc_valid for sl in range(2)]
-        untouched = self._bc_epoch.get((U.name, U.level), 0) == 0 and not any(valid)
-        if not (untouched or (U.bc_fn is not None and all(valid))):
-            return None
-        key = (U.name, U.level)
-        tmp = self._pair_tmp.get(key)
-        if tmp is None:
-            tmp = self._pair_tmp[key] = Field(U.name + "Tmp", U.level, U.layout, self.ops, 1, None)
-        return U, F, A, w, tmp
-
-    # -- coarse-grid CG as one kernel ---------------------------------------------------------------------------------------
-    def _inline(self, body, lvl: int, depth: int = 0):
-        """Statement list with calls to parameterless, value-less functions of the same level replaced by their bodies."""
-        out = []
-        for st in body:
-            if st[0] == "callstmt" and st[1][1] in self.functions and not st[1][3] and depth < 4:
-                c = st[1]
-                clvl = self._level_of(c[2], _Frame(lvl, {})) if c[2] is not None else lvl
-                fn = self._resolve(c[1], clvl)
-                if clvl != lvl or fn.params or any(x[0] == "return" for x in fn.body):
-                    return None
-                sub = self._inline(fn.body, lvl, depth + 1)
-                if sub is None:
-                    return None
-                out += sub
-            else:
-                out.append(st)
-        return out
-
-    def _norm_of(self, e, fr: _Frame):
-        """Field R if `e` is a call of a function  { Var s = 0; loop over R with reduction(+ : s) { s += R * R }; return sqrt(s) }."""
-        if e[0] != "call" or e[1] not in self.functions or e[3]:
-            return None
-        lvl = self._level_of(e[2], fr) if e[2] is not None else fr.level
-        b = self._resolve(e[1], lvl).body
-        if len(b) != 3 or b[0][0] != "decl" or b[1][0] != "loop" or b[2][0] != "return":
-            return None
-        var, lp = b[0][1], b[1]
-        if lp[2] is not None or lp[4] != ("+", var) or len(lp[5]) != 1 or b[2][1] != ("call", "sqrt", None, [("id", var, None)]):
-            return None
-        if lp[3] is not None and any(_lower_cond(c) is None for c in _conjuncts(lp[3])):
-            return None
-        st = lp[5][0]
-        if st[0] != "assign" or st[1] != "+=" or st[2] != ("id", var, None):
-            return None
-        r = st[3]
-        cfr = _Frame(lvl, {})
-        if r[0] == "bin" and r[1] == "*" and self._same_access(r[2], r[3], cfr) and self._same_access(r[2], lp[1], cfr):
-            return self._field(r[2], cfr)[0]
-        return None
-
-    def _coarse_cg_plan(self, fn: FunctionDecl, lvl: int):
-        key = (fn.name, lvl)
-        if key not in self._cg_plans:
-            try:
-                self._cg_plans[key] = self._match_coarse_cg(fn, lvl)
-            except (Exa4SyntaxError, Exa4Unsupported, IndexError, KeyError, TypeError):
-                self._cg_plans[key] = None
-        return self._cg_plans[key]
-
-    def _match_coarse_cg(self, fn: FunctionDecl, lvl: int):
-        """The conjugate-gradient solver the reference's generator emits for `mgCycle@coarsest`
-        (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:152-201), recognised statement by statement -- and the form its layer-3
-        solver generator writes (Function VCycle_0@coarsest, Testing/Smoothers/Jac.exa4:75-109): alpha = res * res / alphaDenom
-        with the norm carried over instead of a sum of squares, both vector updates in one loop, no `apply bc` statements, the
-        solution possibly slotted (accessed through <active> only)."""
-        if self.domain.world_size != 1 or not hasattr(self.ops, "cg_coarse"):
-            return None
-        if self.domain.face_mask() != (1 << (2 * self.nd)) - 1:
-            return None         # a periodic block is its own neighbour: the solver's `communicate` statements do something
-        body = self._inline(fn.body, lvl)
-        if body is None:
-            return None
-        fr = _Frame(lvl, {})
-        pos = [0]
-
-        def peek():
-            return body[pos[0]] if pos[0] < len(body) else ("end",)
-
-        def take():
-            pos[0] += 1
-            return body[pos[0] - 1]
-
-        def loop1(st):        # plain loop with one assignment
-            if st[0] == "loop" and st[2] is None and st[3] is None and st[4] is None and len(st[5]) == 1 and st[5][0][0] == "assign":
-                return st[5][0]
-            return None
-
-        def fld(e):
-            return self._field(e, fr)[0]
-
-        def active_only(e):       # a slotted field may take part if the solver touches its active slot only
-            return e[0] == "fld" and e[2] in (None, "active", "activeSlot", "current", "currentSlot")
-
-        def opt_comm(F):
-            if peek()[0] == "comm" and fld(peek()[3]) is F:
-                take()
-
-        def opt_bc(F):
-            if peek()[0] == "applybc" and fld(peek()[1]) is F:
-                take()
-                return True
-            return False
-
-        # communicate u; r = f - A u; apply bc to r
-        if peek()[0] == "comm":
-            take()
-        a = loop1(take())
-        rf = self._residual_form(a[3], fr) if a and a[1] == "=" else None
-        if rf is None:
-            return None
-        R, F, A, U = fld(a[2]), fld(rf[0]), rf[1], fld(rf[2])
-        if not active_only(rf[2]):
-            return None
-        bc_r = opt_bc(R)
-        opt_comm(R)
-        # Var rr = Norm(); Var rr0 = rr
-        d1, d2 = take(), take()
-        if d1[0] != "decl" or self._norm_of(d1[2], fr) is not R or d2[0] != "decl" or d2[2] != ("id", d1[1], None):
-            return None
-        rr, rr0 = d1[1], d2[1]
-        # p = r; apply bc to p
-        a = loop1(take())
-        if not a or a[1] != "=" or a[3][0] != "fld" or fld(a[3]) is not R:
-            return None
-        P = fld(a[2])
-        bc_p = opt_bc(P)
-        if peek()[0] == "decl" and pos[0] + 1 < len(body) and body[pos[0] + 1][0] == "repeat" and body[pos[0] + 1][2] == peek()[1]:
-            take()                                          # Var curStep : Integer = 0 -- the repeat's counter
-        rep = take()
-        if rep[0] != "repeat" or pos[0] < len(body) and not all(x[0] == "callstmt" and x[1][1] == "print" for x in body[pos[0]:]):
-            return None
-        max_it = int(self._eval(rep[1], fr))
-        tail = body[pos[0]:]                                # print statements after the loop: reached when it runs out of iterations
-        body, pos[0] = self._inline(rep[3], lvl), 0
-        if body is None:
-            return None
-        opt_comm(P)
-        a = loop1(take())                                   # q = A p
-        m = self._sten_times_field(a[3], fr) if a and a[1] == "=" else None
-        if m is None or m[1] != "stencil" or m[0] != 1.0 or m[2] is not A or fld(m[4]) is not P:
-            return None
-        Q = fld(a[2])
-
-        def reduction(x, y):                                # Var v = 0; loop ... reduction(+ : v) { v += x * y }; [Var w = v]
-            d = take()
-            lp = take()
-            if d[0] != "decl" or lp[0] != "loop" or lp[2] is not None or lp[4] != ("+", d[1]) or len(lp[5]) != 1:
-                return None
-            if lp[3] is not None and any(_lower_cond(c) is None for c in _conjuncts(lp[3])):
-                return None
-            st = lp[5][0]
-            if st[0] != "assign" or st[1] != "+=" or st[2] != ("id", d[1], None) or st[3][0] != "bin" or st[3][1] != "*":
-                return None
-            if {id(fld(st[3][2])), id(fld(st[3][3]))} != {id(x), id(y)}:
-                return None
-            name = d[1]
-            if peek()[0] == "decl" and peek()[2] == ("id", name, None):
-                name = take()[1]
-            return name
-
-        sq = lambda v: ("bin", "*", ("id", v, None), ("id", v, None))
-        mark = pos[0]
-        num = reduction(R, R)
-        from_norm = num is None                             # no sum of squares: alpha's numerator is the squared norm
-        if from_norm:
-            pos[0] = mark
-        den = reduction(P, Q)
-        d = take()
-        if not den or d[0] != "decl" or d[2] != ("bin", "/", sq(rr) if from_norm else ("id", num, None), ("id", den, None)):
-            return None
-        alpha = d[1]
-        st = take()
-        if st[0] == "loop" and st[2] is None and st[3] is None and st[4] is None and len(st[5]) == 2 and all(x[0] == "assign" for x in st[5]):
-            a, a2 = st[5]                                   # both updates in one loop
-            bc_u = False
-        else:
-            a = loop1(st)
-            bc_u = None
-        # u += alpha p
-        if (not a or a[1] != "+=" or not active_only(a[2]) or fld(a[2]) is not U or a[3] != ("bin", "*", ("id", alpha, None), a[3][3])
-                or fld(a[3][3]) is not P):
-            return None
-        if bc_u is None:
-            bc_u = opt_bc(U)
-            a2 = loop1(take())
-        a = a2                                              # r -= alpha q
-        if not a or a[1] != "-=" or fld(a[2]) is not R or a[3] != ("bin", "*", ("id", alpha, None), a[3][3]) or fld(a[3][3]) is not Q:
-            return None
-        if opt_bc(R) != bc_r:
-            return None
-        d = take()                                          # Var rrNew = Norm()
-        if d[0] != "decl" or self._norm_of(d[2], fr) is not R:
-            return None
-        new = d[1]
-        c = take()                                          # if ( rrNew <= tol * rr0 ) { return }
-        if (c[0] != "if" or c[3] or len(c[2]) != 1 or c[2][0] != ("return", None) or c[1][0] != "bin" or c[1][1] != "<="
-                or c[1][2] != ("id", new, None) or c[1][3][0] != "bin" or c[1][3][1] != "*" or c[1][3][3] != ("id", rr0, None)):
-            return None
-        tol = float(self._eval(c[1][3][2], fr))
-        d = take()                                          # Var beta = (rrNew * rrNew) / (rr * rr)
-        if d[0] != "decl" or d[2] != ("bin", "/", sq(new), sq(rr)):
-            return None
-        beta = d[1]
-        a = loop1(take())                                   # p = r + beta p
-        if (not a or a[1] != "=" or fld(a[2]) is not P or a[3][0] != "bin" or a[3][1] != "+" or a[3][2][0] != "fld" or fld(a[3][2]) is not R
-                or a[3][3] != ("bin", "*", ("id", beta, None), a[3][3][3]) or fld(a[3][3][3]) is not P):
-            return None
-        if opt_bc(P) != bc_p:
-            return None
-        if take() != ("assign", "=", ("id", rr, None), ("id", new, None)) or pos[0] != len(body):
-            return None
-        # the kernel applies homogeneous Dirichlet values to r, p and u on every face, or leaves every boundary plane alone: the
-        # program must do one or the other
-        from .lib import CG_ALPHA_FROM_NORM, CG_NO_BC
-
-        flags = CG_ALPHA_FROM_NORM if from_norm else 0
-        if not (bc_r or bc_p or bc_u):
-            flags |= CG_NO_BC
-        else:
-            for fld_, has in ((R, bc_r), (P, bc_p), (U, bc_u)):
-                if not has or fld_.bc_fn != 0:
-                    return None
-        if any(x.num_slots != 1 for x in (F, R, P, Q)) or (U.num_slots != 1 and not flags & CG_NO_BC):
-            return None
-        return U, F, R, P, Q, A, max_it, tol, tail, flags
-
-    def _run_coarse_cg(self, plan):
-        U, F, R, P, Q, A, max_it, tol, tail, flags = plan
-        b, e = self.domain.loop_bounds(U.layout)
-        if not hasattr(self, "_cg_info"):
-            self._cg_info = self.ops.new_array(4)
-        self._cg_tail = (tail, U.level)
-        self.launches += 1
-        self.ops.cg_coarse(U.lc, U.data(), F.lc, F.data(), R.lc, R.data(), P.lc, P.data(), Q.lc, Q.data(), A,
-                           self.domain.geom(U.level), self.domain.face_mask(), max_it, tol, b, e, self._cg_info, flags=flags)
-        return None
-
     def _apply_bc(self, f: Field, slot: int):
         if f.bc_fn is None:
             return
@@ -1383,210 +736,6 @@ class Exa4Program(LazyFusions):
                 self._bc_valid -= {(tf.name, tf.level, sl) for sl in range(tf.num_slots)}
             for b, e in boxes:
                 self._exec_point_assign(st, b, e, colour, fr)
-
-    # `loop over F sequentially { F = native("((double)std::rand()/RAND_MAX)") }` (Testing/Opts/base.exa4:166-170): the generated
-    # loop nest calls the C library's rand() once per point, x fastest, in every process after std::srand(mpiRank); the values come
-    # from libexamg's restatement of glibc's generator (exastencils_amd/crand.py), written on the host and uploaded.
-    @staticmethod
-    def _is_std_rand(e) -> bool:
-        return (e[0] == "call" and e[1] == "native" and len(e[3]) == 1 and e[3][0][0] == "str"
-                and e[3][0][1].replace(" ", "") == "((double)std::rand()/RAND_MAX)")
-
-    def _exec_rand_fill(self, targets, boxes, fr: _Frame):
-        """One loop whose statements all draw from std::rand(): every point draws once per statement, in statement order."""
-        from .crand import CRand, random_start
-
-        fs = [self._field(t, fr) for t in targets]
-        f, slot = fs[0]
-        b, e = self.domain.loop_bounds(f.layout)
-        if len(boxes) != 1 or list(boxes[0][0]) != list(b) or list(boxes[0][1]) != list(e):
-            raise Exa4Unsupported("std::rand() start values on a restricted iteration space")
-        if any(g.layout.shape_zyx != f.layout.shape_zyx for g, _ in fs):
-            raise Exa4Unsupported("std::rand() start values for fields of different layouts in one loop")
-        merged = self._merged_blocks[0] if self._merged_blocks is not None else None
-        gen = getattr(self, "_crand", None)
-        if merged is not None and (gen is not None or getattr(self, "_rand_drawn", False)):
-            raise Exa4Unsupported("merged blocks: one loop drawing from std::rand(), with the default seeding")
-        if merged is None and gen is None:      # this process' generator: seeded by the generated main() (rank; 1 without MPI)
-            gen = self._crand = CRand(self.domain.rank if self.domain.world_size > 1 else 1)
-        self._rand_drawn = True
-        random_start(self.ops, f, slot, self.domain, merged, generator=gen, more_targets=fs[1:])
-        self.launches += 1
-
-    # `loop over B sequentially { Var d : Real = fabs ( B - A ); if ( d > tol ) { print ( ... ) ... return v } }`
-    # (Testing/IOTest/3D_Scalar_CheckEquality_ReadAfterWrite.exa4:25-33): a search for the first point where two fields differ by
-    # more than a tolerance.  One difference loop and one max-reduction on the device decide whether such a point exists; only then
-    # are the fields brought to the host to find the first one in loop order for the program's messages and its `return`.
-    def _match_compare_loop(self, body, fr: _Frame):
-        if len(body) != 2 or body[0][0] != "decl" or body[1][0] != "if" or body[1][3]:
-            return None
-        name, init = body[0][1], body[0][2]
-        if init is None or init[0] != "call" or init[1] not in ("fabs", "abs") or len(init[3]) != 1:
-            return None
-        d = init[3][0]
-        if d[0] != "bin" or d[1] != "-" or d[2][0] != "fld" or d[3][0] != "fld":
-            return None
-        cond, guards = None, []      # `diff > tol`, possibly and-ed with conditions that do not depend on the point
-        for c in _conjuncts(body[1][1]):
-            if c[0] == "bin" and c[1] in (">", ">=") and c[2] == ("id", name, None) and self._is_scalar(c[3]) and cond is None:
-                cond = c
-            elif self._is_scalar(c) and ("id", name, None) not in list(_walk(c)) and not any(
-                    x[0] == "id" and x[1] in ("i0", "i1", "i2") for x in _walk(c)):
-                guards.append(c)
-            else:
-                return None
-        if cond is None:
-            return None
-        if not all(bool(self._eval(gd, fr)) for gd in guards):
-            return ("skip",)
-        then = body[1][2]
-        if not then or then[-1][0] != "return" or any(st[0] not in ("callstmt", "return") for st in then):
-            return None
-        return d[2], d[3], cond[1], cond[3], then
-
-    def _exec_compare_loop(self, m, boxes, fr: _Frame):
-        import numpy as np
-
-        if m == ("skip",):
-            return
-        ea, eb, op, tol_e, then = m
-        A, sa = self._field(ea, fr)
-        B, sb = self._field(eb, fr)
-        tol = float(self._eval(tol_e, fr))
-        if not hasattr(self, "_cmp_tmp") or self._cmp_tmp.numel() < A.layout.size:
-            self._cmp_tmp = self.ops.new_array(A.layout.size)
-        worst = 0.0
-        for b, e in boxes:
-            self.ops.axpby(A.lc, A.data(sa), A.lc, self._cmp_tmp, 1.0, 0.0, b, e)            # tmp = A
-            self.ops.axpby(B.lc, B.data(sb), A.lc, self._cmp_tmp, -1.0, 1.0, b, e)           # tmp -= B
-            t = self.ops.max_err_fn(A.lc, self._cmp_tmp, self.domain.geom(A.level), 0, (), b, e)
-            self.launches += 3
-            worst = max(worst, self.ops.scalar_value(self.comm.allreduce(t, "max")))
-        if not (worst > tol if op == ">" else worst >= tol):
-            return
-        # a point beyond the tolerance exists: the first one in loop order (x fastest) on this block, for the program's messages
-        ha = self.ops.to_host(A.data(sa)).reshape(A.layout.shape_zyx)
-        hb = self.ops.to_host(B.data(sb)).reshape(B.layout.shape_zyx)
-        for b, e in boxes:
-            sl = tuple(slice(A.layout.ref(d) + b[d], A.layout.ref(d) + e[d]) for d in (2, 1, 0))
-            bad = np.argwhere(np.abs(ha[sl] - hb[sl]) > tol if op == ">" else np.abs(ha[sl] - hb[sl]) >= tol)
-            if len(bad):
-                k2, k1, k0 = (int(v) for v in bad[0])
-                vals = {"i0": b[0] + k0, "i1": b[1] + k1, "i2": b[2] + k2}
-                self._cmp_point = (vals, float(ha[sl][k2, k1, k0]), float(hb[sl][k2, k1, k0]))
-                break
-        self._exec_block_at_point(then, fr, A, sa, B, sb)
-
-    # A loop that writes no field -- point-wise `Var`s and `if ( cond ) { print ( ... ) }` -- is a check of the data, not part of the
-    # hot path (Testing/PolyExpl/Jac3Dcc.exa4:58-65: `Var s = Solution<active> * Solution<nextSlot>; if (s == 0.0 || s == 1./0. || ...)
-    # print`): the fields it reads come to the host once, the expressions are evaluated over the whole box with numpy, and the
-    # prints run for the offending points in loop order.
-    @staticmethod
-    def _is_check_loop(body) -> bool:
-        def ok(st):
-            if st[0] == "decl":
-                return True
-            if st[0] == "if":
-                return not st[3] and all(x[0] == "callstmt" and x[1][1] == "print" for x in st[2])
-            return False
-        return bool(body) and all(ok(st) for st in body) and any(st[0] == "if" for st in body)
-
-    def _np_eval(self, e, env, fr: _Frame, box):
-        import numpy as np
-
-        k = e[0]
-        if k == "num":
-            return float(e[1]) if not isinstance(e[1], bool) else e[1]
-        if k == "str":
-            return e[1]
-        if k == "fld":
-            f, slot = self._field(e, fr)
-            key = (f.name, f.level, slot)
-            if key not in env["_fields"]:
-                lay = f.layout
-                sl = tuple(slice(lay.ref(d) + box[0][d], lay.ref(d) + box[1][d]) for d in (2, 1, 0))
-                env["_fields"][key] = self.ops.to_host(f.data(slot)).reshape(lay.shape_zyx)[sl]
-            return env["_fields"][key]
-        if k == "id":
-            if e[1] in env:
-                return env[e[1]]
-            if e[1] in ("i0", "i1", "i2"):
-                d = int(e[1][1])
-                n = [box[1][t] - box[0][t] for t in range(3)]
-                shape = [1, 1, 1]
-                shape[2 - d] = n[d]
-                return (np.arange(box[0][d], box[1][d]).reshape(shape) + np.zeros((n[2], n[1], n[0]), dtype=np.int64))
-            return self._eval(e, fr)
-        if k == "neg":
-            return -self._np_eval(e[1], env, fr, box)
-        if k == "not":
-            return np.logical_not(self._np_eval(e[1], env, fr, box))
-        if k == "bin":
-            a, b = self._np_eval(e[2], env, fr, box), self._np_eval(e[3], env, fr, box)
-            op = e[1]
-            with np.errstate(all="ignore"):
-                if op in ("&&", "and"):
-                    return np.logical_and(a, b)
-                if op in ("||", "or"):
-                    return np.logical_or(a, b)
-                if op == "/":
-                    return np.divide(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
-                table = {"+": np.add, "-": np.subtract, "*": np.multiply, "**": np.power, "%": np.mod, "==": np.equal, "!=": np.not_equal,
-                         "<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal}
-                if op not in table:
-                    raise Exa4Unsupported("operator %s in a check loop" % op)
-                return table[op](a, b)
-        if k == "call" and e[1] in ("fabs", "abs", "sqrt", "exp", "sin", "cos") and len(e[3]) == 1:
-            fn = {"fabs": np.abs, "abs": np.abs, "sqrt": np.sqrt, "exp": np.exp, "sin": np.sin, "cos": np.cos}[e[1]]
-            with np.errstate(all="ignore"):
-                return fn(self._np_eval(e[3][0], env, fr, box))
-        raise Exa4Unsupported("expression %s in a check loop" % (k,))
-
-    def _exec_check_loop(self, body, boxes, fr: _Frame):
-        import numpy as np
-
-        self.ops.synchronize()
-        for box in boxes:
-            n = [box[1][d] - box[0][d] for d in range(3)]
-            if n[0] * n[1] * n[2] == 0:
-                continue
-            env = {"_fields": {}}
-            for st in body:
-                if st[0] == "decl":
-                    env[st[1]] = self._np_eval(st[2], env, fr, box) if st[2] is not None else 0.0
-                    continue
-                mask = np.broadcast_to(np.asarray(self._np_eval(st[1], env, fr, box), dtype=bool), (n[2], n[1], n[0]))
-                for k2, k1, k0 in np.argwhere(mask)[:1000]:      # (a check that fires on every point need not print them all)
-                    pt = {"i0": box[0][0] + int(k0), "i1": box[0][1] + int(k1), "i2": box[0][2] + int(k2)}
-                    for x in st[2]:
-                        out = []
-                        for a in x[1][3]:
-                            v = self._np_eval(a, {**env, **pt}, fr, box) if a[0] != "str" else a[1]
-                            if isinstance(v, np.ndarray):
-                                v = np.broadcast_to(v, (n[2], n[1], n[0]))[k2, k1, k0].item()
-                            out.append(v)
-                        self._emit(" ".join(self._fmt(v) for v in out))
-
-    def _exec_block_at_point(self, stmts, fr: _Frame, A, sa, B, sb):
-        """The statements of the compare loop's `if` at the offending point: prints see the fields' values and i0 / i1 / i2 there."""
-        vals, va, vb = getattr(self, "_cmp_point", ({"i0": -1, "i1": -1, "i2": -1}, float("nan"), float("nan")))
-        for st in stmts:
-            if st[0] == "return":
-                raise _Return(self._eval(st[1], fr) if st[1] is not None else None)
-            c = st[1]
-            if c[1] != "print":
-                self._exec(st, fr)
-                continue
-            out = []
-            for a in c[3]:
-                if a[0] == "fld":
-                    f, _ = self._field(a, fr)
-                    out.append(va if f is A else vb)
-                elif a[0] == "id" and a[1] in vals:
-                    out.append(vals[a[1]])
-                else:
-                    out.append(self._eval(a, fr))
-            self._emit(" ".join(self._fmt(x) for x in out))
 
     # pattern helpers ---------------------------------------------------------------------------------------------------
     def _is_scalar(self, e) -> bool:

@@ -189,7 +189,16 @@ class SolverFromL4(_Program):
             self._agg = SolverFromL4(acfg, ops, whole, Communicator(whole, ops))
             self._agg.setup()
             if cfg.graph_agglomerated and hasattr(ops, "torch") and getattr(getattr(ops, "device", None), "type", "cpu") != "cpu":
+                # warm-up and capture run the cycle once for real: with every field zero the coarse CG would start from a zero
+                # residual (alpha = 0 / 0) and leave NaNs and a spurious "iteration limit" count behind -- give it a right-hand
+                # side, then put the state back (arrays are zeroed in place: the captured graph stays valid)
+                AF = self._agg.RHS[k]
+                ab, ae = self._agg.bounds(AF)
+                ops.set(AF.lc, AF.data(), 1.0, ab, ae)
                 self._agg.capture_cycle()
+                self._agg.reset()
+                self._agg._cg_info.zero_()
+                self._agg._cg_limit_seen = 0
             nc = dom.ncells(k)
             n_own = 1
             n_halo = 1

@@ -65,8 +65,8 @@ def cases(ops, level, with27=True, align=0):
         ops.fill_random(up, 201)
         ops.fill_random(fp, 202)
         Lp, Fp = lup.c_struct(), lfp.c_struct()
-        cs.insert(1, ("jacobi_1step_padded_rows", lambda: ops.stencil_op(2, Lp, up, Fp, fp, Lp, unp, A, w, -1, b, e),
-                      "k_stencil7_rowmarch<2" if 400 <= n - 1 <= 512 else "k_stencil7_zmarch<2", 24 * pts, pts))
+        cs.insert(1, ("jacobi_1step_padded_rows", lambda: ops.stencil_op(2, Lp, up, Fp, fp, Lp, unp, A, w, -1, b, e), "k_stencil7_zmarch<2",
+                      24 * pts, pts))
     if with27:
         nocomm = FieldLayout.node(3, nc, 0, False, False, align)
         cf = ops.new_array(27 * nocomm.size)

@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(256) k_ref(LayoutDev lu, const double *__restr
 
 struct Geo {
   int ntx, nty, ntz, zc, nblocks;
+  int amask;   // ABL & 16: stores moved down to a multiple of amask + 1 bytes (timing only)
 };
 
 // --------------------------------------------------------------------------------------------------------------------
@@ -143,7 +144,7 @@ k_zm(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__r
         } else if (ABL & 16) {
           // timing only: the wave's 1 KiB of output at the 128-byte boundary below its window -- what stores of whole, aligned
           // lines would cost (wrong addresses: neighbouring windows overlap by up to 15 doubles)
-          double *qa = (double *)(((unsigned long long)(q_ - 2 * lane) & ~127ull)) + 2 * lane;
+          double *qa = (double *)(((unsigned long long)(q_ - 2 * lane) & ~(unsigned long long)(g.amask))) + 2 * lane;
           if (vb) __builtin_nontemporal_store(o, (d2 *)qa);
         } else if (vb) {
           __builtin_nontemporal_store(o.x, q_);
@@ -377,6 +378,7 @@ static void report(const Ctx &c, const char *name, float ms, bool check) {
 }
 
 static int g_minchunk = 16;
+static int g_amask = 127;
 
 template <int RY, int WY, int PF, bool EPF, int ABL, bool NTF = false, bool REMAP = false, int WX = 1>
 static void run_zm(const Ctx &c, int blocks, const char *tag) {
@@ -392,6 +394,7 @@ static void run_zm(const Ctx &c, int blocks, const char *tag) {
   g.zc = zc;
   g.ntz = (c.box.n2() + zc - 1) / zc;
   g.nblocks = xy * g.ntz;
+  g.amask = g_amask;
   CHECK(hipMemset(c.un, 0, c.lu.size * 8));
   auto launch = [&]() {
     hipLaunchKernelGGL((k_zm<RY, WY, PF, EPF, ABL, NTF, REMAP, WX>), dim3(g.nblocks), dim3(64, WY * WX), 0, 0, c.lu, c.u, c.lf, c.f, c.un, c.k, c.w, c.box, g);
@@ -519,7 +522,15 @@ int main(int argc, char **argv) {
       run_zm<2, 4, 1, true, 6, false, true, 1>(c, 1 << 24, "no rhs, no stores");
       run_zm<2, 4, 1, true, 7, false, true, 1>(c, 1 << 24, "u rows only");
       run_zm<2, 4, 1, true, 3, false, true, 1>(c, 1 << 24, "u rows + stores");
+      g_amask = 127;
       run_zm<2, 4, 1, true, 16, false, true, 1>(c, 1 << 24, "full, stores moved to line boundaries (timing only)");
+      g_amask = 63;
+      run_zm<2, 4, 1, true, 16, false, true, 1>(c, 1 << 24, "full, stores moved to 64-byte boundaries (timing only)");
+      g_amask = 31;
+      run_zm<2, 4, 1, true, 16, false, true, 1>(c, 1 << 24, "full, stores moved to 32-byte boundaries (timing only)");
+      g_amask = 15;
+      run_zm<2, 4, 1, true, 16, false, true, 1>(c, 1 << 24, "full, stores moved to 16-byte boundaries (timing only)");
+      g_amask = 127;
       run_zm<2, 4, 1, true, 19, false, true, 1>(c, 1 << 24, "u rows + stores at line boundaries (timing only)");
     }
     g_minchunk = 16;
