@@ -220,7 +220,11 @@ def main():
         dom = RectDomain(nd, blocks, rank, tuple(max(blocks) // b for b in blocks))
     # 7-point loops read face ghosts only (one batch per exchange); duplicate planes are computed to the same bits on
     # both sides by every loop of these programs, so their upstream exchange is left out (exastencils_amd/comm.py)
-    comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
+    transport_notes = []
+    if world > 1:
+        comm = open_transport(dom, ops, dist, args, transport_notes)
+    else:
+        comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
     nc = dom.ncells(L)
     Solution = Field("Solution", L, FieldLayout.node(nd, nc, 1, True, True, args.align), ops, 2, None)
     RHS = Field("RHS", L, FieldLayout.node(nd, nc, 0, False, False, args.align), ops, 1, None)
@@ -441,6 +445,8 @@ def main():
             out["duplicate_planes_bit_identical"] = dup_check       # compared after the timed and sustained steps
         if world > 1:
             out["transport"] = getattr(comm, "transport", None)
+            if transport_notes:
+                out["transport_notes"] = transport_notes      # transports that were tried first and did not pass the probe, and why
         if sustained is not None:
             n_sus, t_sus = sustained
             out["sustained_steps"] = n_sus
@@ -505,6 +511,50 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def open_transport(dom, ops, dist, args, notes):
+    """The communicator of an N > 1 run: the transport is PROVEN by a real exchange + all-reduce on a small field before anything is
+    timed, and the verdict is shared by all ranks (MIN over ranks).  Default order: peer writes through HIP IPC, then RCCL
+    send / recv groups, then torch.distributed point-to-point; EXAMG_TRANSPORT pins one.  Nothing is silent: the transport that
+    runs is in the JSON line (`transport`), and so is every transport that was tried before it with the reason it was dropped
+    (`transport_notes`).  Every Communicator the run creates afterwards takes the same transport (EXAMG_TRANSPORT is set)."""
+    import torch
+
+    from exastencils_amd import comm as comm_mod
+    from exastencils_amd.comm import Communicator
+    from exastencils_amd.field import Field
+    from exastencils_amd.layout import FieldLayout
+
+    pinned = os.environ.get("EXAMG_TRANSPORT", "")
+    order = [pinned] if pinned in ("peer", "c", "torch") else (["peer", "c", "torch"] if args.backend == "nccl" else ["peer", "torch"])
+    world = dom.world_size
+    dev = ops.device if args.backend == "nccl" else "cpu"
+    for tr in order:
+        os.environ["EXAMG_TRANSPORT"] = tr
+        ok, why = 1.0, ""
+        try:
+            c = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True, transport=tr)
+            probe = Field("probe", 4, FieldLayout.node(dom.nd, dom.ncells(4), 1, True, True, 0), ops, 1, None)
+            ops.fill_random(probe.data(), 99 + dom.rank)
+            full = Communicator(dom, ops, transport=tr)
+            full.exchange(probe, None, "all")
+            t = ops.from_host(__import__("numpy").array([1.0 + dom.rank]))
+            c.allreduce(t, "sum")
+            ops.synchronize()
+            if hasattr(c, "check"):
+                c.check()
+            if float(ops.to_host(t)[0]) != world * (world + 1) / 2.0:
+                raise RuntimeError("all-reduce of 1 + rank over %d ranks gave %r" % (world, float(ops.to_host(t)[0])))
+        except Exception as ex:     # noqa: BLE001 -- whatever it was, all ranks move on to the next transport together
+            ok, why = 0.0, "%s: %s" % (type(ex).__name__, str(ex)[:300])
+        v = torch.tensor([ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        if float(v.item()) == 1.0:
+            return c
+        notes.append({"transport": tr, "rank": dom.rank, "reason": why or "failed on another rank"})
+        comm_mod._SHARED_C_COMMS.clear()       # the next transport starts from a clean slate (the dropped handles are not reused)
+    raise SystemExit("bench.py: no block-to-block transport passed its probe: %r" % (notes,))
 
 
 def kernel_table(ops, level, align):

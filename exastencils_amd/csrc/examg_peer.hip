@@ -390,6 +390,9 @@ using namespace examg;
 
 extern "C" int examg_comm_create_peer(examg_comm_t **comm, int nranks, int rank) {
   if (!comm) { set_error("examg_comm_create_peer: null argument"); return 1; }
+  if (const char *ff = getenv("EXAMG_PEER_FORCE_FAIL")) {   // fault injection for the fallback tests of the callers
+    if (*ff == '1') { set_error("examg_comm_create_peer: refused (EXAMG_PEER_FORCE_FAIL=1)"); return 1; }
+  }
   if (nranks < 1 || nranks > PEER_MAX_RANKS || rank < 0 || rank >= nranks) { set_error("examg_comm_create_peer: rank %d of %d (at most %d ranks)", rank, nranks, (int)PEER_MAX_RANKS); return 1; }
   examg_comm *c = new examg_comm;
   c->rank = rank;

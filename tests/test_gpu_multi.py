@@ -58,3 +58,16 @@ def test_bench_ranks_sharing_one_gpu_over_the_peer_write_transport(n, extra):
     assert r["vcycle_duplicate_planes_bit_identical"] is True
     assert r.get("solve_iterations") in (5, 6, 7), r
     assert r["solve_residual_reduction"] < 1e-6
+
+
+def test_bench_reports_a_dropped_transport_instead_of_falling_back_silently(monkeypatch):
+    """EXAMG_PEER_FORCE_FAIL=1 makes examg_comm_create_peer refuse on every rank: bench.py's probe drops the peer-write transport on
+    all ranks together, says so in the line (`transport_notes`) and runs on torch.distributed point-to-point (the only other one that
+    takes two ranks on one GPU); the V-cycle with neighbours is then issued eagerly."""
+    monkeypatch.setenv("EXAMG_PEER_FORCE_FAIL", "1")
+    monkeypatch.delenv("EXAMG_TRANSPORT", raising=False)
+    r = _bench(2, ["--backend", "gloo"])
+    assert r["transport"] == "torch"
+    assert r["transport_notes"] and r["transport_notes"][0]["transport"] == "peer" and "FORCE_FAIL" in r["transport_notes"][0]["reason"]
+    assert r["vcycle_graph"] is False and r["duplicate_planes_bit_identical"] is True
+    assert r.get("solve_iterations") in (5, 6, 7), r
