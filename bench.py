@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 BYTES_PER_LU = 24.0
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")      # tools/gpu_pmc.sh; the commit it was taken at is inside
 
 
 def parse():
@@ -173,7 +173,9 @@ def pmc_traffic(case, level, align):
         return None
     for k in prof.get("kernels", []):
         if k.get("case") == case and "traffic" in k:
-            return {"traffic": k["traffic"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"], "source": "profiles/r02_pmc_kernels.json"}
+            return {"traffic": k["traffic"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
+                    "source": "profiles/" + os.path.basename(PMC_PROFILE if not align else PMC_PROFILE.replace(".json", "_align%d.json" % align)),
+                    "source_commit": prof.get("commit"), "source_kernel": k.get("kernel_name")}
     return None
 
 
@@ -439,6 +441,7 @@ def main():
                 "lu_equivalent_frac": BYTES_PER_LU * lus / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic_over_compulsory": (pmc["traffic"] / compulsory) if pmc else None,
                 "traffic_source": pmc["source"] if pmc else None,
+                "traffic_source_commit": pmc.get("source_commit") if pmc else None,     # the tree the counter profile was taken at
             },
         }
         if dup_check is not None:

@@ -2,7 +2,7 @@
 """Memory-side and wave-state counters of the hot kernels: what the time of the streaming kernels goes to.
 
     for S in A B C D; do rocprofv3 --pmc <set S> --output-format csv -d gpurun_out/pmcY_${S}${TAG} -- python3 tools/pmc_kernels.py [--align 16]; done
-    python3 tools/pmc_why.py [--tag _a16] -> profiles/r02_pmc_why[_align16].json
+    python3 tools/pmc_why.py [--tag _a16] -> gpurun_out/<round>_pmc_why[_align16].json (copy into profiles/)
 
 Counter sets (TCC has 4 slots per pass, SQ 8; MI355X_MICROARCH.md, rocprofv3 PMC slots):
   A  TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum
@@ -46,6 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="")
     ap.add_argument("--level", type=int, default=9)
+    ap.add_argument("--round", default="r03")
     args = ap.parse_args()
     go = os.path.join(ROOT, "gpurun_out")
     cases = json.load(open(os.path.join(go, "pmcK_times_L%d%s.json" % (args.level, args.tag))))
@@ -70,7 +71,7 @@ def main():
         if wc and wa is not None:
             r["wave_cycles_waiting_share"] = wa / wc
     out = {"note": __doc__.split("\n\n")[0], "sets": SETS, "level": args.level, "align": 16 if "a16" in args.tag else 0, "kernels": res}
-    path = os.path.join(ROOT, "profiles", "r02_pmc_why%s.json" % ("_align16" if "a16" in args.tag else ""))
+    path = os.path.join(go, "%s_pmc_why%s.json" % (args.round, "_align16" if "a16" in args.tag else ""))
     json.dump(out, open(path, "w"), indent=1)
     for case, r in res.items():
         print(case, {k: (round(v, 4) if isinstance(v, float) and v < 10 else v) for k, v in r.items() if "share" in k or "rate" in k or k == "ms"})
