@@ -41,7 +41,8 @@ def main():
     spec = json.load(open(os.path.join(out, "spec.json")))
     L = spec["level"]
     ops = HipOps(0)
-    flen = tuple(2 // blocks[d] for d in range(3))
+    total = spec.get("total_frag", 2)          # fragment lengths of all blocks of a dimension add up to this
+    flen = tuple(total // blocks[d] for d in range(3))
     dom = RectDomain(3, blocks, rank, flen)
     result = {"transport": None, "checks": {}}
     arrays = {}

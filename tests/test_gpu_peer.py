@@ -2,7 +2,8 @@
 ranks started as fresh child processes (tests/peer_worker.py).  RCCL refuses several ranks on one device; this transport does
 not, and it is the one the N > 1 bench path uses.
 
-Checked per decomposition (1 x 1 x 2 and 1 x 2 x 2 blocks of a 128^3-cell grid):
+Checked per decomposition (1 x 1 x 2, 1 x 2 x 2 and 1 x 1 x 4 blocks of a 128^3-cell grid; in the last the middle blocks have a
+neighbour on both sides of an axis):
   * `communicate` (duplicate + ghost layers, axis by axis and as one batch) restores a scrambled halo of a consistent global field;
   * k overlapped Jacobi pairs (examg_jacobi2_blocks), k overlapped red-black sweeps (examg_rbgs_sweep_blocks), residual +
     restriction (examg_residual_restrict_blocks) and prolongation + correction (examg_prolong_add_blocks): BIT-IDENTICAL to the
@@ -29,8 +30,11 @@ for p in (ROOT, HERE):
 
 pytestmark = pytest.mark.gpu
 
-LEVEL, PAIRS, SWEEPS = 6, 3, 3          # frag_len 2 per dimension in total: 2 * 2^6 = 128 cells per dimension
-CYCLE = {"min_level": 2, "tol": 1e-8, "agglomerate_level": 3, "extra": 0}
+PAIRS, SWEEPS = 3, 3
+# (total fragment length per dimension, finest level, cycle): 128 cells per dimension either way -- 2 * 2^6 for the decompositions
+# with at most two blocks per dimension, 4 * 2^5 for 1 x 1 x 4, whose middle blocks have a neighbour on BOTH sides of z
+GRIDS = {2: (6, {"min_level": 2, "tol": 1e-8, "agglomerate_level": 3, "extra": 0}),
+         4: (5, {"min_level": 1, "tol": 1e-8, "agglomerate_level": 2, "extra": 0})}
 
 
 def _free_port():
@@ -41,9 +45,20 @@ def _free_port():
     return p
 
 
-@pytest.fixture(scope="module")
-def single_block():
+_SINGLE = {}
+
+
+@pytest.fixture()
+def single_block(blocks):
+    total = max(blocks)
+    if total not in _SINGLE:
+        _SINGLE[total] = _single_block(total)
+    return _SINGLE[total]
+
+
+def _single_block(total):
     """The whole grid as one block on the GPU: inputs (saved for the workers) and expected outputs."""
+    LEVEL, CYCLE = GRIDS[total]
     import torch
 
     from exastencils_amd.comm import Communicator
@@ -54,7 +69,7 @@ def single_block():
     from exastencils_amd.solver import ConfigL4, SolverFromL4
 
     ops = HipOps(0)
-    dom = RectDomain(3, (1, 1, 1), 0, (2, 2, 2))
+    dom = RectDomain(3, (1, 1, 1), 0, (total, total, total))
     L = LEVEL
     nc, ncc = dom.ncells(L), dom.ncells(L - 1)
     lay_u = FieldLayout.node(3, nc, 1, True, True, 0)
@@ -69,7 +84,7 @@ def single_block():
     np.save(os.path.join(d, "u.npy"), u.reshape(lay_u.shape_zyx))
     np.save(os.path.join(d, "f.npy"), f.reshape(lay_f.shape_zyx))
     np.save(os.path.join(d, "uc.npy"), uc.reshape(lay_c.shape_zyx))
-    json.dump({"level": L, "pairs": PAIRS, "sweeps": SWEEPS, "cycle": CYCLE}, open(os.path.join(d, "spec.json"), "w"))
+    json.dump({"level": L, "pairs": PAIRS, "sweeps": SWEEPS, "cycle": CYCLE, "total_frag": total}, open(os.path.join(d, "spec.json"), "w"))
 
     A = laplace_fd(3, dom.h(L), "mp")
     w = 0.8 / A.diag
@@ -100,7 +115,7 @@ def single_block():
     ops.prolong_add(lay_c.c_struct(), ops.from_host(uc), lay_u.c_struct(), x, b, e)
     exp["prolong"] = owned(x, lay_u, nc)
 
-    cfg = ConfigL4(nd=3, min_level=CYCLE["min_level"], max_level=L, frag_len=(2, 2, 2), tol=CYCLE["tol"], fused_rbgs=True,
+    cfg = ConfigL4(nd=3, min_level=CYCLE["min_level"], max_level=L, frag_len=(total, total, total), tol=CYCLE["tol"], fused_rbgs=True,
                    fused_residual_restrict=True, fused_residual_norm=True)
     P = SolverFromL4(cfg, ops, dom, Communicator(dom, ops))
     P.setup()
@@ -110,7 +125,7 @@ def single_block():
 
     from oracle import mg
 
-    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=CYCLE["min_level"], max_level=L, frag_len=(2, 2, 2), tol=CYCLE["tol"]))
+    O = mg.ProgramA(mg.ConfigA(nd=3, min_level=CYCLE["min_level"], max_level=L, frag_len=(total, total, total), tol=CYCLE["tol"]))
     O.setup()
     O.Solve()
     return {"dir": d, "exp": exp, "it": its, "res": list(P.res_history), "oracle_it": O.iterations, "oracle_res": list(O.res_history), "nc": nc, "ncc": ncc}
@@ -152,7 +167,7 @@ def _run_ranks(blocks, d):
     return world
 
 
-@pytest.mark.parametrize("blocks", [(1, 1, 2), (1, 2, 2)])
+@pytest.mark.parametrize("blocks", [(1, 1, 2), (1, 2, 2), (1, 1, 4)])
 def test_peer_transport_multi_process_on_one_gpu(single_block, blocks):
     sb = single_block
     d = sb["dir"]
@@ -192,3 +207,22 @@ def test_peer_transport_multi_process_on_one_gpu(single_block, blocks):
     for r in range(world):
         got, want = arrs[r]["cycle_eager"], piece(sb["exp"]["cycle"], r, nc)
         assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+
+
+def test_a_lost_neighbour_ends_in_an_error_not_in_a_spinning_kernel(tmp_path):
+    """Rank 0 exchanges once more than rank 1: its receive kernel gives up after EXAMG_PEER_TIMEOUT_MS (0.5 s here), examg_comm_status
+    names the wait, and later calls on that communicator return at once instead of waiting again."""
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EXAMG_PEER_TIMEOUT_MS="500")
+    env.pop("EXAMG_TRANSPORT", None)
+    outs = [str(tmp_path / ("r%d.json" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "peer_timeout_worker.py"), str(r), str(port), outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT) for r in range(2)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    r0 = json.load(open(outs[0]))
+    assert r0["transport"] == "peer"
+    assert r0["error"] and "receive waited for a message" in r0["error"] and "EXAMG_PEER_TIMEOUT_MS" in r0["error"]
+    assert 0.4 < r0["seconds"] < 20.0
+    assert r0["second_attempt_seconds"] < 0.4
