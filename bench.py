@@ -223,7 +223,23 @@ def main():
     # 7-point loops read face ghosts only (one batch per exchange); duplicate planes are computed to the same bits on
     # both sides by every loop of these programs, so their upstream exchange is left out (exastencils_amd/comm.py)
     transport_notes = []
+    # At N > 1 nothing may look like a slow benchmark that is in fact a transport which never completes: from here until the first
+    # overlapped pass has finished a watchdog ends the process with a diagnosis (exit code 4) after --preflight-timeout seconds.
+    preflight_done, comm = None, None
     if world > 1:
+        import threading
+
+        preflight_done = threading.Event()
+
+        def preflight_watchdog():
+            if not preflight_done.wait(args.preflight_timeout):
+                sys.stderr.write("bench.py rank %d: transport probe / first halo exchange did not complete within %g s (transport %r, tried before: %r); "
+                                 "EXAMG_TRANSPORT=torch pins the torch.distributed point-to-point path\n"
+                                 % (rank, args.preflight_timeout, getattr(comm, "transport", os.environ.get("EXAMG_TRANSPORT")), transport_notes))
+                sys.stderr.flush()
+                os._exit(4)
+
+        threading.Thread(target=preflight_watchdog, daemon=True).start()
         comm = open_transport(dom, ops, dist, args, transport_notes)
     else:
         comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
@@ -279,24 +295,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # communicator set-up (RCCL connects peers lazily at the first point-to-point batch) is not part of any step.  At N > 1 a
-    # transport that never completes its first exchange must not look like a slow benchmark: a watchdog ends the process with a
-    # diagnosis (exit code 4; EXAMG_TRANSPORT=torch keeps the messages on torch.distributed)
-    preflight_done = None
-    if world > 1:
-        import threading
-
-        preflight_done = threading.Event()
-
-        def preflight_watchdog():
-            if not preflight_done.wait(args.preflight_timeout):
-                sys.stderr.write("bench.py rank %d: first halo exchange / barrier did not complete within %g s (transport %r); "
-                                 "EXAMG_TRANSPORT=torch selects the torch.distributed point-to-point path\n"
-                                 % (rank, args.preflight_timeout, getattr(comm, "transport", None)))
-                sys.stderr.flush()
-                os._exit(4)
-
-        threading.Thread(target=preflight_watchdog, daemon=True).start()
     comm.exchange(Solution, Solution.active, "ghost", axis_only=True)
     barrier()
     if world > 1:
