@@ -513,6 +513,40 @@ def test_stencil_field_entry_fastest_transformation_other_entry_counts(hip, orc,
     assert_same(g, c, "entry-fastest, half sweep")
 
 
+@pytest.mark.parametrize("K,shape", [(7, (70, 20, 12)), (27, (130, 24, 10))])
+@pytest.mark.parametrize("entry_fastest", [False, True])
+def test_stencil_field_smoother_weight_written_as_omega_over_diag(hip, orc, K, shape, entry_fastest):
+    """`Solution += (0.8 / diag(A)) * (RHS - A * Solution)` on a stencil field (Testing/PolyExpl/RBGS3Dvc.exa4:52): the weight is evaluated
+    per point as w / c_diag (EXAMG_WEIGHT_DIVIDE), not as (1.0 / c_diag) * w -- bit-identical to the oracle's loop with the same form, and
+    different from the other form somewhere (the two round differently)."""
+    import dataclasses
+
+    from exastencils_amd.field import helmholtz27_offsets
+
+    offs = helmholtz27_offsets() if K == 27 else stencil_field_offsets(3)
+    b, e = [1, 1, 1], list(shape)
+
+    def case(ops, wform):
+        lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+        u, f, dst = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size)
+        ops.fill_random(u, 12345)
+        ops.fill_random(f, 4711)
+        cf = ops.new_array(K * lf.size)
+        ops.fill_random(cf, 99)
+        cf += 3.0
+        st = Stencil(offs, [], cf, lf)
+        if entry_fastest:
+            st = st.entry_fastest(ops)
+        st = dataclasses.replace(st, wform=wform)
+        ops.stencil_op(SMOOTH, lu.c_struct(), u, lf.c_struct(), f, lu.c_struct(), dst, st, 0.8, -1, b, e)
+        return [dst]
+
+    g, c = both(hip, orc, lambda ops: case(ops, 1))
+    assert_same(g, c, "omega / diag(A)")
+    g0 = [hip.to_host(t) for t in case(hip, 0)]
+    assert not np.array_equal(g[0], g0[0])
+
+
 def test_stencil_field_transformation_round_trip(hip):
     l = FieldLayout.node(3, (37, 11, 6), 0)
     for K in (7, 27):
