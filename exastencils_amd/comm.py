@@ -33,6 +33,7 @@ from .domain import RectDomain
 from .field import Field
 
 
+_PEER_GENERATION = [0]      # bumped whenever the peer-write regions of this process are re-allocated (graphs captured earlier are stale)
 _SHARED_C_COMMS: Dict[Tuple, object] = {}     # (library, world size, rank) -> examg_comm_t*: one RCCL communicator per process
 
 
@@ -193,6 +194,8 @@ class Communicator:
         _lib.check(L.examg_comm_peer_connect(self._c, allbuf), "examg_comm_peer_connect")
         if self.dist is not None:
             self.dist.barrier(group=self.group)
+        # kernels recorded into a hipGraph before this point hold the addresses of the regions that were just replaced
+        _PEER_GENERATION[0] += 1
 
     @staticmethod
     def _max_face_bytes(lay, nd: int) -> int:
@@ -205,6 +208,11 @@ class Communicator:
                     n *= lay.idx("GRE", t) - lay.idx("GLB", t)
             best = max(best, n)
         return 8 * best
+
+    @property
+    def generation(self) -> int:
+        """Changes when the peer-write regions were re-allocated: a hipGraph that contains exchanges is valid for one generation."""
+        return _PEER_GENERATION[0] if self.transport == "peer" else 0
 
     def check(self):
         """Raise if a wait of the peer-write transport has given up (lost neighbour, mismatched exchange sequences)."""

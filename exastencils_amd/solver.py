@@ -568,9 +568,12 @@ class SolverFromL4(_Program):
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.mgCycle(hi)
         self._graphs["cycle"] = g
+        self._graph_generation = getattr(self.comm, "generation", 0)
         return g
 
     def replay_cycle(self):
+        if getattr(self.comm, "generation", 0) != getattr(self, "_graph_generation", 0):
+            raise RuntimeError("the peer-write regions were re-allocated after this cycle was captured (a larger field was exchanged since): capture again")
         self._graphs["cycle"].replay()
 
 
