@@ -212,7 +212,7 @@ class Communicator:
     @property
     def generation(self) -> int:
         """Changes when the peer-write regions were re-allocated: a hipGraph that contains exchanges is valid for one generation."""
-        return _PEER_GENERATION[0] if self.transport == "peer" else 0
+        return _PEER_GENERATION[0] if (self.transport == "peer" and self._c is not None) else 0      # no neighbours: no exchange kernels in its graphs
 
     def check(self):
         """Raise if a wait of the peer-write transport has given up (lost neighbour, mismatched exchange sequences)."""
