@@ -405,9 +405,11 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
 //     0.618 -> 0.590 ms at 512^3, the difference between the verbatim and the padded layout;
 //   * no window edges inside a row: x-neighbours across segments come from the neighbouring lane by a wave rotate (DPP
 //     wave_rol / wave_ror), edge loads only at the two ends of the row; no partial lines are fetched twice.
-// Loads per point are those of the kernel above (own rows once, two y-halo rows per wave through L2).  ~300 VGPRs with two
-// rows per wave: one wave per SIMD, the software pipeline (everything step m+1 needs is in flight during step m) hides the
-// latency instead of occupancy.  Arithmetic: conv7 / finish as above -- bit-identical.
+// Loads per point are those of the kernel above (own rows once, two y-halo rows per wave through L2).  256 VGPRs (+ ~46 spilled to
+// AGPRs) with two rows per wave: one wave per SIMD, the software pipeline (the `u` planes and halo rows step m+1 needs are in flight
+// during step m; the right-hand side of plane m, which only the last instructions of step m read, is loaded at the start of that
+// step, ahead of the next stage's loads -- loads return in order) hides the latency instead of occupancy.  Arithmetic: conv7 /
+// finish as above -- bit-identical.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double lane_rotl(double v) {   // lane l receives lane l+1, lane 63 receives lane 0
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -487,9 +489,21 @@ k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, co
       um[r][j] = load2(ur[r] + xs[j] + lu.s2 * (mb - 1));
       uc[r][j] = load2(ur[r] + xs[j] + lu.s2 * mb);
     }
+  // one pipeline stage = what step m needs of u; the right-hand side of a plane is needed by the last instructions of its step only:
+  // its loads are issued at the start of that step, BEFORE the next stage's loads (loads return in order), not a step ahead
   struct Stage {
-    d2 up[RY][RM_NSEG], f[RY][RM_NSEG], hm[RM_NSEG], hp[RM_NSEG];
+    d2 up[RY][RM_NSEG], hm[RM_NSEG], hp[RM_NSEG];
     double el[RY], er[RY];
+  };
+  struct Rhs {
+    d2 f[RY][RM_NSEG];
+  };
+  auto load_rhs = [&](Rhs &fv, int m) {
+    if (MODE == EXAMG_APPLY) return;
+#pragma unroll
+    for (int r = 0; r < RY; ++r)
+#pragma unroll
+      for (int j = 0; j < RM_NSEG; ++j) fv.f[r][j] = load2(fr[r] + xs[j] + lf.s2 * m);
   };
   auto load_stage = [&](Stage &st, int m) {
 #pragma unroll
@@ -497,7 +511,6 @@ k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, co
 #pragma unroll
       for (int j = 0; j < RM_NSEG; ++j) {
         st.up[r][j] = load2(ur[r] + xs[j] + lu.s2 * (m + 1));
-        if (MODE != EXAMG_APPLY) st.f[r][j] = load2(fr[r] + xs[j] + lf.s2 * m);
       }
       st.el[r] = 0.0;
       st.er[r] = 0.0;
@@ -510,7 +523,7 @@ k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, co
       st.hp[j] = load2(uhp + xs[j] + lu.s2 * m);
     }
   };
-  auto compute = [&](const Stage &st, int m) {
+  auto compute = [&](const Stage &st, const Rhs &fv, int m) {
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
       d2 o[RM_NSEG];
@@ -534,8 +547,8 @@ k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, co
         const d2 tp_ = (r == RY - 1) ? st.hp[j] : uc[r == RY - 1 ? r : r + 1][j];
         const double acc_a = conv7<ORDER>(k, uc[r][j].x, xl, uc[r][j].y, tm_.x, tp_.x, um[r][j].x, st.up[r][j].x);
         const double acc_b = conv7<ORDER>(k, uc[r][j].y, uc[r][j].x, xr, tm_.y, tp_.y, um[r][j].y, st.up[r][j].y);
-        o[j].x = finish<MODE>(uc[r][j].x, acc_a, st.f[r][j].x, w);
-        o[j].y = finish<MODE>(uc[r][j].y, acc_b, st.f[r][j].y, w);
+        o[j].x = finish<MODE>(uc[r][j].x, acc_a, MODE == EXAMG_APPLY ? 0.0 : fv.f[r][j].x, w);
+        o[j].y = finish<MODE>(uc[r][j].y, acc_b, MODE == EXAMG_APPLY ? 0.0 : fv.f[r][j].y, w);
       }
       if (rw + r < box.e1) {
         double *row = dr[r] + box.b0 + ld.s2 * m;                       // &dst[x = b0] of this row and plane
@@ -569,14 +582,16 @@ k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, co
       }
   };
   Stage st[2];
+  Rhs fv;
   load_stage(st[0], mb);
   int m = mb;
   while (m < me) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (m < me) {
+        load_rhs(fv, m);
         if (m + 1 < me) load_stage(st[j ^ 1], m + 1);
-        compute(st[j], m);
+        compute(st[j], fv, m);
         ++m;
       }
     }
@@ -623,7 +638,9 @@ static int launch_rowmarch(const LayoutDev &lu, const double *u, const LayoutDev
                            const Coef7 &k, double w, const Box &box, hipStream_t s) {
   RowMarchGeom g;
   g.nty = (box.n1() + RM_RY * RM_WY - 1) / (RM_RY * RM_WY);
-  int zc = g_rm_zc > 0 ? g_rm_zc : 32;   // 512^3: 8 .. 64 planes per chunk are within 2 % of each other (tools/sweep_rowmarch.py)
+  // 512^3 (64 tiles of 8 rows per layer): 64-plane chunks = 512 workgroups, two even rounds over the 256 CUs (one workgroup per CU at 256
+  // VGPRs): 0.565 / 0.578 ms on a fast / slow box; 32 or 128 planes +0.5 %, chunk lengths that leave a ragged last round (48, 86) +4..15 %
+  int zc = g_rm_zc > 0 ? g_rm_zc : 64;
   if (zc > box.n2()) zc = box.n2();
   g.zc = zc;
   g.ntz = (box.n2() + zc - 1) / zc;
