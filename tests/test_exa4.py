@@ -76,8 +76,22 @@ SHARED_RESULTS = [
     # 2 x 2 x 2 processes of 256^3 cells, each with std::srand(mpiRank): run as one merged block, one generator per former process
     ("Testing/Opts/base_par.exa4", "Testing/Opts/par_naive.knowledge", "Testing/Opts/par.results"),
     ("Testing/LayoutTrafo/opts.exa4", "Testing/LayoutTrafo/par_all.knowledge", "Testing/Opts/par.results"),
+    # the reference's own temporal-blocking tests (.gitlab-ci.yml:437-483,521-542): the Opts program with its smoother calls
+    # under `repeat .. with contraction`, checked against the results of the untransformed program
+    ("Testing/Opts/tempBlock.exa4", "Testing/Opts/seq_all.knowledge", "Testing/Opts/seq.results"),
+    ("Testing/Opts/tempBlock.exa4", "Testing/Opts/seq_poly.knowledge", "Testing/Opts/seq.results"),
+    ("Testing/Opts/tempBlock_par.exa4", "Testing/Opts/par_all.knowledge", "Testing/Opts/par.results"),
+    # the reference's CUDA CI jobs (.gitlab-ci.yml:787-797): the programs of Testing/CUDA with `cuda_enabled` knowledge must print the
+    # SISC results files -- its own CPU <-> GPU parity precedent; here the same pairs through the interpreter
+    ("Testing/CUDA/2D_ConstCoeff.exa4", "Testing/CUDA/2D_ConstCoeff.knowledge", "Testing/SISC/2D_ConstCoeff.results"),
+    ("Testing/CUDA/2D_ConstCoeff.exa4", "Testing/CUDA/2D_ConstCoeff_VarFieldSize.knowledge", "Testing/SISC/2D_ConstCoeff.results"),
+    ("Testing/CUDA/2D_VarCoeff.exa4", "Testing/CUDA/2D_VarCoeff_VarFieldSize.knowledge", "Testing/CUDA/2D_VarCoeff.results"),
+    ("Testing/CUDA/3D_ConstCoeff.exa4", "Testing/CUDA/3D_ConstCoeff.knowledge", "Testing/SISC/3D_ConstCoeff.results"),
+    ("Testing/CUDA/3D_ConstCoeff.exa4", "Testing/CUDA/3D_ConstCoeff_VarFieldSize.knowledge", "Testing/SISC/3D_ConstCoeff.results"),
+    ("Testing/CUDA/3D_VarCoeff.exa4", "Testing/CUDA/3D_VarCoeff.knowledge", "Testing/SISC/3D_VarCoeff.results"),
+    ("Testing/CUDA/3D_VarCoeff.exa4", "Testing/CUDA/3D_VarCoeff_VarFieldSize.knowledge", "Testing/SISC/3D_VarCoeff.results"),
 ]
-SHARED_SLOW = {"Testing/Opts/par_naive.knowledge", "Testing/LayoutTrafo/par_all.knowledge"}      # 512^3 on the CPU, ~1 min each
+SHARED_SLOW = {"Testing/Opts/par_naive.knowledge", "Testing/LayoutTrafo/par_all.knowledge", "Testing/Opts/par_all.knowledge"}      # 512^3 on the CPU, ~1 min each
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
