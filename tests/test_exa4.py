@@ -90,6 +90,10 @@ SHARED_RESULTS = [
     ("Testing/CUDA/3D_ConstCoeff.exa4", "Testing/CUDA/3D_ConstCoeff_VarFieldSize.knowledge", "Testing/SISC/3D_ConstCoeff.results"),
     ("Testing/CUDA/3D_VarCoeff.exa4", "Testing/CUDA/3D_VarCoeff.knowledge", "Testing/SISC/3D_VarCoeff.results"),
     ("Testing/CUDA/3D_VarCoeff.exa4", "Testing/CUDA/3D_VarCoeff_VarFieldSize.knowledge", "Testing/SISC/3D_VarCoeff.results"),
+    # common-subexpression-elimination tests of the generator (.gitlab-ci.yml:732-746): knowledge switches only, same results
+    ("Testing/SISC/2D_VarCoeff.exa4", "Testing/CSE/2D_VarCoeff_conv.knowledge", "Testing/SISC/2D_VarCoeff.results"),
+    ("Testing/SISC/2D_VarCoeff.exa4", "Testing/CSE/2D_VarCoeff_lc.knowledge", "Testing/SISC/2D_VarCoeff.results"),
+    ("Testing/SISC/3D_VarCoeff.exa4", "Testing/CSE/3D_VarCoeff_both.knowledge", "Testing/SISC/3D_VarCoeff.results"),
 ]
 SHARED_SLOW = {"Testing/Opts/par_naive.knowledge", "Testing/LayoutTrafo/par_all.knowledge", "Testing/Opts/par_all.knowledge"}      # 512^3 on the CPU, ~1 min each
 
