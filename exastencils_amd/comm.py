@@ -68,7 +68,7 @@ class Communicator:
         self._stage = bool(self.dist is not None and self.dist.get_backend(group) == "gloo" and getattr(ops, "device", None) is not None
                            and getattr(ops.device, "type", "cpu") != "cpu")
         self._bufs: Dict[Tuple, object] = {}
-        self.stats = {"messages": 0, "bytes": 0}
+        self.stats = {"messages": 0, "bytes": 0, "c_exchanges": 0}   # messages / bytes: torch transport; c_exchanges: examg_exchange calls
         # transport selection on GPUs: the library's own transports, chosen the same way on every rank
         on_gpu = hasattr(ops, "L") and hasattr(ops.L, "examg_exchange") and getattr(getattr(ops, "device", None), "type", "cpu") != "cpu"
         if transport == "auto":
@@ -287,6 +287,7 @@ class Communicator:
 
         L = self.ops.L
         wsp, nbytes = self._workspace(f.lc, f.layout)
+        self.stats["c_exchanges"] += 1
         _lib.check(L.examg_exchange(self._c, C.byref(f.lc), self.ops.ptr(x), C.byref(self._nb), int(what), wsp, nbytes,
                                     self.ops._stream()), "examg_exchange")
 

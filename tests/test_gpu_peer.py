@@ -11,7 +11,10 @@ neighbour on both sides of an axis):
   * all-reduce / all-gather;
   * the V-cycle leg of bench.py (fused sweeps, fused residual + restriction, agglomerated coarse levels, duplicate exchange left
     out): eager == replay from a hipGraph (bitwise), iteration counts and residual histories == the single block's and the
-    oracle's within 1e-10 (north_star tolerance), duplicate planes bit-identical on both owners afterwards."""
+    oracle's within 1e-10 (north_star tolerance), duplicate planes bit-identical on both owners afterwards.
+Further down: BASELINE configs[3] (27-entry Helmholtz field, Jacobi pairs, transformed coefficient layout) and configs[4] (FMG start +
+fused red-black cycles) as decomposed programs of 2 and 4 processes (1 x 1 x 2, 1 x 2 x 2, 2 x 2 x 1) against the single block and the
+oracle program, and the lost-neighbour timeout."""
 import json
 import os
 import socket
@@ -207,6 +210,87 @@ def test_peer_transport_multi_process_on_one_gpu(single_block, blocks):
     for r in range(world):
         got, want = arrs[r]["cycle_eager"], piece(sb["exp"]["cycle"], r, nc)
         assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+
+
+# BASELINE configs[3] / configs[4] in their decomposed form (the 8-GPU node is not ours to use: 2 and 4 processes on the one device).
+# configs[3]: 27-entry variable-coefficient Helmholtz field under the applied layout transformation, Jacobi pairs (edge / corner
+# ghosts of the 27-point stencil arrive through the axis-by-axis exchange); configs[4]: FMG start + fused red-black cycles.
+SOLVER_CASES = {
+    "helmholtz27": dict(nd=3, min_level=1, max_level=5, smoother="jacobi", omega=0.8, stencil="helmholtz27", restrict_scale=1.0, tol=1e-8,
+                        cg_max=512, bc_fn=0, sol_fn=9, coef_fn=7, kappa=10.0, ksq=2.0, rhs_from_solution=True, temporal_blocking=True,
+                        coef_entry_fastest=True),
+    "fmg_rbgs": dict(nd=3, min_level=1, max_level=5, smoother="rbgs", omega=1.0, stencil="scaled", restrict_scale=1.0, tol=1e-8, cg_max=512,
+                     bc_fn=1, fmg=True, fused_rbgs=True),
+}
+_SOLVER_SINGLE = {}
+
+
+def _solver_single(case):
+    """The same program as ONE block: on the GPU (expected solution) and through the oracle's program (expected history)."""
+    if case in _SOLVER_SINGLE:
+        return _SOLVER_SINGLE[case]
+    from oracle import mg
+
+    from exastencils_amd.ops import HipOps
+    from exastencils_amd.solver import ConfigL3, SolverFromL3
+
+    kw = SOLVER_CASES[case]
+    ops = HipOps(0)
+    P = SolverFromL3(ConfigL3(frag_len=(2, 2, 2), **kw), ops)
+    P.setup()
+    its = P.Solve()
+    S = P.Solution[kw["max_level"]]
+    lay, n = S.layout, 2 << kw["max_level"]
+    a = ops.to_host(S.data()).reshape(lay.shape_zyx)
+    own = a[tuple(slice(lay.ref(d), lay.ref(d) + n + 1) for d in (2, 1, 0))].copy()
+    okw = {k: v for k, v in kw.items() if k not in ("temporal_blocking", "coef_entry_fastest", "fused_rbgs")}
+    O = mg.ProgramB(mg.ConfigB(nfrag=(1, 1, 1), frag_len=(2, 2, 2), **okw))
+    O.setup()
+    O.Solve()
+    _SOLVER_SINGLE[case] = {"it": its, "res": list(P.res_history), "sol": own, "oracle_it": O.iterations, "oracle_res": list(O.res_history)}
+    return _SOLVER_SINGLE[case]
+
+
+@pytest.mark.parametrize("blocks,case", [((1, 1, 2), "helmholtz27"), ((1, 2, 2), "helmholtz27"), ((1, 1, 2), "fmg_rbgs"), ((2, 2, 1), "fmg_rbgs")])
+def test_config3_and_config4_programs_decomposed_over_the_peer_transport(tmp_path, blocks, case):
+    sb = _solver_single(case)
+    d = str(tmp_path)
+    json.dump(SOLVER_CASES, open(os.path.join(d, "cases.json"), "w"))
+    world = blocks[0] * blocks[1] * blocks[2]
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EXAMG_PEER_TIMEOUT_MS="30000")
+    env.pop("EXAMG_TRANSPORT", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "peer_solver_worker.py"), str(r), str(world), ",".join(map(str, blocks)), str(port), d, case],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=420)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("peer solver workers timed out")
+    for r, (p, log) in enumerate(zip(procs, logs)):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, log[-3000:])
+    n = 2 << SOLVER_CASES[case]["max_level"]
+    nc = tuple(n // blocks[k] for k in range(3))
+    outs = [json.load(open(os.path.join(d, "%s_%d.json" % (case, r)))) for r in range(world)]
+    for r, o in enumerate(outs):
+        assert o["transport"] == "peer" and o["exchanges"] > 0
+        assert o["dup_consistent"], "rank %d: duplicate planes differ between their owners" % r
+        assert o["res"] == outs[0]["res"] and o["it"] == outs[0]["it"]
+    h = outs[0]
+    assert h["it"] == sb["it"] == sb["oracle_it"]
+    r0 = sb["res"][0]
+    for x, y, z in zip(h["res"], sb["res"], sb["oracle_res"]):
+        assert abs(x - y) <= 1e-10 * abs(y) + 64 * 2.2e-16 * r0, (h["res"], sb["res"])
+        assert abs(x - z) <= 1e-10 * abs(z) + 64 * 2.2e-16 * r0, (h["res"], sb["oracle_res"])
+    for r in range(world):
+        pos = (r % blocks[0], (r // blocks[0]) % blocks[1], r // (blocks[0] * blocks[1]))
+        want = sb["sol"][tuple(slice(pos[k] * nc[k], pos[k] * nc[k] + nc[k] + 1) for k in (2, 1, 0))]
+        got = np.load(os.path.join(d, "%s_%d.npy" % (case, r)))
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-9 * max(np.abs(want).max(), 1e-300), "rank %d: max abs %.3e" % (r, np.abs(got - want).max())
 
 
 def test_a_lost_neighbour_ends_in_an_error_not_in_a_spinning_kernel(tmp_path):
