@@ -94,6 +94,21 @@ __device__ __forceinline__ double lane_above(double v) {   // lane l receives la
   return __hiloint2double(hi, lo);
 }
 
+// The same shifts where the end lane's result is never used: it receives 0 (bound_ctrl) instead of its own value, which
+// saves the copy that ties the old value to the destination (one v_mov_b32 per dword).
+__device__ __forceinline__ double lane_below0(double v) {   // lane l receives lane l-1, lane 0 receives 0.0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_above0(double v) {   // lane l receives lane l+1, lane 63 receives 0.0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 // ---- shared by the 7-point kernels (kernels_stencil.hip, kernels_twostage.hip, kernels_stencilfield.hip) ----------
 typedef double d2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(8))) d2u { double a, b; };  // 16-byte access at 8-byte alignment
