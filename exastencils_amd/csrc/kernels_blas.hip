@@ -621,11 +621,11 @@ __global__ void __launch_bounds__(256) k_init_helmholtz27(LayoutDev lc, double *
     const long long k = lidx(lc, i0, i1, i2);
     int ent = 1;
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx)
+    for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int dz = -1; dz <= 1; ++dz) {
+        for (int dx = -1; dx <= 1; ++dx) {
           const int nnz = (dx != 0) + (dy != 0) + (dz != 0);
           double s = 0.0;
           bool first = true;

@@ -464,6 +464,10 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
 #undef VB
 }
 
+// kernels_sf27pair.hip: two Jacobi steps on a 27-entry stencil field (records) in one pass; 1 = launched, 0 = not applicable, -1 = error
+int sf27_jacobi2_try(const examg_layout_t *lu, const double *u_in, double *u_out, const examg_layout_t *lf, const double *rhs,
+                     const examg_stencil_t *st, double w, const Box &box1, const Box &box2, hipStream_t s);
+
 // launch knobs (debug build: examg_debug_two_stage*; per host thread): workgroup count target, tile order
 static thread_local int g_ts_blocks = -1;      // workgroup count target; -1: by size and variant (launch_two_stage_lds)
 static thread_local int g_ts_disable = 0;
@@ -820,6 +824,7 @@ extern "C" int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in,
   }
   if (two_stage_ok(lu, lf, st, box2) && box_inside(lu, box1, 1) && box_inside(lf, box1, 0) && stage_boxes_ok(lf, box1, box2))
     return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box2, (hipStream_t)stream, &box1);
+  if (const int r27 = sf27_jacobi2_try(lu, u_in, u_out, lf, rhs, st, w, box1, box2, (hipStream_t)stream)) return r27 < 0 ? 1 : 0;
   if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2_boxes: fallback needs a distinct tmp array"); return 1; }
   const int reach = stencil_reach(st);
   int32_t b2[3], e2[3];
@@ -882,6 +887,7 @@ extern "C" int examg_jacobi2(const examg_layout_t *lu, const double *u_in, doubl
   const Box box = make_box(begin, end);
   if (box.count() == 0) return 0;
   if (two_stage_ok(lu, lf, st, box)) return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box, (hipStream_t)stream);
+  if (const int r27 = sf27_jacobi2_try(lu, u_in, u_out, lf, rhs, st, w, box, box, (hipStream_t)stream)) return r27 < 0 ? 1 : 0;
   if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2: fallback needs a distinct tmp array"); return 1; }
   // the intermediate sweep needs the box's shell (Dirichlet / halo values) in tmp
   const int reach = stencil_reach(st);

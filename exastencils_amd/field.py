@@ -146,8 +146,10 @@ def stencil_field_offsets(nd: int) -> List[Tuple[int, int, int]]:
 
 
 def helmholtz27_offsets() -> List[Tuple[int, int, int]]:
-    """Entry order of the 27-entry stencil field of examg_init_helmholtz27: centre first, then (dx,dy,dz) lexicographic."""
-    return [(0, 0, 0)] + [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if (a, b, c) != (0, 0, 0)]
+    """Entry order of the 27-entry stencil field of examg_init_helmholtz27: centre first, then the offsets with dz = -1, 0, +1 (dz
+    slowest, dx fastest) -- the order in which a pass that marches in z can finish the sum of a point one plane at a time
+    (csrc/kernels_sf27pair.hip)."""
+    return [(0, 0, 0)] + [(a, b, c) for c in (-1, 0, 1) for b in (-1, 0, 1) for a in (-1, 0, 1) if (a, b, c) != (0, 0, 0)]
 
 
 def _fn_program(fn: int, p0: float):

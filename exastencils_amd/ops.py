@@ -85,6 +85,12 @@ class HipOps:
                                    C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin), ivec(end), self._stream()),
               "examg_jacobi2")
 
+    def jacobi_residual(self, lu, u_in, u_out, lf, rhs, lr, res, st: Stencil, w: float, begin, end):
+        """One Jacobi step and the residual of its result in one pass (examg_jacobi_residual)."""
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_jacobi_residual(C.byref(lu), self.ptr(u_in), self.ptr(u_out), C.byref(lf), self.ptr(rhs), C.byref(lr), self.ptr(res),
+                                           C.byref(sc), float(w), ivec(begin), ivec(end), self._stream()), "examg_jacobi_residual")
+
     def jacobi2_boxes(self, lu, u_in, u_out, tmp, lf, rhs, st: Stencil, w: float, begin1, end1, begin2, end2):
         sc = st.c_struct(self.ptr)
         check(self.L.examg_jacobi2_boxes(C.byref(lu), self.ptr(u_in), self.ptr(u_out), self.ptr(tmp) if tmp is not None else None,

@@ -143,6 +143,16 @@ int examg_jacobi2(const examg_layout_t *lu, const double *u_in, double *u_out, d
                   const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end,
                   examg_stream_t stream);
 
+/* One Jacobi step on [begin,end) and the residual of its result in ONE pass: u_out = J(u_in), res = rhs - A u_out on the box (the
+ * last pre-smoothing `Smoother@current` + `Residual@current = RHS - Laplace * Solution`, Testing/SISC/3D_VarCoeff.exa4:141-153,
+ * Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:215-219).  27-entry stencil fields in the record layout (EXAMG_CLAYOUT_ENTRY_FASTEST,
+ * entry order of examg_init_helmholtz27) share the 216 B of coefficients per point between the two loops; everything else runs
+ * examg_jacobi, then examg_residual.  The residual reads the one-point shell of the box from u_in: bit-identical to those two calls
+ * when u_out holds u_in's values there (the slots of a field after `apply bc` / `communicate`).  u_in != u_out. */
+int examg_jacobi_residual(const examg_layout_t *lu, const double *u_in, double *u_out, const examg_layout_t *lf, const double *rhs,
+                          const examg_layout_t *lr, double *res, const examg_stencil_t *st, double w, const int32_t *begin,
+                          const int32_t *end, examg_stream_t stream);
+
 /* As examg_jacobi2 with separate boxes: stage 1 = J on [begin1,end1) (points outside keep u_in's value), stage 2 = J of
  * that field on [begin2,end2), inside box 1, written to u_out.  With block neighbours: box 1 = the loop's box, box 2 =
  * box 1 without the duplicate planes at interior faces, whose second step needs the neighbour's first-step values

@@ -487,7 +487,8 @@ void orc_set_num_threads(int n) { (void)n; }
  * The reference ships stencil fields with 2d+1 entries only (Testing/SISC/3D_VarCoeff.exa4); this is
  * the same mechanism (entry index slowest, C/stencil/ir/IR_StencilConvolution.scala:73-95) with 27
  * entries -- no golden exists for it in the reference ("parity unpinned").
- * Entry order: (0,0,0) first, then offsets (dx,dy,dz) in lexicographic order, dx slowest.
+ * Entry order: (0,0,0) first, then the offsets with dz = -1, 0, +1 (dz slowest, dx fastest): a pass that marches in z can then
+ * finish the 27-term sum of a point plane by plane (exastencils_amd/csrc/kernels_sf27pair.hip).
  * Element matrix of the unit cube (Q1): 1/3 on the diagonal, 0 across an edge, -1/12 across a face
  * diagonal and across the body diagonal; entry(o) = sum over the elements containing both nodes.   */
 void orc_init_helmholtz27(const orc_layout_t *lc, double *cf, const orc_geom_t *g, int coef_fn, const double *p,
@@ -509,9 +510,9 @@ void orc_init_helmholtz27(const orc_layout_t *lc, double *cf, const orc_geom_t *
               ae[sx][sy][sz] = orc_eval_fn(coef_fn, p, x + (sx ? 0.5 : -0.5) * h, y + (sy ? 0.5 : -0.5) * h, z + (sz ? 0.5 : -0.5) * h);
         const ptrdiff_t k = lay_idx(lc, i0, i1, i2);
         int ent = 1;
-        for (int dx = -1; dx <= 1; ++dx)
+        for (int dz = -1; dz <= 1; ++dz)
           for (int dy = -1; dy <= 1; ++dy)
-            for (int dz = -1; dz <= 1; ++dz) {
+            for (int dx = -1; dx <= 1; ++dx) {
               const int nnz = (dx != 0) + (dy != 0) + (dz != 0);
               double s = 0.0;
               int first = 1;

@@ -832,7 +832,7 @@ class ProgramB:
         pp = (C.c_double * 4)(self.cfg.kappa, self.cfg.ksq, 0, 0)
         lc = lay.c()
         lib().orc_init_helmholtz27(C.byref(lc), _ptr(cf), C.byref(g), self.cfg.coef_fn, pp, _ivec(b), _ivec(e))
-        offs = [(0, 0, 0)] + [(a, b_, c) for a in (-1, 0, 1) for b_ in (-1, 0, 1) for c in (-1, 0, 1) if (a, b_, c) != (0, 0, 0)]
+        offs = [(0, 0, 0)] + [(a, b_, c) for c in (-1, 0, 1) for b_ in (-1, 0, 1) for a in (-1, 0, 1) if (a, b_, c) != (0, 0, 0)]
         return Stencil(offs, [], cf, lay)
 
     # -- leveled functions ------------------------------------------------

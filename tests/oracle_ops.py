@@ -94,6 +94,10 @@ class OracleOps:
         self.stencil_op(2, lu, u_in, lf, rhs, lu, tmp, st, w, -1, begin, end)
         self.stencil_op(2, lu, tmp, lf, rhs, lu, u_out, st, w, -1, begin, end)
 
+    def jacobi_residual(self, lu, u_in, u_out, lf, rhs, lr, res, st, w, begin, end):
+        self.stencil_op(2, lu, u_in, lf, rhs, lu, u_out, st, w, -1, begin, end)
+        self.stencil_op(1, lu, u_out, lf, rhs, lr, res, st, 0.0, -1, begin, end)
+
     def jacobi2_boxes(self, lu, u_in, u_out, tmp, lf, rhs, st, w, begin1, end1, begin2, end2):
         tmp.copy_(u_in)
         self.stencil_op(2, lu, u_in, lf, rhs, lu, tmp, st, w, -1, begin1, end1)

@@ -500,6 +500,68 @@ def test_stencil_field_27_entries_under_the_entry_fastest_layout_transformation(
     assert_same(g, c, "27-entry stencil field, entry-fastest coefficients")
 
 
+def _sf27_pair_case(ops, shape, b1, e1, b2, e2, kind, entry_fastest=True):
+    """Two Jacobi steps (kind 'pair': step 1 on box 1, step 2 on box 2) or one step + residual ('residual') on a 27-entry stencil field
+    with random positive-diagonal coefficients; one call on the GPU, the separate loops through the oracle."""
+    from exastencils_amd.field import helmholtz27_offsets
+
+    lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+    u, f, out, tmp, res = (ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size),
+                           ops.new_array(lu.size))
+    ops.fill_random(u, 12345)
+    ops.fill_random(f, 4711)
+    ops.fill_random(out, 5)
+    ops.fill_random(res, 6)
+    cf = ops.new_array(27 * lf.size)
+    ops.fill_random(cf, 99)
+    cf[:lf.size] += 8.0                      # diagonal entry (planes layout: entry 0 first)
+    st = Stencil(helmholtz27_offsets(), [], cf, lf)
+    if entry_fastest:
+        st = st.entry_fastest(ops)
+    L, Fl = lu.c_struct(), lf.c_struct()
+    if kind == "pair":
+        if not entry_fastest:                # the separate loops: step 1 on box 1 into a copy of u (points outside keep u), step 2 on box 2
+            tmp.copy_(u)
+            ops.stencil_op(SMOOTH, L, u, Fl, f, L, tmp, st, 0.8, -1, b1, e1)
+            ops.stencil_op(SMOOTH, L, tmp, Fl, f, L, out, st, 0.8, -1, b2, e2)
+        elif (b1, e1) == (b2, e2):
+            ops.jacobi2(L, u, out, tmp, Fl, f, st, 0.8, b2, e2)
+        else:
+            ops.jacobi2_boxes(L, u, out, tmp, Fl, f, st, 0.8, b1, e1, b2, e2)
+        # compare on box 2 only (outside it the fallback and the pass leave different things)
+        keep = ops.new_array(lu.size)
+        ops.axpby(L, out, L, keep, 1.0, 0.0, b2, e2)
+        return [keep, u]
+    out.copy_(u)       # the residual reads the shell of the box from u_out: both arrays hold the same boundary / ghost values
+    if not entry_fastest:
+        ops.stencil_op(SMOOTH, L, u, Fl, f, L, out, st, 0.8, -1, b2, e2)
+        ops.stencil_op(RESIDUAL, L, out, Fl, f, L, res, st, 0.0, -1, b2, e2)
+    else:
+        ops.jacobi_residual(L, u, out, Fl, f, L, res, st, 0.8, b2, e2)
+    ko, kr = ops.new_array(lu.size), ops.new_array(lu.size)
+    ops.axpby(L, out, L, ko, 1.0, 0.0, b2, e2)
+    ops.axpby(L, res, L, kr, 1.0, 0.0, b2, e2)
+    return [ko, kr, u]
+
+
+@pytest.mark.parametrize("kind", ["pair", "residual"])
+@pytest.mark.parametrize("shape,b1,e1,b2,e2", [
+    ((66, 66, 66), [1, 1, 1], [66, 66, 66], [1, 1, 1], [66, 66, 66]),          # two x windows, ragged row groups, one chunk
+    ((130, 40, 70), [1, 1, 1], [130, 40, 70], [1, 1, 1], [130, 40, 70]),       # three windows, two z chunks of 64 / 5 planes
+    ((130, 40, 20), [0, 1, 0], [131, 40, 21], [0, 1, 0], [131, 40, 21]),       # interior faces: the halo reaches the ghost layers
+    ((200, 24, 36), [0, 0, 0], [201, 25, 37], [1, 1, 1], [200, 24, 36]),       # separate stage boxes (block with neighbours)
+])
+def test_two_jacobi_steps_on_a_27_entry_field_in_one_pass(hip, orc, kind, shape, b1, e1, b2, e2):
+    """Temporal blocking on config 4's operator (csrc/kernels_sf27pair.hip): both steps of a point share its 216 B of coefficients.
+    Same 27 products in the same order as the one-step loops: bit-identical to running them one after the other (oracle)."""
+    if kind == "residual" and (b1, e1) != (b2, e2):
+        pytest.skip("one step + residual has a single box")
+    g = _sf27_pair_case(hip, shape, b1, e1, b2, e2, kind)
+    hip.synchronize()
+    c = _sf27_pair_case(orc, shape, b1, e1, b2, e2, kind, entry_fastest=False)
+    assert_same([hip.to_host(t) for t in g], [orc.to_host(t) for t in c], "27-entry pair " + kind)
+
+
 @pytest.mark.parametrize("nd,shape", [(3, (70, 20, 12)), (3, (24, 10, 9)), (2, (80, 33, 0))])
 def test_stencil_field_entry_fastest_transformation_other_entry_counts(hip, orc, nd, shape):
     """2d+1-entry stencil fields under the same transformation (generic kernel), all three loop kinds and a coloured half sweep."""
