@@ -759,7 +759,10 @@ def helmholtz27_cycle(ops, L):
                    restrict_scale=1.0, tol=1e-8, cg_max=512, bc_fn=0, sol_fn=9, coef_fn=7, kappa=10.0, ksq=2.0, rhs_from_solution=True,
                    fused_coarse=True,
                    # LayoutTransformations { transform LaplaceCoeff with [x, y, z, i] => [i, x, y, z] }: the 27 entries of a point contiguous
-                   coef_entry_fastest=True)
+                   coef_entry_fastest=True,
+                   # temporal blocking on the coefficient stream (csrc/kernels_sf27pair.hip; same bits as the separate loops): per level 2 + (1 +
+                   # residual) before and 2 + 1 after the coarse-grid correction -- four passes over the coefficients instead of seven
+                   temporal_blocking=True, fused_smooth_residual=True)
     P = SolverFromL3(cfg, ops)
     P.setup()
     r0 = P._residual_and_norm(cfg.max_level)
@@ -786,6 +789,7 @@ def helmholtz27_cycle(ops, L):
         comp += 7 * 240.0 * p + (8.0 * p + 8.0 * c) + 8.0 * c + (16.0 * p + 8.0 * c)
     return {"helmholtz27_vcycle_ms": ms, "helmholtz27_levels": cfg.max_level - cfg.min_level + 1,
             "helmholtz27_coefficient_layout": "entry-fastest (LayoutTransformations [x,y,z,i] => [i,x,y,z])",
+            "helmholtz27_passes_per_level": "pair, step + residual | pair, step (7 loops of 240 B per point in 4 passes over the coefficients)",
             "helmholtz27_residual_reduction_6_cycles": r1 / r0 if r0 else None,
             "helmholtz27_vcycle_frac": comp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 

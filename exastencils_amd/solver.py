@@ -615,6 +615,9 @@ class ConfigL3:
     # stencil fields: the coefficient field under `LayoutTransformations { transform LaplaceCoeff with [x, y, z, i] => [i, x, y, z] }`
     # (layoutTransformation/, Testing/LayoutTrafo/*.exa4): entries of a point contiguous -- ONE coefficient stream per sweep
     coef_entry_fastest: bool = False
+    # single block + Jacobi: the last pre-smoothing step and UpResidual@current as one pass (examg_jacobi_residual: 27-entry record fields
+    # share the coefficient stream between the two loops; same bits as the two statements)
+    fused_smooth_residual: bool = False
     rhs_from_solution: bool = False   # RHS = A * sol_fn (discrete manufactured solution)
     # InitSolution of Testing/Opts/base.exa4:166-170: Solution@finest = (double)std::rand()/RAND_MAX, drawn by every process of the
     # reference's process grid after std::srand(mpiRank) (exastencils_amd/crand.py); None: Solution starts at zero
@@ -845,6 +848,25 @@ class SolverFromL3(_Program):
     def VCycle(self, l: int, solution_is_zero: bool = False):
         if l == self.cfg.min_level:
             return self.VCycle_0(l)
+        if (self.cfg.fused_smooth_residual and self.cfg.smoother == "jacobi" and self.cfg.n_smooth >= 1 and self._single_block() and
+                not solution_is_zero and hasattr(self.ops, "jacobi_residual")):
+            # `repeat n times { Smoother@current }` + `UpResidual@current`: the last Smoother call and the residual loop in one pass.
+            # Both slots of Solution hold the same boundary values (apply_bc writes every slot), which is what the residual reads
+            # around the box.
+            self.Smoothers(l, self.cfg.n_smooth - 1)
+            S, R, F = self.Solution[l], self.Residual[l], self.RHS[l]
+            b, e = self.bounds(S)
+            assert (b, e) == self.bounds(R)
+            self.ops.jacobi_residual(S.lc, S.data(S.active), S.data(S.next), F.lc, F.data(), R.lc, R.data(), self.Laplace[l], self._w(l), b, e)
+            S.advance()
+            self.Restriction(l)
+            zero_start = self._starts_from_zero(l - 1)
+            if not zero_start:
+                self.SetSolution(l - 1, 0.0)
+            self.VCycle(l - 1, solution_is_zero=zero_start)
+            self.Correction(l)
+            self.Smoothers(l, self.cfg.n_smooth)
+            return
         self.Smoothers(l, self.cfg.n_smooth, zero_input=solution_is_zero)
         if self.cfg.fused_residual_restrict and self._single_block():
             # UpResidual@current + Restriction@current: nothing reads Residual@current before UpResidual writes it again

@@ -123,7 +123,8 @@ def test_config4_helmholtz27_history_vs_own_oracle(hip, name, entry_fastest):
     kw["frag_len"] = tuple(kw["frag_len"])
     # entry_fastest: the coefficient fields under `transform LaplaceCoeff with [x, y, z, i] => [i, x, y, z]` (what bench.py runs):
     # where the coefficients live changes, no value does -- the same fixture
-    P = SolverFromL3(ConfigL3(**kw, coef_entry_fastest=entry_fastest), hip)
+    # ... together with the one-pass forms on the records (pairs of steps, step + residual): the same statements
+    P = SolverFromL3(ConfigL3(**kw, coef_entry_fastest=entry_fastest, temporal_blocking=entry_fastest, fused_smooth_residual=entry_fastest), hip)
     assert all(A.ctransform == (1 if entry_fastest else 0) for A in P.Laplace.values())
     P.setup()
     P.Solve()

@@ -571,6 +571,12 @@ def test_config4_helmholtz27_on_gpu(hip):
     assert P.iterations == O.iterations
     _close(P.res_history, O.res_history, 1e-9)       # coefficients pass through device exp()
     assert P.err_history[-1] < 1e-8
+    # what bench.py runs: coefficient records, pairs of Jacobi steps and the last pre-smoothing step + residual as one pass each
+    # (csrc/kernels_sf27pair.hip on the levels with rows of 32 points and more): the same statements -- the same bits
+    Q = SolverFromL3(ConfigL3(frag_len=(2, 2, 2), coef_entry_fastest=True, temporal_blocking=True, fused_smooth_residual=True, **kw), hip)
+    Q.setup()
+    Q.Solve()
+    assert Q.res_history == P.res_history and Q.err_history == P.err_history
 
 
 def test_cpp_host_program_matches_oracle():

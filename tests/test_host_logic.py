@@ -146,6 +146,11 @@ def test_config4_helmholtz27_program():
     P.Solve()
     assert P.res_history == O.res_history and P.err_history == O.err_history
     assert P.iterations <= 8 and P.err_history[-1] < 1e-8
+    # pairs of Jacobi steps and the last pre-smoothing step + residual as single calls: the same statements, the same bits
+    Q = SolverFromL3(ConfigL3(frag_len=(2, 2, 2), temporal_blocking=True, fused_smooth_residual=True, **HELMHOLTZ27), OracleOps())
+    Q.setup()
+    Q.Solve()
+    assert Q.res_history == P.res_history and Q.err_history == P.err_history
     # the stencil field is symmetric positive: row sums equal -k^2 in the interior (constant functions are in the kernel
     # of the stiffness part), diagonal positive
     import numpy as np
