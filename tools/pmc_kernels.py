@@ -47,7 +47,7 @@ def cases(ops, level, with27=True, align=0):
         ("rbgs_half_sweep", lambda: ops.stencil_op(2, L, u, F, f, L, u, A, w, 0, b, e), "k_stencil7_zmarch<2", 24 * pts, pts // 2),
         ("jacobi_2step", lambda: ops.jacobi2(L, u, un, None, F, f, A, w, b, e), "k_two_stage7_lds<0, false, 8, true, 1, 0", 24 * pts, 2 * pts),
         ("rbgs_fused_sweep", lambda: ops.rbgs_sweep_fused(L, u, un, F, f, A, w, 0, b, e), "k_two_stage7_lds<0, true, 8, true, 1, 0", 24 * pts, pts),
-        ("rbgs_fused_sweep_prolong", lambda: ops.rbgs_sweep_fused_prolong(L, u, un, F, f, A, w, 0, b, e, Lc, uc), "k_two_stage7_lds<0, true, 8, true, 4, 1",
+        ("rbgs_fused_sweep_prolong", lambda: ops.rbgs_sweep_fused_prolong(L, u, un, F, f, A, w, 0, b, e, Lc, uc), "k_two_stage7_lds<0, true, 8, true, 1, 1",
          24 * pts + 8 * cpts, pts),
         ("rbgs_fused_sweep_zero", lambda: ops.rbgs_sweep_fused_zero(L, un, F, f, A, w, 0, b, e), "k_two_stage7_lds<0, true, 8, true, 1, 2", 16 * pts, pts),
         ("residual_restrict", lambda: ops.residual_restrict(L, u, F, f, L, r, A, Fc, fc, 1.0, b, e, bc, ec), "k_residual_restrict3",
@@ -84,6 +84,12 @@ def cases(ops, level, with27=True, align=0):
         A27t = A27.entry_fastest(ops)
         cs.append(("jacobi_27entry_field_entry_fastest", lambda: ops.stencil_op(2, L, u, Fn, f27, L, un, A27t, 0.8, -1, b, e),
                    "k_stencilfield27_rec<2>", (24 + 8 * 27) * pts, pts))
+        # temporal blocking on the records (csrc/kernels_sf27pair.hip): both loops of a pair share the coefficients of a point
+        r27 = ops.new_array(lu.size)
+        cs.append(("jacobi_27entry_two_steps", lambda: ops.jacobi2(L, u, un, None, Fn, f27, A27t, 0.8, b, e),
+                   "k_sf27_two_stage<2>", (24 + 8 * 27) * pts, 2 * pts))
+        cs.append(("jacobi_27entry_step_residual", lambda: ops.jacobi_residual(L, u, un, Fn, f27, L, r27, A27t, 0.8, b, e),
+                   "k_sf27_two_stage<1>", (32 + 8 * 27) * pts, 2 * pts))
     return cs, dict(u=u)
 
 
