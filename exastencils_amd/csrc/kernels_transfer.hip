@@ -54,30 +54,35 @@ k_restrict(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, double 
 // one 16-byte load, the (2I-1) column from the lane below (DPP; lane 0 reads it).  A wave owns 64 coarse points of one
 // coarse row and marches in coarse z: fine plane 2K+1 serves coarse planes K and K+1, so a step loads 6 rows, not 9.
 // Same 27 products in the same order as k_restrict (x offset outermost, then y, then z).
+// RW = 2: a wave owns TWO consecutive coarse rows (five fine rows 2J-1 .. 2J+3 instead of 2 x 3: the fine row between them is read
+// once -- fabric traffic 1.51 x -> 1.25 x compulsory).
+template <int RW>
 __global__ void __launch_bounds__(256)
 k_restrict3_wide(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, double *__restrict__ fc, double scale, Box box,
                  int ntx, int zc, int nwaves) {
+  constexpr int NR = 2 * RW + 1;      // fine rows of the wave
   const int lane = threadIdx.x;
   long long t = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
   if (t >= nwaves) return;
   const int tx = (int)(t % ntx);
   t /= ntx;
-  const int n1 = box.n1();
-  const int I1 = box.b1 + (int)(t % n1);
-  const int kb = box.b2 + (int)(t / n1) * zc;
+  const int n1w = (box.n1() + RW - 1) / RW;
+  const int I1 = box.b1 + (int)(t % n1w) * RW;
+  const int kb = box.b2 + (int)(t / n1w) * zc;
   const int ke = min(kb + zc, box.e2);
   int I0 = box.b0 + tx * 64 + lane;
   const bool valid = I0 < box.e0;
   if (!valid) I0 = box.e0 - 1;
-  const double *row[3];
+  const bool second = RW == 2 && I1 + 1 < box.e1;      // wave-uniform: the box has this wave's second coarse row
+  const double *row[NR];
 #pragma unroll
-  for (int b = 0; b < 3; ++b) row[b] = rf + lfine.origin + 2 * I0 + lfine.s1 * (2 * I1 + b - 1);
+  for (int b = 0; b < NR; ++b) row[b] = rf + lfine.origin + 2 * I0 + lfine.s1 * (2 * I1 + ((b < 3 || second) ? b : 2) - 1);
   double *out = fc + lc.origin + I0 + lc.s1 * I1;
   const double w1[3] = {0.25, 0.5, 0.25};
-  d2 P[3][3];      // [plane slot: 2K-1, 2K, 2K+1][row: 2J-1, 2J, 2J+1]
-  double E[3][3];  // lane 0: the column 2I-1
+  d2 P[3][NR];      // [plane slot: 2K-1, 2K, 2K+1][fine row]
+  double E[3][NR];  // lane 0: the column 2I-1
 #pragma unroll
-  for (int b = 0; b < 3; ++b) {
+  for (int b = 0; b < NR; ++b) {
     P[0][b] = load2(row[b] + lfine.s2 * (2 * kb - 1));
     E[0][b] = lane == 0 ? row[b][lfine.s2 * (2 * kb - 1) - 1] : 0.0;
   }
@@ -85,34 +90,37 @@ k_restrict3_wide(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, d
 #pragma unroll
     for (int c = 1; c < 3; ++c)
 #pragma unroll
-      for (int b = 0; b < 3; ++b) P[c][b] = load2(row[b] + lfine.s2 * (2 * K + c - 1));
+      for (int b = 0; b < NR; ++b) P[c][b] = load2(row[b] + lfine.s2 * (2 * K + c - 1));
     if (lane == 0) {
 #pragma unroll
       for (int c = 1; c < 3; ++c)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) E[c][b] = row[b][lfine.s2 * (2 * K + c - 1) - 1];
+        for (int b = 0; b < NR; ++b) E[c][b] = row[b][lfine.s2 * (2 * K + c - 1) - 1];
     }
-    double acc = 0.0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int r = 0; r < RW; ++r) {
+      double acc = 0.0;
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          double v;
-          if (a == 0) {
-            v = lane_below(P[c][b].y);
-            if (lane == 0) v = E[c][b];
-          } else {
-            v = a == 1 ? P[c][b].x : P[c][b].y;
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double v;
+            if (a == 0) {
+              v = lane_below(P[c][2 * r + b].y);
+              if (lane == 0) v = E[c][2 * r + b];
+            } else {
+              v = a == 1 ? P[c][2 * r + b].x : P[c][2 * r + b].y;
+            }
+            const double wgt = scale * ((w1[a] * w1[b]) * w1[c]);
+            const double tv = wgt * v;
+            acc = (a == 0 && b == 0 && c == 0) ? tv : acc + tv;
           }
-          const double wgt = scale * ((w1[a] * w1[b]) * w1[c]);
-          const double tv = wgt * v;
-          acc = (a == 0 && b == 0 && c == 0) ? tv : acc + tv;
-        }
-    if (valid) out[lc.s2 * K] = acc;
+      if (valid && (r == 0 || second)) out[lc.s1 * r + lc.s2 * K] = acc;
+    }
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < NR; ++b) {
       P[0][b] = P[2][b];
       E[0][b] = E[2][b];
     }
@@ -326,6 +334,7 @@ static thread_local int g_restrict_wide = 1;
 // chunks of 8 coarse planes at any size: with a fixed count of 24576 waves the chunks of blocks larger than 512^3 grew long and the
 // front wide (tools/sweep_big_others.py: 768^3 1.86 -> 1.75 ms, 1024^3 4.69 -> 4.16 ms; 512^3 0.527 -> 0.523, there 13 planes before)
 static thread_local int g_rr_waves = 1 << 22, g_rr_minzc = 8;
+static thread_local int g_restrict_rows = 2;     // examg_debug_restrict(-1 / -2): coarse rows per wave of the wide restriction kernel
 static thread_local int g_restrict_waves = -1;   // examg_debug_restrict(n > 1): wave count target of the wide restriction kernel
 static thread_local int g_prolong_zb = -1;    // planes per workgroup of the pair prolongation (examg_debug_prolong)   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
 
@@ -352,6 +361,7 @@ extern "C" int examg_debug_prolong(int zb) {
   return 0;
 }
 extern "C" int examg_debug_restrict(int wide) {
+  if (wide < 0) { examg::g_restrict_rows = wide == -1 ? 1 : 2; return 0; }
   examg::g_restrict_wide = wide != 0;
   examg::g_restrict_waves = wide > 1 ? wide : -1;
   return 0;
@@ -374,7 +384,8 @@ extern "C" int examg_restrict(const examg_layout_t *lfine_, const double *rf, co
   hipStream_t s = (hipStream_t)stream;
   if (lfine_->nd == 3 && box.n0() >= 32 && g_restrict_wide) {
     const int ntx = (box.n0() + 63) / 64;
-    const long long cols = (long long)ntx * box.n1();
+    const int rw = g_restrict_rows == 1 ? 1 : 2;      // coarse rows per wave
+    const long long cols = (long long)ntx * ((box.n1() + rw - 1) / rw);
     // ~4096 waves up to 512^3 -> 256^3; beyond that shorter chunks (tools/sweep_big_others2.py: 768^3 -> 384^3 0.90 -> 0.83 ms,
     // 1024^3 -> 512^3 2.35 -> 2.14 ms with 65536 waves)
     const int waves_target = g_restrict_waves > 0 ? g_restrict_waves : (box.count() >= 25000000LL ? 65536 : 4096);
@@ -385,8 +396,12 @@ extern "C" int examg_restrict(const examg_layout_t *lfine_, const double *rf, co
     if (zc > box.n2()) zc = box.n2();
     ntz = (box.n2() + zc - 1) / zc;
     const long long nwaves = cols * ntz;
-    hipLaunchKernelGGL(k_restrict3_wide, dim3((unsigned)((nwaves + 3) / 4)), dim3(64, 4, 1), 0, s, lf, rf, lc, fc, scale, box, ntx, zc,
-                       (int)nwaves);
+    if (rw == 2)
+      hipLaunchKernelGGL((k_restrict3_wide<2>), dim3((unsigned)((nwaves + 3) / 4)), dim3(64, 4, 1), 0, s, lf, rf, lc, fc, scale, box, ntx, zc,
+                         (int)nwaves);
+    else
+      hipLaunchKernelGGL((k_restrict3_wide<1>), dim3((unsigned)((nwaves + 3) / 4)), dim3(64, 4, 1), 0, s, lf, rf, lc, fc, scale, box, ntx, zc,
+                         (int)nwaves);
   } else if (lfine_->nd == 3) hipLaunchKernelGGL((k_restrict<3>), grid_for(box.count()), dim3(256), 0, s, lf, rf, lc, fc, scale, box);
   else if (lfine_->nd == 2) hipLaunchKernelGGL((k_restrict<2>), grid_for(box.count()), dim3(256), 0, s, lf, rf, lc, fc, scale, box);
   else { set_error("examg_restrict: nd must be 2 or 3"); return 1; }
