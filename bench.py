@@ -643,7 +643,7 @@ def vcycle(ops, dom, comm, L, world, align=0, check_dups=True):
     # the gathered coarsest level grows with the blocks (16 x 32 x 64 points on 8 GPUs, 5 ms for a single-workgroup CG): it
     # coarsens log2(max blocks per dimension) levels further, back to a few hundred points
     extra = max(dom.num_blocks).bit_length() - 1 if world > 1 else 0
-    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True, agglomerate_level=agg, fused_prolong_min_points=50_000_000, fused_zero_start=True, fused_residual_norm=True,
+    cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True, agglomerate_level=agg, fused_prolong_min_points=10_000_000, fused_zero_start=True, fused_residual_norm=True,
                    agglomerate_extra_levels=extra, align=align)
     P = SolverFromL4(cfg, ops, dom, comm)
     P.setup()
@@ -725,7 +725,7 @@ def fmg_solve(ops, L, align=0):
     from exastencils_amd.solver import ConfigL3, SolverFromL3
 
     cfg = ConfigL3(nd=3, min_level=2, max_level=L, smoother="rbgs", omega=1.0, stencil="scaled", restrict_scale=1.0, tol=1e-6,
-                   cg_max=512, bc_fn=1, fmg=True, fused_rbgs=True, fused_residual_restrict=True, fused_prolong_min_points=50_000_000,
+                   cg_max=512, bc_fn=1, fmg=True, fused_rbgs=True, fused_residual_restrict=True, fused_prolong_min_points=10_000_000,
                    fused_zero_start=True, fused_residual_norm=True, fused_coarse=True, align=align)
     P = SolverFromL3(cfg, ops)
     P.setup()

@@ -14,7 +14,7 @@
 // it by the summation order of the reduction (1e-15 relative).
 //
 //   hipcc --offload-arch=gfx950 -O2 -Iinclude examples/poisson3d_fast_host.cpp -Lexastencils_amd -lexamg -o poisson3d_fast_host
-//   LD_LIBRARY_PATH=exastencils_amd ./poisson3d_fast_host [maxLevel=9] [minLevel=4] [foldMinPoints=50000000]
+//   LD_LIBRARY_PATH=exastencils_amd ./poisson3d_fast_host [maxLevel=9] [minLevel=4] [foldMinPoints=10000000]
 //
 // Prints the residual norm per V-cycle (4 significant digits), the full-precision values ('# ' lines), the iteration count, and
 // `vcycle_ms` (graph replay, steady state) / `totalTimeSolve_ms` (the benchmark's own reported quantity).
@@ -38,7 +38,7 @@ static void checkHip(hipError_t e, const char *what) {
 }
 
 static int minLevel = 4, maxLevel = 9;
-static long long foldMinPoints = 50000000;
+static long long foldMinPoints = 10000000;
 struct Level {
   examg_layout_t withComm, noGhost;
   double *Solution, *SolutionAlt, *RHS, *Residual;   // SolutionAlt: the second array of the out-of-place sweeps

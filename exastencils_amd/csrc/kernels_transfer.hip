@@ -134,16 +134,20 @@ k_restrict3_wide(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, d
 // produce a coarse value (lane 0 only supplies r(2I-1) to lane 1 through the DPP shift), tiles advance by 63 points.
 // Every residual is the expression of the residual kernel, the 27 products are added in k_restrict's order: bit-identical
 // to examg_residual followed by examg_restrict.
-template <int ORDER>
+// RW = 2: a wave owns TWO consecutive coarse rows: seven fine rows of u and five of rhs for four fine rows of progress instead of
+// 2 x (5 + 3), five residual rows instead of 2 x 3 (the row between the two coarse rows is evaluated once).
+template <int ORDER, int RW>
 __global__ void __launch_bounds__(256)
 k_residual_restrict3(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ f, LayoutDev lc,
                      double *__restrict__ fc, Coef7 k, double scale, Box box, int ntx, int zc, int nwaves) {
+  constexpr int NR = 2 * RW + 1;     // residual (and rhs) rows of the wave: 2J-1 .. 2J+2RW-1
+  constexpr int NU = NR + 2;         // u rows: 2J-2 .. 2J+2RW
   const int lane = threadIdx.x;
   long long t = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
   if (t >= nwaves) return;
-  const int n1 = box.n1();
-  const int J = box.b1 + (int)(t % n1);        // consecutive waves of a workgroup: consecutive coarse rows (shared fine rows)
-  t /= n1;
+  const int n1w = (box.n1() + RW - 1) / RW;
+  const int J = box.b1 + (int)(t % n1w) * RW;   // consecutive waves of a workgroup: consecutive coarse rows (shared fine rows)
+  t /= n1w;
   const int tx = (int)(t % ntx);
   const int kb = box.b2 + (int)(t / ntx) * zc;
   const int ke = min(kb + zc, box.e2);
@@ -151,23 +155,25 @@ k_residual_restrict3(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, c
   const bool valid = lane >= 1 && I < box.e0;
   if (I >= box.e0) I = box.e0 - 1;
   const bool edge = lane == 63 || I == box.e0 - 1;   // the x+1 neighbour of the pair's second point is in no lane
-  const double *ur[5], *fr[3];
+  const bool second = RW == 2 && J + 1 < box.e1;     // wave-uniform: the box has this wave's second coarse row
+  // rows of a second coarse row that the box does not have are read as the last rows of the first (nothing is stored for them)
+  const double *ur[NU], *fr[NR];
 #pragma unroll
-  for (int r = 0; r < 5; ++r) ur[r] = u + lu.origin + 2 * I + lu.s1 * (2 * J - 2 + r);
+  for (int r = 0; r < NU; ++r) ur[r] = u + lu.origin + 2 * I + lu.s1 * (2 * J - 2 + ((r < 5 || second) ? r : 4));
 #pragma unroll
-  for (int r = 0; r < 3; ++r) fr[r] = f + lf.origin + 2 * I + lf.s1 * (2 * J - 1 + r);
+  for (int r = 0; r < NR; ++r) fr[r] = f + lf.origin + 2 * I + lf.s1 * (2 * J - 1 + ((r < 3 || second) ? r : 2));
   double *out = fc + lc.origin + I + lc.s1 * J;
   const double w1[3] = {0.25, 0.5, 0.25};
 
-  d2 U[3][5];   // fine planes p-1, p, p+1; rows 2J-2 .. 2J+2
-  d2 R[3][3];   // residual planes 2K-1, 2K, 2K+1; rows 2J-1 .. 2J+1
-  auto load_plane = [&](d2 (&P)[5], int p) {
+  d2 U[3][NU];   // fine planes p-1, p, p+1
+  d2 R[3][NR];   // residual planes 2K-1, 2K, 2K+1
+  auto load_plane = [&](d2 (&P)[NU], int p) {
 #pragma unroll
-    for (int r = 0; r < 5; ++r) P[r] = load2(ur[r] + lu.s2 * p);
+    for (int r = 0; r < NU; ++r) P[r] = load2(ur[r] + lu.s2 * p);
   };
-  auto residual_plane = [&](d2 (&out_r)[3], int p) {      // needs U = planes p-1, p, p+1
+  auto residual_plane = [&](d2 (&out_r)[NR], int p) {      // needs U = planes p-1, p, p+1
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < NR; ++b) {
       const d2 c = U[1][b + 1], ym = U[1][b], yp = U[1][b + 2], zm = U[0][b + 1], zp = U[2][b + 1];
       const d2 fv = load2(fr[b] + lf.s2 * p);
       const double xl = lane_below(c.y);
@@ -189,28 +195,32 @@ k_residual_restrict3(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, c
     for (int c = 1; c < 3; ++c) {
       const int p = 2 * K + c - 1;                        // fine plane of this residual plane
 #pragma unroll
-      for (int r = 0; r < 5; ++r) {
+      for (int r = 0; r < NU; ++r) {
         U[0][r] = U[1][r];
         U[1][r] = U[2][r];
       }
       load_plane(U[2], p + 1);
       residual_plane(R[c], p);
     }
-    double acc = 0.0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int q = 0; q < RW; ++q) {
+      double acc = 0.0;
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const double v = a == 0 ? lane_below(R[c][b].y) : (a == 1 ? R[c][b].x : R[c][b].y);
-          const double wgt = scale * ((w1[a] * w1[b]) * w1[c]);
-          const double tv = wgt * v;
-          acc = (a == 0 && b == 0 && c == 0) ? tv : acc + tv;
-        }
-    if (valid) out[lc.s2 * K] = acc;
+        for (int b = 0; b < 3; ++b)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) R[0][b] = R[2][b];
+          for (int c = 0; c < 3; ++c) {
+            const d2 rv = R[c][2 * q + b];
+            const double v = a == 0 ? lane_below(rv.y) : (a == 1 ? rv.x : rv.y);
+            const double wgt = scale * ((w1[a] * w1[b]) * w1[c]);
+            const double tv = wgt * v;
+            acc = (a == 0 && b == 0 && c == 0) ? tv : acc + tv;
+          }
+      if (valid && (q == 0 || second)) out[lc.s1 * q + lc.s2 * K] = acc;
+    }
+#pragma unroll
+    for (int b = 0; b < NR; ++b) R[0][b] = R[2][b];
   }
 }
 
@@ -333,7 +343,7 @@ static thread_local int g_restrict_wide = 1;
 // 4096: 0.560, 9216: 0.511, 18432: 0.486, 24576: 0.479, 36864: 0.481 -- many short waves keep the tail of the launch short
 // chunks of 8 coarse planes at any size: with a fixed count of 24576 waves the chunks of blocks larger than 512^3 grew long and the
 // front wide (tools/sweep_big_others.py: 768^3 1.86 -> 1.75 ms, 1024^3 4.69 -> 4.16 ms; 512^3 0.527 -> 0.523, there 13 planes before)
-static thread_local int g_rr_waves = 1 << 22, g_rr_minzc = 8;
+static thread_local int g_rr_waves = 1 << 22, g_rr_minzc = 8, g_rr_rows = 0;   // examg_debug_residual_restrict(waves, minzc [+ 1000: two coarse rows per wave, + 2000: one]); 0 = by size
 static thread_local int g_restrict_rows = 2;     // examg_debug_restrict(-1 / -2): coarse rows per wave of the wide restriction kernel
 static thread_local int g_restrict_waves = -1;   // examg_debug_restrict(n > 1): wave count target of the wide restriction kernel
 static thread_local int g_prolong_zb = -1;    // planes per workgroup of the pair prolongation (examg_debug_prolong)   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
@@ -352,6 +362,8 @@ using namespace examg;
 #ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_residual_restrict(int waves, int minzc) {
   examg::g_rr_waves = waves > 0 ? waves : (1 << 22);
+  examg::g_rr_rows = minzc >= 2000 ? 1 : (minzc >= 1000 ? 2 : 0);
+  minzc %= 1000;
   if (minzc > 0) examg::g_rr_minzc = minzc;
   return 0;
 }
@@ -447,7 +459,10 @@ extern "C" int examg_residual_restrict(const examg_layout_t *lu_, const double *
     Coef7 k;
     for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
     const int ntx = (cb.n0() + 62) / 63;
-    const long long cols = (long long)ntx * cb.n1();
+    // coarse rows per wave: two from 512^3 -> 256^3 (0.520 -> 0.496 ms; 242 VGPRs, two waves per SIMD), one below (256^3 -> 128^3: 0.067 ms
+    // against 0.074 with two)
+    const int rw = g_rr_rows > 0 ? g_rr_rows : (cb.count() >= 8000000LL ? 2 : 1);
+    const long long cols = (long long)ntx * ((cb.n1() + rw - 1) / rw);
     int ntz = (int)((g_rr_waves + cols - 1) / cols);
     if (ntz < 1) ntz = 1;
     int zc = (cb.n2() + ntz - 1) / ntz;
@@ -457,8 +472,15 @@ extern "C" int examg_residual_restrict(const examg_layout_t *lu_, const double *
     const long long nwaves = cols * ntz;
     dim3 grid((unsigned)((nwaves + 3) / 4)), block(64, 4, 1);
     hipStream_t s = (hipStream_t)stream;
-    if (ord == 0) hipLaunchKernelGGL((k_residual_restrict3<0>), grid, block, 0, s, lu, u, lf, rhs, lc, fc, k, scale, cb, ntx, zc, (int)nwaves);
-    else hipLaunchKernelGGL((k_residual_restrict3<1>), grid, block, 0, s, lu, u, lf, rhs, lc, fc, k, scale, cb, ntx, zc, (int)nwaves);
+#define EXAMG_RR(O, W) hipLaunchKernelGGL((k_residual_restrict3<O, W>), grid, block, 0, s, lu, u, lf, rhs, lc, fc, k, scale, cb, ntx, zc, (int)nwaves)
+    if (rw == 2) {
+      if (ord == 0) EXAMG_RR(0, 2);
+      else EXAMG_RR(1, 2);
+    } else {
+      if (ord == 0) EXAMG_RR(0, 1);
+      else EXAMG_RR(1, 1);
+    }
+#undef EXAMG_RR
     EXAMG_CHECK_LAUNCH("k_residual_restrict3");
     return 0;
   }

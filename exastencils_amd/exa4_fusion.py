@@ -34,7 +34,7 @@ class LazyFusions:
         self._cont: list = []                 # active statement lists, innermost last: [body, index, frame, is_loop, is_function]
         self._summary: dict = {}
         self.fusions = {"residual_restrict": 0, "residual_norm": 0, "zero_start": 0, "folded_correction": 0}
-        self.fused_prolong_min_points = 50_000_000     # the fold pays from ~5e7 points (exastencils_amd/solver.py: ConfigL4)
+        self.fused_prolong_min_points = 10_000_000     # the fold pays from ~10^7 points: 256^3 0.110 ms against 0.090 + 0.062 for sweep and correction, 128^3 0.028 against 0.023
         # residual + norm sums the squares in the residual kernel's own (fixed) order, not in the order of the dot kernel: the
         # printed norm then differs from `fuse=False` in the last bits (fields stay bit-identical).  Opt-in for that reason.
         self.fuse_residual_norm = False

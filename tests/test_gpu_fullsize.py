@@ -69,10 +69,10 @@ def test_config3_512_history_vs_own_oracle(hip, fused):
     """BASELINE configs[2]: Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:121-249 at 512^3, levels 4..9, RBGS V(3,3),
     CG coarse solve, stop at 1e-6: every residual of the Solve loop within 1e-10 of the oracle's."""
     rec = _fixture("config3_512")
-    cfg = ConfigL4(**rec["config"], fused_rbgs=fused, fused_residual_restrict=fused, fused_prolong_min_points=50_000_000 if fused else 0, fused_zero_start=fused, fused_residual_norm=fused)
+    cfg = ConfigL4(**rec["config"], fused_rbgs=fused, fused_residual_restrict=fused, fused_prolong_min_points=10_000_000 if fused else 0, fused_zero_start=fused, fused_residual_norm=fused)
     P = SolverFromL4(cfg, hip)
     P.setup()
-    assert P._folds_prolongation(cfg.max_level) == fused and not P._folds_prolongation(cfg.max_level - 1)
+    assert P._folds_prolongation(cfg.max_level) == fused and P._folds_prolongation(cfg.max_level - 1) == fused and not P._folds_prolongation(cfg.max_level - 2)
     P.Solve()
     assert P.iterations == rec["iterations"]
     _check_history(P.res_history, rec["res"])
@@ -82,7 +82,7 @@ def test_config3_512_history_vs_own_oracle(hip, fused):
 def test_config3_512_graph_replay_history(hip):
     """The same solve with the V-cycle replayed from a hipGraph (what bench.py times)."""
     rec = _fixture("config3_512")
-    cfg = ConfigL4(**rec["config"], fused_rbgs=True, fused_residual_restrict=True, fused_prolong_min_points=50_000_000, fused_zero_start=True, fused_residual_norm=True)
+    cfg = ConfigL4(**rec["config"], fused_rbgs=True, fused_residual_restrict=True, fused_prolong_min_points=10_000_000, fused_zero_start=True, fused_residual_norm=True)
     P = SolverFromL4(cfg, hip)
     P.setup()
     P.capture_cycle()
@@ -98,7 +98,7 @@ def test_config5_512_fmg_history_vs_own_oracle(hip, fused):
     red-black V(3,3) cycles (Testing/Smoothers/RBGS.exa4:125-133), levels 2..9."""
     rec = _fixture("config5_512")
     kw = dict(rec["config"])
-    P = SolverFromL3(ConfigL3(**kw, fused_rbgs=fused, fused_residual_restrict=fused, fused_prolong_min_points=50_000_000 if fused else 0,
+    P = SolverFromL3(ConfigL3(**kw, fused_rbgs=fused, fused_residual_restrict=fused, fused_prolong_min_points=10_000_000 if fused else 0,
                               fused_zero_start=fused, fused_residual_norm=fused, fused_coarse=fused), hip)
     P.setup()
     assert P._folds_prolongation(kw["max_level"]) == fused
