@@ -40,7 +40,7 @@ __host__ __device__ constexpr int s27_dy(int k) {
 __host__ __device__ constexpr int s27_dz(int k) { return k == 0 ? 0 : (k <= 9 ? -1 : (k <= 17 ? 0 : 1)); }
 
 static thread_local int g_s27_disable = 0;    // examg_debug_sf27_pair(0 / 1, planes per chunk)
-static thread_local int g_s27_zc = 64;
+static thread_local int g_s27_zc = 0;       // 0: by the rule in launch_sf27_pair
 
 template <int MODE2>   // second stage: EXAMG_SMOOTH (-> out) or EXAMG_RESIDUAL (first-stage field -> out, its residual -> res)
 __global__ void __launch_bounds__(64 * S27_NW)
@@ -204,7 +204,19 @@ static int launch_sf27_pair(int mode2, const examg_layout_t *lu_, const double *
   S27Geom g;
   g.ntx = (box2.n0() + S27_XO - 1) / S27_XO;
   g.nty = (box2.n1() + S27_YO - 1) / S27_YO;
-  int zc = g_s27_zc > 0 ? g_s27_zc : 64;
+  // planes per chunk: one workgroup per CU at a time -- the chunk count that minimises  rounds of 256 workgroups x (planes per chunk +
+  // 4 planes of halo and start-up); 512^3: 64 planes (measured: 16 / 32 / 64 / 128 / 256 planes 8.78 / 8.18 / 8.01 / 8.23 / 8.97 ms)
+  int zc = g_s27_zc;
+  if (zc <= 0) {
+    const long long xy = (long long)g.ntx * g.nty;
+    const int n2 = box2.n2();
+    long long best = -1;
+    for (int t = 1; t <= (n2 + 7) / 8; ++t) {
+      const int c = (n2 + t - 1) / t;
+      const long long cost = ((xy * ((n2 + c - 1) / c) + 255) / 256) * (c + 4);
+      if (best < 0 || cost < best) { best = cost; zc = c; }
+    }
+  }
   if (zc > box2.n2()) zc = box2.n2();
   g.zc = zc;
   g.ntz = (box2.n2() + zc - 1) / zc;
@@ -234,7 +246,7 @@ using namespace examg;
 #ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_sf27_pair(int enable, int zc) {
   g_s27_disable = enable ? 0 : 1;
-  g_s27_zc = zc > 0 ? zc : 64;
+  g_s27_zc = zc > 0 ? zc : 0;
   return 0;
 }
 #endif

@@ -43,14 +43,18 @@ cases = [("one step, planes", lambda: ops.stencil_op(2, Ls, u, Fs, f, Ls, un, pl
          ("step + residual, one pass", lambda: ops.jacobi_residual(Ls, u, un, Fs, f, Ls, res, rec, 0.8, b, e), 248)]
 if dbg:
     L.examg_debug_sf27_pair.argtypes = [C.c_int, C.c_int]
-    for zc in (16, 32, 64, 128, 256):
+    for zc in (16, 32, 37, 64, 128, 256):
         cases.append(("two steps, one pass, %d planes" % zc, (lambda zc=zc: (L.examg_debug_sf27_pair(1, zc), ops.jacobi2(Ls, u, un, None, Fs, f, rec, 0.8, b, e))), 240))
 for _ in range(5):
     for _, fn, _ in cases:
         fn()
+if dbg:
+    L.examg_debug_sf27_pair(1, 0)
 out = {k: [] for k, _, _ in cases}
 for _ in range(3):
     for k, fn, _ in cases:
+        if dbg and "planes" not in k:
+            L.examg_debug_sf27_pair(1, 0)
         fn(); out[k].append(timed(fn))
 for k, _, nb in cases:
     ms = statistics.median(out[k])
