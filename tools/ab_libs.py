@@ -21,6 +21,8 @@ w = 0.8 / A.diag
 b, e = [1, 1, 1], [n, n, n]
 Ls, Fs, Lc = lu.c_struct(), lf.c_struct(), lc.c_struct()
 cases = {
+    "one Jacobi step": lambda o: o.stencil_op(2, Ls, u, Fs, f, Ls, un, A, w, -1, b, e),
+    "residual": lambda o: o.stencil_op(1, Ls, u, Fs, f, Ls, un, A, 0.0, -1, b, e),
     "two Jacobi steps": lambda o: o.jacobi2(Ls, u, un, None, Fs, f, A, w, b, e),
     "fused red-black sweep": lambda o: o.rbgs_sweep_fused(Ls, u, un, Fs, f, A, w, 0, b, e),
     "correction + sweep": lambda o: o.rbgs_sweep_fused_prolong(Ls, u, un, Fs, f, A, w, 0, b, e, Lc, uc),
