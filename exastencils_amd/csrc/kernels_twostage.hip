@@ -67,12 +67,13 @@ struct TSProl {
 //
 // VAR: 0 = as described; 1 = PROL; 2 = the input field is zero everywhere (a coarse level's first pre-smoothing pass after
 // `Solution = 0`): nothing is loaded for it, the arithmetic is the same expression on the constant 0.0.
-template <int ORDER, bool COL, int NW, bool NT, int WPE, int VAR, int PF = 0>
+template <int ORDER, bool COL, int NW, bool NT, int WPE, int VAR, int PF = 0, int RPW = 2>
 __global__ void __launch_bounds__(64 * NW, WPE)
 k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs,
                  double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g, TSProl pr) {
   constexpr bool PROL = VAR == 1, ZIN = VAR == 2;
-  constexpr int NS = 2 * NW;        // stage-1 rows of the workgroup: s = 0 .. NS-1, global row rw0 - 1 + s
+  static_assert(RPW == 2 || VAR == 0, "the folded forms are written for two rows per wave");
+  constexpr int NS = RPW * NW;      // stage-1 rows of the workgroup: s = 0 .. NS-1, global row rw0 - 1 + s (RPW rows per wave)
   constexpr int NI = NS + 2;        // input rows: i = 0 .. NI-1, global row rw0 - 2 + i (centre of stage-1 row s is i = s+1)
   constexpr int NO = NS - 2;        // output rows: stage-1 rows 1 .. NS-2
   constexpr int NCR = NI / 2 + 1, CW = 66, CT = NCR * CW;   // coarse tile: rows, row pitch (65 columns used), doubles per plane
@@ -111,11 +112,15 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   const bool st_a = out_lane && inx_a, st_b = out_lane && inx_b;
 
   // this wave: stage-1 rows s0 = 2*wv, s0 + 1; their centre input rows i = s + 1; global rows
-  const int s0 = 2 * wv;
-  const int grow[2] = {rw0 - 1 + s0, rw0 + s0};
-  const bool row_in1[2] = {grow[0] >= box1.b1 && grow[0] < box1.e1, grow[1] >= box1.b1 && grow[1] < box1.e1};
-  // output rows: stage-1 rows 1 .. NS-2 inside the box
-  const bool row_out[2] = {s0 >= 1 && grow[0] >= box.b1 && grow[0] < box.e1, s0 + 1 <= NS - 2 && grow[1] >= box.b1 && grow[1] < box.e1};
+  const int s0 = RPW * wv;
+  int grow[RPW];
+  bool row_in1[RPW], row_out[RPW];      // output rows: stage-1 rows 1 .. NS-2 inside the box
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    grow[r] = rw0 - 1 + s0 + r;
+    row_in1[r] = grow[r] >= box1.b1 && grow[r] < box1.e1;
+    row_out[r] = s0 + r >= 1 && s0 + r <= NS - 2 && grow[r] >= box.b1 && grow[r] < box.e1;
+  }
   // the two outermost input rows (i = 0 and i = NI-1) are nobody's centre row: wave 0 / wave NW-1 carry them along
   const bool has_outer = wv == 0 || wv == NW - 1;
   const int outer_i = wv == 0 ? 0 : NI - 1;
@@ -162,8 +167,12 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   auto load_at = [&](const Site &st, long long pb) {
     return load2(reinterpret_cast<const double *>(st.row + pb + st.voff));
   };
-  const Site urow[2] = {site(u, lu, grow[0]), site(u, lu, grow[1])};
-  const Site frow[2] = {site(rhs, lf, grow[0]), site(rhs, lf, grow[1])};
+  Site urow[RPW], frow[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    urow[r] = site(u, lu, grow[r]);
+    frow[r] = site(rhs, lf, grow[r]);
+  }
   const Site uouter = site(u, lu, rw0 - 2 + outer_i);
   PlaneCursor cu = cursor(lu, mb - 2), cf = cursor(lf, mb - 1);    // the next plane to load
   auto load_u = [&](const Site &st) {
@@ -174,8 +183,10 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   // stores: scalar base of (xw, row) on plane 0 of the output + the running offset of plane m + 16 bytes per lane (rows and planes of
   // output points lie inside the allocation; before the first output plane the offset is not used)
   const unsigned vo = (unsigned)lane * 16u;
-  char *const obase[2] = {reinterpret_cast<char *>(out + ((long long)(xw + lu.ref0) + (long long)((unsigned)lu.s1 * (unsigned)max(grow[0] + lu.ref1, 0)))),
-                         reinterpret_cast<char *>(out + ((long long)(xw + lu.ref0) + (long long)((unsigned)lu.s1 * (unsigned)max(grow[1] + lu.ref1, 0))))};
+  char *obase[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+    obase[r] = reinterpret_cast<char *>(out + ((long long)(xw + lu.ref0) + (long long)((unsigned)lu.s1 * (unsigned)max(grow[r] + lu.ref1, 0))));
   long long obytes = uniform64(lu.s2 * 8 * (long long)(mb - 2 + lu.ref2));   // plane m of the first step
   const long long ostep = uniform64(lu.s2 * 8);
 
@@ -186,13 +197,13 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   //   V[j], V[j+1], V[j+2]           stage-1 planes m-1, m (m = q-1) and q (computed in the step)
   //   F[j], F[j+1], F[j+2]           rhs on planes m, q, q+1 (in flight); plane q+2 is loaded into F[j+3]
   //   O[j+2], O[j+3]                 outer halo row on planes q+1, q+2; plane q+3 is loaded into O[j]
-  d2 U[4][2], V[4][2], F[4][2], O[4];
+  d2 U[4][RPW], V[4][RPW], F[4][RPW], O[4];
   d2 Ocur = {0.0, 0.0};
   O[0] = O[1] = O[2] = O[3] = Ocur;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {      // input planes mb-2 .. mb+1; the outer row is not needed on the first of them
-    U[j][0] = load_u(urow[0]);
-    U[j][1] = load_u(urow[1]);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) U[j][r] = load_u(urow[r]);
     if (has_outer && j >= 1) {
       const d2 o = load_u(uouter);
       if (j == 1) Ocur = o;
@@ -202,12 +213,12 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   }
 #pragma unroll
   for (int j = 1; j < 3; ++j) {      // rhs planes mb-1, mb
-    F[j][0] = load_f(0);
-    F[j][1] = load_f(1);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) F[j][r] = load_f(r);
     advance(cf);
   }
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < RPW; ++r) {
     F[0][r] = F[1][r];
     F[3][r] = F[1][r];
   }
@@ -291,7 +302,7 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     corr_plane(U[1], Ocur, mb - 1, Tb, Ta, T_{});      // odd plane: coarse planes Pa + 1, then Pa
   }
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < RPW; ++r) {
     V[0][r] = U[0][r];
     V[1][r] = U[0][r];
     V[2][r] = U[0][r];
@@ -300,8 +311,8 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   // publish input plane q0 = mb-1.  LDS plane buffers are chosen by the step's position in its group of four: the input plane
   // and the stage-1 plane of step j live in buffer j & 1 (compile-time LDS offsets)
   {
-    UB(0, s0 + 1) = U[1][0];
-    UB(0, s0 + 2) = U[1][1];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) UB(0, s0 + 1 + r) = U[1][r];
     if (has_outer) UB(0, outer_i) = Ocur;
   }
   __syncthreads();
@@ -314,11 +325,13 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   // first colour) & 1 -- the same in every workgroup: windows advance by 124 columns, row groups by 2 NW - 2 rows and chunks by an
   // even number of planes (launcher, which picks the instantiation) -- the first point of row r is updated in stage 1 of step j,
   // and in stage 2 (one plane behind, the other colour), iff ((r + j) & 1) == PF: a compile-time fact in the unrolled loop.
-  auto step = [&](const int q, auto PHc) {
-    constexpr int PH = decltype(PHc)::value;
-    d2 (&Um)[2] = U[PH & 3], (&Uc)[2] = U[(PH + 1) & 3], (&Up)[2] = U[(PH + 2) & 3], (&Upf)[2] = U[(PH + 3) & 3];
-    d2 (&Vm)[2] = V[PH & 3], (&Vc)[2] = V[(PH + 1) & 3], (&Vn)[2] = V[(PH + 2) & 3];
-    d2 (&Fm)[2] = F[PH & 3], (&Fq)[2] = F[(PH + 1) & 3], (&Fnew)[2] = F[(PH + 3) & 3];
+  // (With an odd number of rows per wave the parity of a wave's first row alternates from wave to wave: PFW = PF ^ (wave & 1), one copy
+  // of the loop per parity, each wave runs its own.)
+  auto step = [&](const int q, auto PHc, auto PFWc) {
+    constexpr int PH = decltype(PHc)::value, PFW = decltype(PFWc)::value;
+    d2 (&Um)[RPW] = U[PH & 3], (&Uc)[RPW] = U[(PH + 1) & 3], (&Up)[RPW] = U[(PH + 2) & 3], (&Upf)[RPW] = U[(PH + 3) & 3];
+    d2 (&Vm)[RPW] = V[PH & 3], (&Vc)[RPW] = V[(PH + 1) & 3], (&Vn)[RPW] = V[(PH + 2) & 3];
+    d2 (&Fm)[RPW] = F[PH & 3], (&Fq)[RPW] = F[(PH + 1) & 3], (&Fnew)[RPW] = F[(PH + 3) & 3];
     d2 &Oc = O[(PH + 2) & 3], &Onew = O[PH & 3];
     const int m = q - 1;
     constexpr int ub = PH & 1, vb = (PH + 1) & 1;
@@ -329,12 +342,12 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     }
     // y-neighbour rows of this step from LDS
     const d2 ulo = UB(ub, s0);          // input row below the first own row
-    const d2 uhi = UB(ub, s0 + 3);      // input row above the second own row
+    const d2 uhi = UB(ub, s0 + RPW + 1);      // input row above the last own row
     // stage-1 rows below / above the own ones, read without conditions: the first wave's lower and the last wave's upper row do not
     // exist (clamped to some row of the buffer) and are neighbours of halo rows only, which stage 2 does not evaluate; before the
     // first output plane the buffer holds nothing yet and stage 2 does not run
     const d2 vlo = VB(vb, s0 >= 1 ? s0 - 1 : 0);
-    const d2 vhi = VB(vb, s0 + 2 <= NS - 1 ? s0 + 2 : NS - 1);
+    const d2 vhi = VB(vb, s0 + RPW <= NS - 1 ? s0 + RPW : NS - 1);
     // prefetch: input plane q+3 of the own rows is not needed yet; plane q+2 is in flight (Upf), rhs q+1 in flight (Fqn)
     // ---- stage 1 on plane q, own rows ----
     const bool pin = q >= box1.b2 && q < box1.e2;
@@ -342,11 +355,11 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
       constexpr int r = decltype(Rc)::value;
       const d2 c = Uc[r];
       const bool on = pin && row_in1[r];     // wave-uniform; off: the plane / row passes through (evaluated all the same: no branch,
-      const d2 ym = r == 0 ? ulo : Uc[0];    // no copies at a join -- the result is dropped by the select that the x range needs anyway)
-      const d2 yp = r == 0 ? Uc[1] : uhi;
+      const d2 ym = r == 0 ? ulo : Uc[r == 0 ? 0 : r - 1];    // no copies at a join -- the result is dropped by the select that the x range needs anyway)
+      const d2 yp = r == RPW - 1 ? uhi : Uc[r == RPW - 1 ? r : r + 1];
       const d2 f = Fq[r];
       if (COL) {
-        if constexpr (((r + PH) & 1) == PF) {
+        if constexpr (((r + PH) & 1) == PFW) {
           const double xl = lane_below0(c.y);
           const double acc = conv7<ORDER>(k, c.x, xl, c.y, ym.x, yp.x, Um[r].x, Up[r].x);
           const double nv = c.x + w * (f.x - acc);
@@ -371,16 +384,17 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     };
     stage1(I0_{});
     stage1(I1_{});
+    if constexpr (RPW >= 3) stage1(I2_{});
     // ---- stage 2 on plane m = q-1, own rows that are output rows ----
     auto stage2 = [&](auto Rc) {
       constexpr int r = decltype(Rc)::value;
       if (m >= mlo && row_out[r]) {   // wave-uniform
         const d2 c = Vc[r];
-        const d2 ym = r == 0 ? vlo : Vc[0];
-        const d2 yp = r == 0 ? Vc[1] : vhi;
+        const d2 ym = r == 0 ? vlo : Vc[r == 0 ? 0 : r - 1];
+        const d2 yp = r == RPW - 1 ? vhi : Vc[r == RPW - 1 ? r : r + 1];
         d2 o = c;
         if (COL) {
-          if constexpr (((r + PH) & 1) == PF) {
+          if constexpr (((r + PH) & 1) == PFW) {
             const double xl = lane_below0(c.y);
             const double acc = conv7<ORDER>(k, c.x, xl, c.y, ym.x, yp.x, Vm[r].x, Vn[r].x);
             o.x = c.x + w * (Fm[r].x - acc);      // no select: a lane outside the box does not store
@@ -417,14 +431,16 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     };
     stage2(I0_{});
     stage2(I1_{});
+    if constexpr (RPW >= 3) stage2(I2_{});
     // ---- publish input plane q+1 and stage-1 plane q; issue the next loads into the slots this step has finished with ----
     if (q < me) {
       constexpr int nb = (PH + 1) & 1;
-      UB(nb, s0 + 1) = Up[0];
-      UB(nb, s0 + 2) = Up[1];
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        UB(nb, s0 + 1 + r) = Up[r];
+        VB(ub, s0 + r) = Vn[r];
+      }
       if (has_outer) UB(nb, outer_i) = Oc;
-      VB(ub, s0) = Vn[0];
-      VB(ub, s0 + 1) = Vn[1];
       if constexpr (PROL && !(PH & 1)) {
         // even input plane q+1: coarse plane (q+3)/2 is first needed by input plane q+2 (corrected after this step's
         // barrier); its buffer held plane (q-1)/2, last read for input plane q at the start of step q-1
@@ -439,7 +455,7 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     }
     // loads without a condition (past the chunk they fetch planes nobody uses; offsets are clamped into the array)
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < RPW; ++r) {
       Um[r] = load_u(urow[r]);      // the slot of plane q-1 is free: it becomes plane q+3
       Fnew[r] = load_f(r);          // rhs plane q+2
     }
@@ -451,14 +467,22 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);    // nothing of the next step is scheduled into this one (register pressure: 4 waves per SIMD)
   };
-  for (int q = mb - 1; q <= me; q += 4) {
-    step(q, I0_{});
-    if (q + 1 > me) break;
-    step(q + 1, I1_{});
-    if (q + 2 > me) break;
-    step(q + 2, I2_{});
-    if (q + 3 > me) break;
-    step(q + 3, I3_{});
+  auto march = [&](auto PFWc) {
+    for (int q = mb - 1; q <= me; q += 4) {
+      step(q, I0_{}, PFWc);
+      if (q + 1 > me) break;
+      step(q + 1, I1_{}, PFWc);
+      if (q + 2 > me) break;
+      step(q + 2, I2_{}, PFWc);
+      if (q + 3 > me) break;
+      step(q + 3, I3_{}, PFWc);
+    }
+  };
+  if constexpr (COL && (RPW & 1)) {
+    if (wv & 1) march(std::integral_constant<int, PF ^ 1>{});
+    else march(std::integral_constant<int, PF>{});
+  } else {
+    march(std::integral_constant<int, PF>{});
   }
 #undef UB
 #undef VB
@@ -489,11 +513,11 @@ static thread_local int g_ts_lds = -2;
 static thread_local int g_ts_wpe = 1;          // plain passes: 4 = capped at 128 VGPRs (examg_debug_two_stage_prol(wpe + 10) sets it)
 static thread_local int g_ts_prol_wpe = 1;     // PROL variants: 1 = uncapped (151 / 176 VGPRs: 512^3 0.742 ms), 4 = capped at 128 VGPRs (spills in the unrolled loop: 1.15 ms)
 
-template <bool COL, int NW, int WPE = 1>
+template <bool COL, int NW, int WPE = 1, int RPW = 2>
 static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs,
                                 double *out, const examg_stencil_t *st, double w, int first, const Box &box, const Box &box1,
                                 hipStream_t s, const TSProl *prol = nullptr, bool zero_in = false) {
-  constexpr int NO = 2 * NW - 2;
+  constexpr int NO = RPW * NW - 2;
   const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
   TSGeom g;
   // padded layouts (even strides): start the windows so that every 16-byte access is aligned (kernels_stencil.hip: launch_zmarch)
@@ -573,10 +597,11 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
     set_error("examg two-stage kernel: no zero-input variant of this form");
     return 1;
   }
+  if (RPW != 2 && (prol || zero_in)) { set_error("examg two-stage kernel: the folded forms have two rows per wave"); return 1; }
   // COL: the kernel instantiation by the parity that fixes which point of a pair each unrolled step updates (see the kernel)
   const int pf = COL ? ((box.b0 - 2 - g.xs) + (box.b1 - g.ys - 1) + (box.b2 - g.zs - 1) + first) & 1 : 0;
 #define EXAMG_TS_LAUNCH(ORD, W, V, PFV) \
-  hipLaunchKernelGGL((k_two_stage7_lds<ORD, COL, NW, true, W, V, PFV>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr)
+  hipLaunchKernelGGL((k_two_stage7_lds<ORD, COL, NW, true, W, V, PFV, ((V) == 0 ? RPW : 2)>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr)
 #define EXAMG_TS_LAUNCH_PF(ORD, W, V)              \
   do {                                             \
     if constexpr (COL) {                           \
@@ -615,6 +640,13 @@ static int launch_two_stage(const examg_layout_t *lu_, const double *u, const ex
   const Box &b1 = box1 ? *box1 : box;
   int impl = g_ts_lds == -2 ? (box.n1() >= 192 ? 8 : 5) : g_ts_lds;
   if (zero_in && impl == 6) impl = 5;
+  // plain passes on the largest levels: three rows per wave -- 22 of 26 rows of a workgroup are outputs instead of 14 of 18 (100 KB of
+  // LDS, 164-189 VGPRs: one workgroup per CU, which the two-row Jacobi pair has anyway).  512^3, same process: Jacobi pair 0.667 ->
+  // 0.650 ms, red-black sweep 0.672 -> 0.657 (another box: 0.636 -> 0.628, 0.656 -> 0.628)
+  if (g_ts_lds == -2 && impl == 8 && !prol && !zero_in && box.count() >= 50000000LL) impl = 83;
+  if (impl == 83 && !prol && !zero_in)      // three rows per wave: plain passes only
+    return launch_two_stage_lds<COL, 8, 1, 3>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol, zero_in);
+  if (impl == 83) impl = 8;
   if (impl == 8) return launch_two_stage_lds<COL, 8>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol, zero_in);
   if (impl == 6) return launch_two_stage_lds<COL, 6>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol, zero_in);
   return launch_two_stage_lds<COL, 5>(lu_, u, lf_, rhs, out, st, w, first, box, b1, s, prol, zero_in);

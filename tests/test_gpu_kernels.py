@@ -216,10 +216,10 @@ def _two_stage_reference(orc, kind, shape, st, b, e, first=0):
     return [orc.to_host(out), orc.to_host(u)]
 
 
-@pytest.fixture(params=[5, 8], ids=["lds5", "lds8"])
+@pytest.fixture(params=[5, 8, 83], ids=["lds5", "lds8", "lds8x3"])
 def two_stage_variant(request, hipd):
-    """Both workgroup shapes of the two-stage kernel (5 or 8 waves share a row stack through LDS), forced through the debug
-    build; yields the kernel layer to use."""
+    """The workgroup shapes of the two-stage kernel (5 or 8 waves with two rows each, 8 waves with three rows each -- plain passes --
+    share a row stack through LDS), forced through the debug build; yields the kernel layer to use."""
     import ctypes as C
 
     hipd.L.examg_debug_two_stage_lds.argtypes = [C.c_int]
