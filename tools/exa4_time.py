@@ -41,7 +41,7 @@ S = SolverFromL4(ConfigL4(nd=3, min_level=lo, max_level=hi, tol=1e-6, fused_coar
 S.setup()
 t_drv = timed(lambda: S.mgCycle(hi))
 S2 = SolverFromL4(ConfigL4(nd=3, min_level=lo, max_level=hi, tol=1e-6, fused_coarse=True, fused_rbgs=True, fused_residual_restrict=True,
-                           fused_prolong_min_points=50_000_000, fused_zero_start=True, fused_residual_norm=True), ops)
+                           fused_prolong_min_points=10_000_000, fused_zero_start=True, fused_residual_norm=True), ops)
 S2.setup()
 S2.capture_cycle()
 t_fused = timed(S2.replay_cycle)

@@ -10,7 +10,7 @@ from exastencils_amd.solver import ConfigL3, SolverFromL3
 
 ops = HipOps(0)
 out = {}
-ONE_PASS = dict(fused_prolong_min_points=50_000_000, fused_zero_start=True, fused_residual_norm=True, fused_coarse=True)
+ONE_PASS = dict(fused_prolong_min_points=10_000_000, fused_zero_start=True, fused_residual_norm=True, fused_coarse=True)
 for fmg, extra, name in ((False, ONE_PASS, "v_cycles_only"), (True, {}, "fmg_round1_forms"), (True, ONE_PASS, "fmg")):
     cfg = ConfigL3(nd=3, min_level=2, max_level=9, smoother="rbgs", omega=1.0, stencil="scaled", restrict_scale=1.0, tol=1e-6,
                    cg_max=512, bc_fn=1, fmg=fmg, fused_rbgs=True, fused_residual_restrict=True, **extra)

@@ -15,7 +15,7 @@ from exastencils_amd.solver import ConfigL4, SolverFromL4
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 ops = HipOps(0)
 P = SolverFromL4(ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True,
-                          fused_prolong_min_points=50_000_000, fused_zero_start=True), ops)
+                          fused_prolong_min_points=10_000_000, fused_zero_start=True), ops)
 P.setup()
 P.capture_cycle()
 for _ in range(3):
