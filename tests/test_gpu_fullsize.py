@@ -135,3 +135,36 @@ def test_config4_helmholtz27_history_vs_own_oracle(hip, name, entry_fastest):
     _check_solution(hip, P.Solution[kw["max_level"]], rec)
     del P
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("shape,b,e", [((800, 320, 220), [1, 1, 1], [800, 320, 220]), ((1000, 300, 200), [0, 1, 0], [1001, 300, 201])])
+def test_large_anisotropic_blocks_one_pass_equals_two_launches(hip, shape, b, e):
+    """Blocks above 5*10^7 points take the three-rows-per-wave form of the two-stage kernel (ragged windows, row groups of 22, chunks;
+    the second case starts on duplicate planes: the halo reaches the ghost layers): the Jacobi pair equals two launches of the one-step
+    kernel and the fused red-black sweep the two colour loops, bit for bit (those kernels are checked against the oracle at sizes
+    the oracle finishes in seconds)."""
+    import torch
+
+    from exastencils_amd.field import laplace_fd
+    from exastencils_amd.layout import FieldLayout
+
+    lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0, True, False)
+    u, f = hip.new_array(lu.size), hip.new_array(lf.size)
+    hip.fill_random(u, 1)
+    hip.fill_random(f, 2)
+    A = laplace_fd(3, tuple(1.0 / s for s in shape))
+    w = 0.8 / A.diag
+    Ls, Fs = lu.c_struct(), lf.c_struct()
+    fused, t1, t2 = u.clone(), u.clone(), u.clone()
+    hip.jacobi2(Ls, u, fused, None, Fs, f, A, w, b, e)
+    hip.stencil_op(2, Ls, u, Fs, f, Ls, t1, A, w, -1, b, e)
+    hip.stencil_op(2, Ls, t1, Fs, f, Ls, t2, A, w, -1, b, e)
+    assert torch.equal(fused, t2)
+    del fused, t1, t2
+    fused, t3 = u.clone(), u.clone()
+    hip.rbgs_sweep_fused(Ls, u, fused, Fs, f, A, w, 0, b, e)
+    for c in (0, 1):
+        hip.stencil_op(2, Ls, t3, Fs, f, Ls, t3, A, w, c, b, e)
+    assert torch.equal(fused, t3)
+    del fused, t3, u, f
+    torch.cuda.empty_cache()
