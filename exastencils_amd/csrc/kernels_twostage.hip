@@ -621,10 +621,15 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
     else EXAMG_TS_LAUNCH_ORD(1, 1);
   } else if (zero_in) {
     if constexpr (COL && NW != 6) EXAMG_TS_LAUNCH_ORD(WPE, 2);
-  } else if (g_ts_wpe == 4 && NW != 6) {
-    EXAMG_TS_LAUNCH_ORD((NW == 6 ? 1 : 4), 0);
   } else {
-    EXAMG_TS_LAUNCH_ORD(1, 0);
+    bool done = false;
+    if constexpr (NW != 6 && RPW == 2) {     // the register cap exists for the two-row form only
+      if (g_ts_wpe == 4) {
+        EXAMG_TS_LAUNCH_ORD(4, 0);
+        done = true;
+      }
+    }
+    if (!done) EXAMG_TS_LAUNCH_ORD(1, 0);
   }
 #undef EXAMG_TS_LAUNCH_ORD
 #undef EXAMG_TS_LAUNCH_PF
