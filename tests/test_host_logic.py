@@ -162,3 +162,18 @@ def test_config4_helmholtz27_program():
     rows = cf[inner].sum(axis=0)
     assert np.allclose(rows, -2.0, atol=1e-9 * np.abs(cf[0]).max())
     assert (cf[0][2:-2, 2:-2, 2:-2] > 0).all()
+
+
+def test_pairs_and_step_with_residual_under_an_fmg_start_change_no_bit():
+    """Testing/FMG/3D_VarCoeff.exa4's shape (stencil field, FMG start: SetFuncDir / ResetBC rewrite the boundary planes of EVERY slot, which is
+    what the one-pass step + residual relies on) with Jacobi pairs and the last pre-smoothing step + residual as single calls: the same
+    histories as statement by statement."""
+    kw = dict(nd=3, min_level=1, max_level=4, smoother="jacobi", omega=0.85, stencil="varcoeff", restrict_scale=1.0, tol=1e-5,
+              cg_max=1024, bc_fn=6, rhs_fn=5, sol_fn=6, coef_fn=7, kappa=10.0, fmg=True)
+    P = SolverFromL3(ConfigL3(frag_len=(2, 2, 2), **kw), OracleOps())
+    P.setup()
+    P.Solve()
+    Q = SolverFromL3(ConfigL3(frag_len=(2, 2, 2), temporal_blocking=True, fused_smooth_residual=True, **kw), OracleOps())
+    Q.setup()
+    Q.Solve()
+    assert Q.res_history == P.res_history and Q.err_history == P.err_history and Q.iterations == P.iterations
