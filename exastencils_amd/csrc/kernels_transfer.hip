@@ -143,9 +143,18 @@ k_residual_restrict3(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, c
   constexpr int NR = 2 * RW + 1;     // residual (and rhs) rows of the wave: 2J-1 .. 2J+2RW-1
   constexpr int NU = NR + 2;         // u rows: 2J-2 .. 2J+2RW
   const int lane = threadIdx.x;
-  long long t = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
-  if (t >= nwaves) return;
   const int n1w = (box.n1() + RW - 1) / RW;
+  long long wg = blockIdx.x;
+  // workgroups are dealt round-robin to the 8 XCDs: within a layer (one x tile, one z chunk) every XCD takes a band of y-adjacent
+  // workgroups, whose shared fine rows then meet in one L2 (512^3: 0.462 -> 0.455 ms)
+  if ((n1w & 3) == 0) {
+    const int wpl = n1w >> 2, per = wpl >> 3;
+    const long long lz = wg / wpl;
+    const int r = (int)(wg - lz * wpl);
+    wg = lz * wpl + (r < (per << 3) ? (r & 7) * per + (r >> 3) : r);
+  }
+  long long t = wg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+  if (t >= nwaves) return;
   const int J = box.b1 + (int)(t % n1w) * RW;   // consecutive waves of a workgroup: consecutive coarse rows (shared fine rows)
   t /= n1w;
   const int tx = (int)(t % ntx);

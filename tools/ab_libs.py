@@ -20,7 +20,11 @@ A = laplace_fd(3, (1.0 / n,) * 3)
 w = 0.8 / A.diag
 b, e = [1, 1, 1], [n, n, n]
 Ls, Fs, Lc = lu.c_struct(), lf.c_struct(), lc.c_struct()
+lfc = FieldLayout.node(3, (n // 2,) * 3, 0, True, False)
+fcz = ops.new_array(lfc.size)
+Fcs = lfc.c_struct()
 cases = {
+    "residual + restriction": lambda o: o.residual_restrict(Ls, u, Fs, f, Ls, None, A, Fcs, fcz, 1.0, b, e, [1, 1, 1], [n // 2] * 3),
     "one Jacobi step": lambda o: o.stencil_op(2, Ls, u, Fs, f, Ls, un, A, w, -1, b, e),
     "residual": lambda o: o.stencil_op(1, Ls, u, Fs, f, Ls, un, A, 0.0, -1, b, e),
     "two Jacobi steps": lambda o: o.jacobi2(Ls, u, un, None, Fs, f, A, w, b, e),
