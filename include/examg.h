@@ -138,7 +138,9 @@ int examg_rbgs_sweep_fused_boxes(const examg_layout_t *lu, const double *u_in, d
 /* Two Jacobi steps (Smoother called twice, Testing/Smoothers/Jac.exa4:125-131) in ONE pass: temporal blocking in the
  * sense of baseExt/ir/IR_ContractingLoop.scala.  u_out[box] = J(J(u_in)); bit-identical to two examg_jacobi calls
  * u_in -> tmp -> u_out.  Only valid when no halo exchange is needed between the two steps (single block, or ghost
- * layers two deep); `tmp` is used by the fallback path only (general stencils, small boxes) and may be NULL otherwise. */
+ * layers two deep); `tmp` is used by the fallback path only (general stencils, small boxes) and may be NULL otherwise.
+ * One-pass forms exist for the 3-D 7-point constant stencil and for 27-entry stencil fields in the record layout
+ * (EXAMG_CLAYOUT_ENTRY_FASTEST, entry order of examg_init_helmholtz27: the two steps of a point share its 216 B of coefficients). */
 int examg_jacobi2(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp, const examg_layout_t *lf,
                   const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end,
                   examg_stream_t stream);
