@@ -62,11 +62,19 @@ k_restrict3_wide(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, d
                  int ntx, int zc, int nwaves) {
   constexpr int NR = 2 * RW + 1;      // fine rows of the wave
   const int lane = threadIdx.x;
-  long long t = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int n1w = (box.n1() + RW - 1) / RW;
+  long long wg = blockIdx.x;
+  // XCD bands of y-adjacent workgroups within a z chunk (see k_residual_restrict3): 512^3 -> 256^3 0.229 -> 0.225 ms, 256^3 -> 128^3 0.026 -> 0.024
+  if (((ntx * n1w) & 3) == 0) {
+    const int wpl = (ntx * n1w) >> 2, per = wpl >> 3;
+    const long long lz = wg / wpl;
+    const int r = (int)(wg - lz * wpl);
+    wg = lz * wpl + (r < (per << 3) ? (r & 7) * per + (r >> 3) : r);
+  }
+  long long t = wg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
   if (t >= nwaves) return;
   const int tx = (int)(t % ntx);
   t /= ntx;
-  const int n1w = (box.n1() + RW - 1) / RW;
   const int I1 = box.b1 + (int)(t % n1w) * RW;
   const int kb = box.b2 + (int)(t / n1w) * zc;
   const int ke = min(kb + zc, box.e2);

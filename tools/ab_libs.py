@@ -24,6 +24,7 @@ lfc = FieldLayout.node(3, (n // 2,) * 3, 0, True, False)
 fcz = ops.new_array(lfc.size)
 Fcs = lfc.c_struct()
 cases = {
+    "restriction": lambda o: o.restrict(Ls, un, Fcs, fcz, 1.0, [1, 1, 1], [n // 2] * 3),
     "residual + restriction": lambda o: o.residual_restrict(Ls, u, Fs, f, Ls, None, A, Fcs, fcz, 1.0, b, e, [1, 1, 1], [n // 2] * 3),
     "one Jacobi step": lambda o: o.stencil_op(2, Ls, u, Fs, f, Ls, un, A, w, -1, b, e),
     "residual": lambda o: o.stencil_op(1, Ls, u, Fs, f, Ls, un, A, 0.0, -1, b, e),
