@@ -23,6 +23,14 @@ Ls, Fs, Lc = lu.c_struct(), lf.c_struct(), lc.c_struct()
 lfc = FieldLayout.node(3, (n // 2,) * 3, 0, True, False)
 fcz = ops.new_array(lfc.size)
 Fcs = lfc.c_struct()
+if "--sf27" in sys.argv:
+    from exastencils_amd.field import Stencil, helmholtz27_offsets
+    lf0 = FieldLayout.node(3, (n, n, n), 0)
+    f0 = ops.new_array(lf0.size); ops.fill_random(f0, 5)
+    cf = ops.new_array(27 * lf0.size); ops.fill_random(cf, 3); cf[:lf0.size] += 8.0
+    rec = Stencil(helmholtz27_offsets(), [], cf, lf0).entry_fastest(ops)
+    F0 = lf0.c_struct()
+    cases27 = {"27-entry step, records": lambda o: o.stencil_op(2, Ls, u, F0, f0, Ls, un, rec, 0.8, -1, b, e)}
 cases = {
     "restriction": lambda o: o.restrict(Ls, un, Fcs, fcz, 1.0, [1, 1, 1], [n // 2] * 3),
     "residual + restriction": lambda o: o.residual_restrict(Ls, u, Fs, f, Ls, None, A, Fcs, fcz, 1.0, b, e, [1, 1, 1], [n // 2] * 3),
@@ -33,6 +41,9 @@ cases = {
     "correction + sweep": lambda o: o.rbgs_sweep_fused_prolong(Ls, u, un, Fs, f, A, w, 0, b, e, Lc, uc),
 }
 
+
+if "--sf27" in sys.argv:
+    cases = cases27
 
 def timed(fn, reps=30):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
