@@ -507,6 +507,10 @@ class Communicator:
         if self._c is not None:
             from .lib import check
 
+            if self.transport == "peer":
+                # a program may reduce before its first exchange or gather (or have no communicated layers at all): the regions the
+                # all-reduce writes into must exist; every rank gets here together, so the collective growth is safe
+                self._peer_ensure(0, 0)
             check(self.ops.L.examg_allreduce(self._c, self.ops.ptr(t), int(t.numel()), 0 if op == "sum" else 1, self.ops._stream()),
                   "examg_allreduce")
             return t
@@ -518,6 +522,14 @@ class Communicator:
             return t
         self.dist.all_reduce(t, op=rop, group=self.group)
         return t
+
+    def reduce_value(self, t, op: str = "sum") -> float:
+        """All-reduce of a device scalar AND its host value -- the `MPI_Allreduce` + read that follows every reduction loop.  The host
+        waits for the device here anyway, so this is also where a wait of the peer-write transport that gave up (lost neighbour, a
+        rank stalled beyond EXAMG_PEER_TIMEOUT_MS) is turned into an exception instead of a wrong number."""
+        v = self.ops.scalar_value(self.allreduce(t, op))
+        self.check()
+        return v
 
     def all_gather(self, outs: List, t):
         """Every rank's `t` into `outs[rank]` (coarse-level agglomeration, exastencils_amd/solver.py); `outs` are consecutive

@@ -17,7 +17,7 @@
 //             pack box -> receiver.slab[channel'][q & 1];  fence(system);  receiver.ready[channel'] = q + 1
 //   receiver  wait until ready[channel'] >= q + 1;  unpack slab[channel'][q & 1] -> box;  sender.ack[channel] = q + 1
 // Both sides execute the same sequence of exchanges (one program, many blocks), as MPI requires of them too.  A wait that sees
-// no progress for EXAMG_PEER_TIMEOUT_MS (default 20 s) sets the communicator's error word and every later wait returns at
+// no progress for EXAMG_PEER_TIMEOUT_MS (default 120 s; the tests use a short one) sets the communicator's error word and every later wait returns at
 // once: a lost peer ends in an error at the next examg_comm_status(), never in a kernel that spins forever.
 //
 // Why a staging slab and not a write into the neighbour's ghost planes: field arrays are ordinary (coarse-grained) device memory,
@@ -398,7 +398,7 @@ extern "C" int examg_comm_create_peer(examg_comm_t **comm, int nranks, int rank)
   c->rank = rank;
   c->size = nranks;
   c->peer = new PeerState;
-  long long ms = 20000;
+  long long ms = 120000;     // long enough for a neighbour that writes a field to disk or captures a graph; callers check examg_comm_status at every host sync
   if (const char *e = getenv("EXAMG_PEER_TIMEOUT_MS")) { const long long v = atoll(e); if (v > 0) ms = v; }
   c->peer->timeout_ticks = ms * 100000;   // wall_clock64 counts at 100 MHz
   if (check_hip(hipMalloc((void **)&c->peer->loc, sizeof(PeerLocal)), "examg_comm_create_peer") ||

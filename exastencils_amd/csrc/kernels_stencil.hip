@@ -808,7 +808,11 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
 
   if (!g_force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
       st->off[0][1] == 0 && st->off[0][2] == 0 && st->ctransform == EXAMG_CLAYOUT_ENTRY_FASTEST && lu_->nd == 3 &&
-      (mode != EXAMG_SMOOTH || st->wform == EXAMG_WEIGHT_INV_TIMES)) {
+      (mode != EXAMG_SMOOTH || st->wform == EXAMG_WEIGHT_INV_TIMES) &&
+      // the 16-byte loads of the record stream are clamped to the allocation; a pair that starts on the very last double of the
+      // coefficient array would be shifted -- a box that holds the last allocated point (a coefficient layout without ghost or
+      // pad layers) takes the generic kernel instead
+      lidx(make_layout(&st->clayout), box.e0 - 1, box.e1 - 1, box.e2 - 1) != make_layout(&st->clayout).size - 1) {
     // transformed coefficient layout: ONE coefficient stream, transposed through LDS (k_stencilfield27_rec)
     const LayoutDev lc27 = make_layout(&st->clayout);
     UOffsets uo;

@@ -514,6 +514,7 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
     def run(self, name: str = "Application"):
         self.call(name)
         self._flush_cg_limit()
+        self.comm.check()         # a wait of the peer-write transport that gave up is an error of the run, not silent garbage
         return self.out
 
     def _flush_cg_limit(self):
@@ -878,7 +879,7 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
                 for b, e in boxes:
                     self.launches += 1
                     t = self.ops.dot(X.lc, X.data(xs), Y.lc, Y.data(ys), b, e)
-                    acc += self.ops.scalar_value(self.comm.allreduce(t, "sum"))
+                    acc += self.comm.reduce_value(t, "sum")
                 fr.vars[var] = fr.vars[var] + acc
                 continue
             if op == "max" and st[1] == "=" and rhs[0] == "call" and rhs[1] == "max" and len(rhs[3]) == 2:
@@ -897,7 +898,7 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
                                 r = self.ops.max_err_fn(X.lc, X.data(xs), self.domain.geom(X.level), fn, par, b, e)
                             else:
                                 r = self.ops.max_err_expr(X.lc, X.data(xs), self.domain.geom(X.level), fn, b, e)
-                            acc = max(acc, self.ops.scalar_value(self.comm.allreduce(r, "max")))
+                            acc = max(acc, self.comm.reduce_value(r, "max"))
                         fr.vars[var] = acc
                         continue
             raise Exa4Unsupported("reduction %s over this loop body" % op)

@@ -243,7 +243,7 @@ class Builtins:
             self.ops.axpby(B.lc, B.data(sb), A.lc, self._cmp_tmp, -1.0, 1.0, b, e)           # tmp -= B
             t = self.ops.max_err_fn(A.lc, self._cmp_tmp, self.domain.geom(A.level), 0, (), b, e)
             self.launches += 3
-            worst = max(worst, self.ops.scalar_value(self.comm.allreduce(t, "max")))
+            worst = max(worst, self.comm.reduce_value(t, "max"))
         if not (worst > tol if op == ">" else worst >= tol):
             return
         # a point beyond the tolerance exists SOMEWHERE (the verdict is all-reduced, so that every block leaves the function together

@@ -107,7 +107,13 @@ class LazyFusions:
         """True if `s` was absorbed together with the pending loop (nothing left to execute)."""
         k = s[0]
         if k in ("decl", "assign", "callstmt", "if", "repeat", "until", "levelscope", "return"):
-            return False                      # no field access of their own: what they contain is gated when it executes
+            # no field access of their own (what they contain is gated when it executes) -- unless one of their expressions names a
+            # field: outside a loop that is an argument of a host-side builtin (printField / writeField / readField, norms of a
+            # field), which reads or writes the array NOW.  The pending loop runs first.
+            e = s[2] if k == "decl" else (s[3] if k == "assign" else (None if k == "levelscope" else s[1]))
+            if e is not None and self._has_field_ref(e):
+                self._flush_pending()
+            return False
         P = self._pending
         if k == "comm":
             return False                      # a block without neighbours: the generated exch function is empty
@@ -130,6 +136,15 @@ class LazyFusions:
                     return True
                 self._pending = P             # ... or it runs first
         self._flush_pending()
+        return False
+
+    @classmethod
+    def _has_field_ref(cls, e) -> bool:
+        """Does the expression tree name a field anywhere (also inside the arguments of a call)?"""
+        if isinstance(e, (list, tuple)):
+            if len(e) >= 4 and e[0] == "fld" and isinstance(e[1], str):
+                return True
+            return any(cls._has_field_ref(x) for x in e)
         return False
 
     def _consume_residual(self, s, fr) -> bool:
@@ -179,7 +194,7 @@ class LazyFusions:
         self._pending = None
         self.launches += 1
         t = self.ops.residual_norm2(U.lc, U.data(P["us"]), F.lc, F.data(P["fs"]), A, b, e, D.lc, D.data(P["ds"]))
-        fr.vars[var] = fr.vars[var] + self.ops.scalar_value(self.comm.allreduce(t, "sum"))
+        fr.vars[var] = fr.vars[var] + self.comm.reduce_value(t, "sum")
         self.fusions["residual_norm"] += 1
         return True
 
@@ -282,6 +297,8 @@ class LazyFusions:
         if k == "loop":
             _, target, only, where, reduction, body = s
             full = only is None and where is None and reduction is None and not in_colour
+            if where is not None and self._expr_reads(where, lvl, key):
+                return READ, False
             res = NEITHER
             for st in body:
                 if st[0] == "decl":

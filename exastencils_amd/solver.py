@@ -87,7 +87,7 @@ class _Program:
     def _dot_host(self, x: Field, y: Field, over: Field, xslot=None, yslot=None) -> float:
         b, e = self.bounds(over, reduction=True)
         t = self.ops.dot(x.lc, x.data(xslot), y.lc, y.data(yslot), b, e)
-        return self.ops.scalar_value(self.comm.allreduce(t, "sum"))
+        return self.comm.reduce_value(t, "sum")
 
     def _single_block(self) -> bool:
         return self.domain.world_size == 1
@@ -257,7 +257,7 @@ class SolverFromL4(_Program):
         self.communicate(S, axis_only=self._faces_only(A))
         b, e = self.bounds(R, reduction=True)
         t = self.ops.residual_norm2(S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), A, b, e, R.lc, R.data())
-        return math.sqrt(self.ops.scalar_value(self.comm.allreduce(t, "sum")))
+        return math.sqrt(self.comm.reduce_value(t, "sum"))
 
     def _update_residual(self, l: int):
         S, R = self.Solution[l], self.Residual[l]
@@ -328,7 +328,7 @@ class SolverFromL4(_Program):
                 S = self.Solution[hi]
                 b, e = self.bounds(S)
                 t = self.ops.max_err_fn(S.lc, S.data(), self.domain.geom(hi), cfg.sol_fn, (), b, e)
-                err = self.ops.scalar_value(self.comm.allreduce(t, "max"))
+                err = self.comm.reduce_value(t, "max")
                 self.err_history.append(err)
                 self.log.append(reduced_prec(err))
             curRes = self._residual_and_norm(hi)
@@ -702,14 +702,14 @@ class SolverFromL3(_Program):
         self.communicate(S, S.active)
         b, e = self.bounds(R, reduction=True)
         t = self.ops.residual_norm2(S.lc, S.data(), F.lc, F.data(), A, b, e, R.lc, R.data())
-        return math.sqrt(self.ops.scalar_value(self.comm.allreduce(t, "sum")))
+        return math.sqrt(self.comm.reduce_value(t, "sum"))
 
     # Function NormError_0@finest : Real
     def NormError(self, l: int) -> float:
         S = self.Solution[l]
         b, e = self.bounds(S, reduction=True)
         t = self.ops.max_err_fn(S.lc, S.data(), self.domain.geom(l), self.cfg.sol_fn, (self.cfg.kappa,), b, e)
-        return self.ops.scalar_value(self.comm.allreduce(t, "max"))
+        return self.comm.reduce_value(t, "max")
 
     # Function Smoother@((coarsest + 1) to finest)
     def _one_pass_sweep(self, l: int) -> bool:

@@ -445,7 +445,7 @@ int examg_allgather(examg_comm_t *comm, const double *send, double *recv, int64_
  *   examg_comm_peer_connect(c, all_handles);
  * To grow the slabs later: synchronise the device on every rank, host barrier, then alloc / gather / connect again (sequence
  * numbers restart).  The workspace arguments of examg_exchange / examg_*_blocks are ignored (may be NULL).  A wait that sees no
- * progress for EXAMG_PEER_TIMEOUT_MS (default 20000) gives up, makes every later wait return at once and is reported by
+ * progress for EXAMG_PEER_TIMEOUT_MS (default 120000) gives up, makes every later wait return at once and is reported by
  * examg_comm_status() -- a lost neighbour never leaves a kernel spinning. */
 #define EXAMG_PEER_HANDLE_BYTES 128
 int examg_comm_create_peer(examg_comm_t **comm, int nranks, int rank);

@@ -5,6 +5,10 @@
 // Errors print and exit, as the reference's CUDA_CheckError does (cuda/CUDA_Error.scala); every wrapper returns void.
 #include <hip/hip_runtime.h>
 
+#include <signal.h>
+#include <unistd.h>
+
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -46,6 +50,7 @@ struct LevelInfo {
 LevelInfo g_lv[EXA_NUM_LEVELS];
 int g_blocks[3] = {1, 1, 1}, g_pos[3] = {0, 0, 0}, g_rank = 0, g_size = 1;
 examg_comm_t *g_comm = nullptr;
+std::string g_peerFile;               // this rank's handle file of the peer-write bootstrap (removed in destroyGlobals)
 examg_neighbors_t g_nb;
 uint32_t g_faceMask = 63u;
 double *g_scalar = nullptr, *g_work = nullptr;
@@ -134,23 +139,33 @@ void initGlobals(const int numBlocks[3], int mpiRank, const void *commId) {
     const examg_layout_t finest = nodeLayout(EXA_MAX_LEVEL, 1);
     unsigned char mine[EXAMG_PEER_HANDLE_BYTES];
     check(examg_comm_peer_alloc(g_comm, examg_exchange_workspace_bytes(&finest) / 4, 0, mine), "examg_comm_peer_alloc");
+    // A file is <pid of its writer><handle>: a reader only accepts the file of a LIVE process, so what an earlier run with the same base
+    // left behind is never mapped (it waits for the new file instead), and every rank removes its own file when it is done.
+    g_peerFile = std::string(peerBase) + "." + std::to_string(mpiRank);
     {
-      const std::string path = std::string(peerBase) + "." + std::to_string(mpiRank), tmp = path + ".tmp";
+      const std::string tmp = g_peerFile + ".tmp";
+      const long long pid = (long long)getpid();
+      std::remove(g_peerFile.c_str());
       FILE *f = std::fopen(tmp.c_str(), "wb");
-      if (!f || std::fwrite(mine, 1, sizeof(mine), f) != sizeof(mine)) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); std::exit(1); }
+      if (!f || std::fwrite(&pid, sizeof(pid), 1, f) != 1 || std::fwrite(mine, 1, sizeof(mine), f) != sizeof(mine)) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); std::exit(1); }
       std::fclose(f);
-      std::rename(tmp.c_str(), path.c_str());
+      std::rename(tmp.c_str(), g_peerFile.c_str());
     }
     std::vector<unsigned char> all((size_t)g_size * EXAMG_PEER_HANDLE_BYTES);
     for (int r = 0; r < g_size; ++r) {
       const std::string path = std::string(peerBase) + "." + std::to_string(r);
-      FILE *f = nullptr;
-      for (int tries = 0; tries < 600 && !(f = std::fopen(path.c_str(), "rb")); ++tries) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-      if (!f || std::fread(all.data() + (size_t)r * EXAMG_PEER_HANDLE_BYTES, 1, EXAMG_PEER_HANDLE_BYTES, f) != EXAMG_PEER_HANDLE_BYTES) {
-        std::fprintf(stderr, "cannot read %s\n", path.c_str());
-        std::exit(1);
+      bool got = false;
+      for (int tries = 0; tries < 600 && !got; ++tries) {
+        if (FILE *f = std::fopen(path.c_str(), "rb")) {
+          long long pid = 0;
+          got = std::fread(&pid, sizeof(pid), 1, f) == 1 &&
+                std::fread(all.data() + (size_t)r * EXAMG_PEER_HANDLE_BYTES, 1, EXAMG_PEER_HANDLE_BYTES, f) == EXAMG_PEER_HANDLE_BYTES &&
+                pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM);
+          std::fclose(f);
+        }
+        if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
       }
-      std::fclose(f);
+      if (!got) { std::fprintf(stderr, "no handle of a live rank %d in %s\n", r, path.c_str()); std::exit(1); }
     }
     check(examg_comm_peer_connect(g_comm, all.data()), "examg_comm_peer_connect");
   } else {
@@ -224,6 +239,7 @@ void destroyGlobals(void) {
   (void)hipFree(g_scalar);
   (void)hipFree(g_work);
   check(examg_comm_destroy(g_comm), "examg_comm_destroy");
+  if (!g_peerFile.empty()) std::remove(g_peerFile.c_str());
 }
 
 void exa_allreduce_sum(double *x) {
@@ -231,6 +247,7 @@ void exa_allreduce_sum(double *x) {
   checkHip(hipMemcpy(g_scalar, x, sizeof(double), hipMemcpyHostToDevice), "exa_allreduce_sum");
   check(examg_allreduce(g_comm, g_scalar, 1, 0, nullptr), "examg_allreduce");
   checkHip(hipMemcpy(x, g_scalar, sizeof(double), hipMemcpyDeviceToHost), "exa_allreduce_sum");
+  check(examg_comm_status(g_comm, nullptr), "examg_comm_status");   // the host has waited for the device here anyway: a wait that gave up ends the run
 }
 
 #define EXA_I(L) ((L) - EXA_MIN_LEVEL)

@@ -268,6 +268,32 @@ def test_fused_passes_change_no_bit():
         assert fused.launches < plain.launches
 
 
+@pytest.mark.parametrize("after,field", [
+    ("  Defect@finest ( )\n  Var res0", "r@finest"),                      # pending residual loop
+    ("  apply bc to u@coarser\n  Cycle@coarser", "u@coarser"),            # pending `u@coarser = 0.0`
+    ("  apply bc to u\n  Sweeps ( )\n}\n\nFunction Cycle@coarsest", "u"),   # pending correction loop
+])
+def test_field_io_sees_the_pending_loop(tmp_path, after, field):
+    """A host-side field access (printField / writeField) right after a loop the interpreter keeps pending for a one-pass kernel
+    must see that loop's result: the files written with fuse=True equal those written with fuse=False byte for byte."""
+    with open(os.path.join(EX, "poisson3d_rbgs.exa4")) as f:
+        text = f.read()
+    head, tail = after.split("\n", 1)
+    assert text.count(after) == 1
+    files = {}
+    for fuse in (False, True):
+        out = str(tmp_path / ("field_%d.txt" % fuse))
+        prog = text.replace(after, head + '\n  printField ( "%s", %s )\n' % (out, field) + tail)
+        P = exa4.Exa4Program(prog, dict(dimensionality=3, minLevel=2, maxLevel=6), ops=OracleOps(), fuse=fuse)
+        P.fuse_min_row, P.fused_prolong_min_points = 8, 0
+        P.run()
+        files[fuse] = (open(out, "rb").read(), P.printed_values)
+    assert files[True][0] == files[False][0] and len(files[True][0]) > 1000
+    if field != "u@coarser":          # (that one is the zero field by construction)
+        assert any(float(l.split()[-1]) != 0.0 for l in files[True][0].decode().splitlines() if l.strip())
+    assert files[True][1] == files[False][1]
+
+
 def test_generated_cg_solver_is_recognised():
     """`Cycle@coarsest` of the example (and the reference's mgCycle@coarsest, when present) is the generated CG solver
     and becomes one examg_cg_coarse call; so does the slotted program's CG -- the layer-3 generator's form: alpha from the squared

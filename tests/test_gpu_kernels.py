@@ -487,7 +487,10 @@ def test_stencil_field_27_entries_long_rows(hip, orc, mode, n):
 
 @pytest.mark.parametrize("mode", [APPLY, RESIDUAL, SMOOTH])
 @pytest.mark.parametrize("case", [((66, 66, 66), [1, 1, 1], [66, 66, 66]), ((130, 40, 20), [0, 1, 0], [131, 40, 21]),
-                                  ((200, 24, 12), [1, 1, 1], [200, 24, 12])])
+                                  ((200, 24, 12), [1, 1, 1], [200, 24, 12]),
+                                  # a box that holds the LAST allocated point of the coefficient layout (no ghost / pad layers behind it):
+                                  # the record kernel's clamped 16-byte loads would shift its last entry -- the dispatch must not take it
+                                  ((70, 12, 9), [0, 0, 0], [71, 13, 10])])
 def test_stencil_field_27_entries_under_the_entry_fastest_layout_transformation(hip, orc, mode, case):
     """Config 4's operator with its coefficient field transformed by `[x, y, z, i] => [i, x, y, z]` (the reference's
     LayoutTransformations mechanism, Compiler/src/exastencils/layoutTransformation/): one 216-byte record per point, read as ONE
