@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")      # tools/gpu_pmc.sh; the commit it was taken at is inside
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -65,9 +65,12 @@ def parse():
                          "(what leaving their exchange out relies on; on by default)")
     ap.add_argument("--sustained-seconds", type=float, default=5.0,
                     help="after the K timed steps: the same step for at least this long, reported as sustained_* beside the headline (0: skip)")
+    ap.add_argument("--blocks", default="",
+                    help="N > 1: block decomposition -- 'zy' (default: 8 -> 1x2x4, whole rows / planes in every halo), 'cube' (8 -> 2x2x2, SURVEY.md 8e: "
+                         "the reference's domain_rect_numBlocks of its benchmark configurations) or explicit 'bx,by,bz'")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend that carries the bootstrap / timing collectives; 'gloo': several ranks "
                                                       "on ONE GPU (the halo traffic still moves device to device through the peer-write transport)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def host_info():
@@ -200,7 +203,19 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    run(args, world, rank, local_rank, dist)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def run(args, world, rank, local_rank, dist, injected=False):
+    """One rank of the benchmark.  `dist`: torch.distributed (main) or an object with the same calls -- tests/filedist.py, with which
+    tests/test_gpu_ranks8.py hosts several ranks per process (one thread and stream each) to rehearse the 8-rank job on a one-GPU box
+    (`injected=True`: every Communicator of the run bootstraps through it).  Rank 0 prints the JSON line and returns it."""
+    import torch
+
+    dist_module = dist if injected else None
     from exastencils_amd.comm import Communicator
     from exastencils_amd.domain import RectDomain
     from exastencils_amd.field import Field, laplace_fd
@@ -209,7 +224,7 @@ def main():
 
     ops = HipOps(local_rank)
     nd, L = 3, args.level
-    blocks = RectDomain.blocks_for(world, nd)
+    blocks = RectDomain.parse_blocks(args.blocks, world, nd)
     if args.scaling == "weak":
         # weak scaling keeps the mesh width: the physical domain grows with the blocks, [0,1]^3 per block (a unit cube cut into
         # 1 x 2 x 4 blocks of 512^3 cells would be an anisotropic mesh, on which point smoothers with full coarsening degrade)
@@ -240,7 +255,7 @@ def main():
                 os._exit(4)
 
         threading.Thread(target=preflight_watchdog, daemon=True).start()
-        comm = open_transport(dom, ops, dist, args, transport_notes)
+        comm = open_transport(dom, ops, dist, args, transport_notes, dist_module)
     else:
         comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
     nc = dom.ncells(L)
@@ -264,7 +279,7 @@ def main():
         # block and its ghosts from the neighbours; RHS (a layout without communication) through a communicating alias of the same
         # array -- both owners of a shared plane then compute the same bits in every step, which `consistent_duplicates` relies on
         # and which is VERIFIED after the timed steps (duplicate_planes_bit_identical)
-        full = Communicator(dom, ops)
+        full = Communicator(dom, ops, dist_module=dist_module)
         for s_ in (0, 1):
             full.exchange(Solution, s_, "all")
         rhs_alias = Field("RHS", L, FieldLayout.node(nd, nc, 0, True, False, args.align), ops, 1, None)
@@ -510,12 +525,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
-def open_transport(dom, ops, dist, args, notes):
+def open_transport(dom, ops, dist, args, notes, dist_module=None):
     """The communicator of an N > 1 run: the transport is PROVEN by a real exchange + all-reduce on a small field before anything is
     timed, and the verdict is shared by all ranks (MIN over ranks).  Default order: peer writes through HIP IPC, then RCCL
     send / recv groups, then torch.distributed point-to-point; EXAMG_TRANSPORT pins one.  Nothing is silent: the transport that
@@ -536,10 +549,10 @@ def open_transport(dom, ops, dist, args, notes):
         os.environ["EXAMG_TRANSPORT"] = tr
         ok, why = 1.0, ""
         try:
-            c = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True, transport=tr)
+            c = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True, transport=tr, dist_module=dist_module)
             probe = Field("probe", 4, FieldLayout.node(dom.nd, dom.ncells(4), 1, True, True, 0), ops, 1, None)
             ops.fill_random(probe.data(), 99 + dom.rank)
-            full = Communicator(dom, ops, transport=tr)
+            full = Communicator(dom, ops, transport=tr, dist_module=dist_module)
             full.exchange(probe, None, "all")
             t = ops.from_host(__import__("numpy").array([1.0 + dom.rank]))
             c.allreduce(t, "sum")

@@ -33,13 +33,13 @@ from .domain import RectDomain
 from .field import Field
 
 
-_PEER_GENERATION = [0]      # bumped whenever the peer-write regions of this process are re-allocated (graphs captured earlier are stale)
+_PEER_GENERATION: Dict[int, int] = {}   # examg_comm_t* -> bumped whenever its peer-write regions are re-allocated (graphs captured earlier are stale)
 _SHARED_C_COMMS: Dict[Tuple, object] = {}     # (library, world size, rank) -> examg_comm_t*: one RCCL communicator per process
 
 
 class Communicator:
     def __init__(self, domain: RectDomain, ops, group=None, concurrent_ghost_axes: bool = False,
-                 consistent_duplicates: bool = False, transport: str = "auto"):
+                 consistent_duplicates: bool = False, transport: str = "auto", dist_module=None):
         """concurrent_ghost_axes: where the caller declares that only face ghosts will be read (`axis_only=True`:
         5/7-point stencil loops), send the ghost planes of all axes in ONE point-to-point batch instead of axis by axis.
         Face ghosts are identical; edge/corner ghosts -- which only the axis-by-axis order makes valid and which
@@ -54,7 +54,12 @@ class Communicator:
         self.consistent_duplicates = consistent_duplicates
         self.dist = None
         if domain.world_size > 1:
-            import torch.distributed as dist
+            # dist_module: an object with the torch.distributed calls used here (bootstrap collectives, point-to-point) -- how a host
+            # that runs SEVERAL blocks per process (one thread and stream per block) or has its own launcher hands over its bootstrap
+            if dist_module is not None:
+                dist = dist_module
+            else:
+                import torch.distributed as dist
 
             if not dist.is_initialized():
                 raise RuntimeError("a decomposition with %d blocks needs torch.distributed to be initialised" % domain.world_size)
@@ -195,7 +200,7 @@ class Communicator:
         if self.dist is not None:
             self.dist.barrier(group=self.group)
         # kernels recorded into a hipGraph before this point hold the addresses of the regions that were just replaced
-        _PEER_GENERATION[0] += 1
+        _PEER_GENERATION[self._c.value] = _PEER_GENERATION.get(self._c.value, 0) + 1
 
     @staticmethod
     def _max_face_bytes(lay, nd: int) -> int:
@@ -212,7 +217,7 @@ class Communicator:
     @property
     def generation(self) -> int:
         """Changes when the peer-write regions were re-allocated: a hipGraph that contains exchanges is valid for one generation."""
-        return _PEER_GENERATION[0] if (self.transport == "peer" and self._c is not None) else 0      # no neighbours: no exchange kernels in its graphs
+        return _PEER_GENERATION.get(self._c.value, 0) if (self.transport == "peer" and self._c is not None) else 0      # no neighbours: no exchange kernels in its graphs
 
     def check(self):
         """Raise if a wait of the peer-write transport has given up (lost neighbour, mismatched exchange sequences)."""

@@ -53,6 +53,7 @@ struct PeerLocal {               // ordinary device memory of the rank: the coun
 struct PeerWire {                // what travels between the ranks, inside EXAMG_PEER_HANDLE_BYTES
   hipIpcMemHandle_t mem;
   unsigned long long region_bytes, slab_bytes, gather_bytes;
+  unsigned long long self_ptr;   // the region's address in the owner's process: what a rank of the SAME process uses (no IPC mapping of one's own memory)
   int rank, pid;
 };
 static_assert(sizeof(PeerWire) <= EXAMG_PEER_HANDLE_BYTES, "EXAMG_PEER_HANDLE_BYTES too small");
@@ -60,6 +61,7 @@ static_assert(sizeof(PeerWire) <= EXAMG_PEER_HANDLE_BYTES, "EXAMG_PEER_HANDLE_BY
 struct PeerState {
   char *mine = nullptr;                 // own region: header | 6 channels x 2 slabs | nranks gather pieces
   char *remote[PEER_MAX_RANKS] = {};    // mapped regions (remote[rank] == mine)
+  bool remote_ipc[PEER_MAX_RANKS] = {}; // remote[r] came from hipIpcOpenMemHandle (not the own region, not a region of this process)
   char **remote_dev = nullptr;          // the same table in device memory
   PeerLocal *loc = nullptr;
   size_t region_bytes = 0, slab_bytes = 0, gather_bytes = 0;
@@ -296,8 +298,9 @@ unsigned copy_blocks(long long count) {      // few, grid-striding workgroups: a
 
 void release_mappings(PeerState *p, int me, int nranks) {
   for (int r = 0; r < nranks; ++r) {
-    if (r != me && p->remote[r]) (void)hipIpcCloseMemHandle(p->remote[r]);
+    if (r != me && p->remote[r] && p->remote_ipc[r]) (void)hipIpcCloseMemHandle(p->remote[r]);
     p->remote[r] = nullptr;
+    p->remote_ipc[r] = false;
   }
   p->connected = false;
 }
@@ -442,6 +445,7 @@ extern "C" int examg_comm_peer_alloc(examg_comm_t *comm, size_t slab_bytes, size
   w.region_bytes = total;
   w.slab_bytes = slab_bytes;
   w.gather_bytes = gather_bytes;
+  w.self_ptr = (unsigned long long)(uintptr_t)p->mine;
   w.rank = comm->rank;
   w.pid = (int)getpid();
   memset(handle_out, 0, EXAMG_PEER_HANDLE_BYTES);
@@ -463,9 +467,16 @@ extern "C" int examg_comm_peer_connect(examg_comm_t *comm, const void *all_handl
       return 1;
     }
     if (r == comm->rank) { p->remote[r] = p->mine; continue; }
+    if (w.pid == (int)getpid()) {
+      // several blocks in ONE process (one host thread and stream per block, as the reference's fragments of a block): the
+      // neighbour's region is in this address space already -- HIP IPC cannot map memory into the process that exported it
+      p->remote[r] = (char *)(uintptr_t)w.self_ptr;
+      continue;
+    }
     void *ptr = nullptr;
     if (check_hip(hipIpcOpenMemHandle(&ptr, w.mem, hipIpcMemLazyEnablePeerAccess), "examg_comm_peer_connect: hipIpcOpenMemHandle")) return 1;
     p->remote[r] = (char *)ptr;
+    p->remote_ipc[r] = true;
   }
   if (check_hip(hipMemcpy(p->remote_dev, p->remote, sizeof(char *) * PEER_MAX_RANKS, hipMemcpyHostToDevice), "examg_comm_peer_connect")) return 1;
   p->connected = true;

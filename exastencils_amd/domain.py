@@ -40,14 +40,22 @@ class RectDomain:
         return self.num_blocks[0] * self.num_blocks[1] * self.num_blocks[2]
 
     @staticmethod
-    def blocks_for(world_size: int, nd: int) -> Tuple[int, int, int]:
-        """Blocks per dimension for a power-of-two number of GPUs: the factors of two go to z and y in turn and never to x
-        (8 -> 1x2x4, 4 -> 1x2x2, 2 -> 1x1x2).  `domain_rect_numBlocks_*` are free knobs of the reference; with the
-        unit-stride dimension undivided every halo is made of whole rows or planes -- an x-face is 512^2 three-double
-        fragments, one cache line each, for packing and for the thin shell launches.  Measured with loop-back neighbours
-        (tools/pair_overhead.py, 512^3 block, three interior faces): 0.79 ms per Jacobi pair against 0.86 ms for 2x2x2."""
+    def blocks_for(world_size: int, nd: int, scheme: str = "zy") -> Tuple[int, int, int]:
+        """Blocks per dimension for a power-of-two number of GPUs.  `domain_rect_numBlocks_*` are free knobs of the reference:
+          "zy"   (default) the factors of two go to z and y in turn and never to x (8 -> 1x2x4, 4 -> 1x2x2, 2 -> 1x1x2): with the
+                 unit-stride dimension undivided every halo is made of whole rows or planes -- an x-face is 512^2 single doubles,
+                 one cache line each, for packing and for the thin shell launches.  Measured with loop-back neighbours
+                 (tools/pair_overhead.py, 512^3 block, three interior faces): 0.79 ms per Jacobi pair against 0.86 ms for 2x2x2.
+          "cube" x, y, z in turn (8 -> 2x2x2, 4 -> 2x2x1, 2 -> 2x1x1): SURVEY.md 8e / the reference's benchmark configurations
+                 (smallest surface; every block of a strong-scaled 512^3 is a 256^3 cube).
+        An explicit "bx,by,bz" is parsed by `parse_blocks`."""
         nb = [1, 1, 1]
-        dims = [2, 1] if nd == 3 else [1]
+        if scheme == "zy":
+            dims = [2, 1] if nd == 3 else [1]
+        elif scheme == "cube":
+            dims = [0, 1, 2][:nd]
+        else:
+            raise ValueError("unknown decomposition scheme %r (zy | cube)" % (scheme,))
         d, n = 0, world_size
         while n > 1:
             if n % 2:
@@ -56,6 +64,22 @@ class RectDomain:
             n //= 2
             d += 1
         return tuple(nb)
+
+    @staticmethod
+    def parse_blocks(text: Optional[str], world_size: int, nd: int) -> Tuple[int, int, int]:
+        """--blocks: None / "" / "zy" / "cube" (see blocks_for) or explicit "bx,by,bz" whose product must be the world size."""
+        if not text:
+            return RectDomain.blocks_for(world_size, nd)
+        if text in ("zy", "cube"):
+            return RectDomain.blocks_for(world_size, nd, text)
+        try:
+            nb = tuple(int(t) for t in text.replace("x", ",").split(","))
+        except ValueError:
+            raise ValueError("--blocks %r: expected zy, cube or bx,by,bz" % (text,)) from None
+        nb = nb + (1,) * (3 - len(nb))
+        if len(nb) != 3 or min(nb) < 1 or nb[0] * nb[1] * nb[2] != world_size or any(nb[d] != 1 for d in range(nd, 3)):
+            raise ValueError("--blocks %r does not describe %d blocks in %d dimensions" % (text, world_size, nd))
+        return nb
 
     def rank_of(self, pos: Sequence[int]) -> int:
         return pos[0] + self.num_blocks[0] * (pos[1] + self.num_blocks[1] * pos[2])

@@ -30,13 +30,26 @@ def main():
 
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    run_rank(rank, world, blocks, out, dist, None)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
 
-    from exastencils_amd.comm import Communicator
+
+def run_rank(rank, world, blocks, out, dist, dist_module):
+    """Everything one rank does.  dist_module None: torch.distributed (one rank per process, main above); otherwise the bootstrap object
+    every Communicator is given (tests/filedist.py: several ranks per process, tests/ranks_host.py)."""
+    import torch
+
+    from exastencils_amd.comm import Communicator as _Communicator
     from exastencils_amd.domain import RectDomain
     from exastencils_amd.field import Field, laplace_fd
     from exastencils_amd.layout import FieldLayout
     from exastencils_amd.ops import HipOps
     from exastencils_amd.smoothers import jacobi_pair, rbgs_sweep
+
+    def Communicator(dom, ops, **kw):
+        return _Communicator(dom, ops, dist_module=dist_module, **kw)
 
     spec = json.load(open(os.path.join(out, "spec.json")))
     L = spec["level"]
@@ -190,9 +203,6 @@ def main():
 
     np.savez(os.path.join(out, "out_%d.npz" % rank), **arrays)
     json.dump(result, open(os.path.join(out, "out_%d.json" % rank), "w"))
-    torch.cuda.synchronize()
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

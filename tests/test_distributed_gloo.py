@@ -272,10 +272,12 @@ def test_bench_vcycle_leg_on_two_blocks(tmp_path):
 
 
 # -------------------------------------------------------------------------------------------------
-def _worker_eight(rank, world, port, out_dir):
-    """The decomposition bench.py uses on a full node, 1 x 2 x 4 blocks: fused red-black sweeps with shells, single-batch
-    ghosts, left-out duplicate exchange, agglomerated coarse levels."""
-    _init(rank, world, port)
+def _worker_eight(rank, world, port, out_dir, scheme="zy", dist_module=None):
+    """The decompositions of a full node -- bench.py's default 1 x 2 x 4 blocks and 2 x 2 x 2 (--blocks cube) --: fused
+    red-black sweeps with shells, single-batch ghosts, left-out duplicate exchange, agglomerated coarse levels.  dist_module: the
+    bootstrap of a rank that is a thread (tests/filedist.py) instead of a process."""
+    if dist_module is None:
+        _init(rank, world, port)
     from oracle import mg
     from oracle_ops import OracleOps
 
@@ -285,10 +287,10 @@ def _worker_eight(rank, world, port, out_dir):
 
     mg.lib().orc_set_num_threads(1)
     ops = OracleOps()
-    blocks = RectDomain.blocks_for(world, 3)
+    blocks = RectDomain.blocks_for(world, 3, scheme)
     flen = tuple(4 // blocks[d] for d in range(3))
     dom = RectDomain(3, blocks, rank, flen)
-    comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
+    comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True, dist_module=dist_module)
     P = SolverFromL4(ConfigL4(nd=3, min_level=0, max_level=3, frag_len=flen, tol=1e-6, fused_coarse=False, fused_rbgs=True,
                               agglomerate_level=1), ops, dom, comm)
     P.setup()
@@ -299,17 +301,44 @@ def _worker_eight(rank, world, port, out_dir):
     Q = SolverFromL3(ConfigL3(nd=3, min_level=0, max_level=3, frag_len=flen, temporal_blocking=True), ops, dom, comm)
     Q.setup()
     Q.Solve()
-    json.dump({"res": P.res_history, "it": P.iterations, "blocks": list(blocks), "res_jac": Q.res_history, "it_jac": Q.iterations},
+    json.dump({"res": P.res_history, "it": P.iterations, "blocks": list(blocks), "res_jac": Q.res_history, "it_jac": Q.iterations,
+               "dups": bool(comm.check_duplicates(P.Solution[3]))},
               open(os.path.join(out_dir, "e_%d.json" % rank), "w"))
-    dist.barrier()
-    dist.destroy_process_group()
+    if dist_module is None:
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        dist_module.barrier()
 
 
-def test_eight_blocks_as_on_a_full_node(tmp_path):
+@pytest.mark.parametrize("scheme,hosted", [("zy", False), ("cube", False), ("cube", True)], ids=["1x2x4", "2x2x2", "2x2x2_threads"])
+def test_eight_blocks_as_on_a_full_node(tmp_path, scheme, hosted):
+    """hosted: the 8 ranks as 8 THREADS of this process with the file bootstrap of tests/filedist.py -- the harness with which
+    tests/test_gpu_peer.py / test_gpu_multi.py run 8 ranks on a one-GPU box (there over the peer-write transport)."""
     from oracle import mg
 
-    port = _free_port()
-    mp.spawn(_worker_eight, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    if hosted:
+        import threading
+
+        from filedist import FileDist
+
+        errs = []
+
+        def body(r):
+            try:
+                _worker_eight(r, 8, 0, str(tmp_path), scheme, FileDist(str(tmp_path / "boot"), r, 8, timeout=120.0))
+            except BaseException as ex:      # noqa: BLE001
+                errs.append((r, repr(ex)))
+
+        ts = [threading.Thread(target=body, args=(r,)) for r in range(8)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+    else:
+        port = _free_port()
+        mp.spawn(_worker_eight, args=(8, port, str(tmp_path), scheme), nprocs=8, join=True)
     O = mg.ProgramA(mg.ConfigA(nd=3, min_level=0, max_level=3, tol=1e-6, nfrag=(1, 1, 1), frag_len=(4, 4, 4)))
     O.setup()
     O.Solve()
@@ -318,7 +347,7 @@ def test_eight_blocks_as_on_a_full_node(tmp_path):
     J.Solve()
     for r in range(8):
         v = json.load(open(tmp_path / ("e_%d.json" % r)))
-        assert v["blocks"] == [1, 2, 4]
+        assert v["blocks"] == ([1, 2, 4] if scheme == "zy" else [2, 2, 2]) and v["dups"] is True
         assert v["it"] == O.iterations and v["it_jac"] == J.iterations
         for x, y in zip(v["res"], O.res_history):
             assert abs(x - y) <= 1e-10 * abs(y) + 1e-13 * O.res_history[0], (v["res"], O.res_history)

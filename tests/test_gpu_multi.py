@@ -71,3 +71,49 @@ def test_bench_reports_a_dropped_transport_instead_of_falling_back_silently(monk
     assert r["transport_notes"] and r["transport_notes"][0]["transport"] == "peer" and "FORCE_FAIL" in r["transport_notes"][0]["reason"]
     assert r["vcycle_graph"] is False and r["duplicate_planes_bit_identical"] is True
     assert r.get("solve_iterations") in (5, 6, 7), r
+
+
+def _bench_hosted(n, per, extra, level=6):
+    """bench.py's `run` as n ranks in n / per processes (tests/ranks_host.py: one thread and stream per rank, bootstrap through files):
+    the 8-rank job within the box's limit of processes on the card."""
+    import tempfile
+
+    boot = tempfile.mkdtemp(prefix="examg_boot_")
+    outp = os.path.join(boot, "bench.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EXAMG_PEER_TIMEOUT_MS="60000")
+    env.pop("EXAMG_TRANSPORT", None)
+    args = ["--gpus", str(n), "--steps", "10", "--warmup", "2", "--level", str(level), "--no-cpu-baseline", "--sustained-seconds", "0.5",
+            "--settle-steps", "10", "--backend", "file"] + extra
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ranks_host.py"), "bench", str(q), str(n // per), str(per), boot, outp, "--"] + args,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT) for q in range(n // per)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("hosted bench ranks timed out")
+    for q, (p, log) in enumerate(zip(procs, logs)):
+        assert p.returncode == 0, "process %d:\n%s" % (q, log[-4000:])
+    return json.load(open(outp))
+
+
+@pytest.mark.parametrize("blocks", ["2,2,2", "1,2,4"])
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_eight_ranks_on_one_gpu(blocks, scaling):
+    """The exact 8-rank job of the driver's 8-GPU run -- bench.py at N = 8 in both decompositions (--blocks cube = 2 x 2 x 2 of
+    SURVEY.md 8e; default 1 x 2 x 4) and both scaling modes -- rehearsed on ONE GPU over the peer-write transport: 4 processes of 2
+    ranks each.  No hang, overlapped Jacobi pairs and the V-cycle with neighbours replayed from a hipGraph, duplicate planes
+    bit-identical on both owners, the Solve converges in the single block's number of cycles."""
+    # weak: a 64^3-cell block per rank; strong: 128^3 cells in total (1 x 2 x 4: blocks of 128 x 64 x 32 cells)
+    r = _bench_hosted(8, 2, ["--blocks", blocks, "--scaling", scaling], level=6 if scaling == "weak" else 7)
+    assert r["n_gpus"] == 8 and r["value"] > 0
+    assert r["config"]["blocks"] == [int(b) for b in blocks.split(",")]
+    assert r["transport"] == "peer" and "transport_notes" not in r
+    assert r["duplicate_planes_bit_identical"] is True
+    assert r["vcycle_graph"] is True and "vcycle_error" not in r, r.get("vcycle_error")
+    assert r["vcycle_duplicate_planes_bit_identical"] is True
+    assert r.get("solve_iterations") in (5, 6, 7, 8), r
+    assert r["solve_residual_reduction"] < 1e-6
+    assert r["scaling"] == scaling

@@ -134,13 +134,17 @@ def _single_block(total):
     return {"dir": d, "exp": exp, "it": its, "res": list(P.res_history), "oracle_it": O.iterations, "oracle_res": list(O.res_history), "nc": nc, "ncc": ncc}
 
 
-def _run_ranks(blocks, d):
+def _run_ranks(blocks, d, per=1):
+    """Start the ranks of a decomposition as fresh child processes (never a re-exec of a process that has touched the GPU).  per = 1: one
+    process per rank, torch.distributed / gloo carries the bootstrap (tests/peer_worker.py).  per > 1: `per` ranks per process, one
+    thread and stream each, bootstrap through files (tests/ranks_host.py, tests/filedist.py) -- the box allows fewer than 8 processes
+    on its card, and 2 x 2 x 2 / 1 x 2 x 4 are what an 8-GPU node runs."""
     world = blocks[0] * blocks[1] * blocks[2]
     port = _free_port()
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     env.pop("EXAMG_TRANSPORT", None)
-    env["EXAMG_PEER_TIMEOUT_MS"] = "30000"
+    env["EXAMG_PEER_TIMEOUT_MS"] = "30000" if per == 1 else "60000"
     for r in range(world):
         for ext in ("npz", "json"):
             try:
@@ -148,10 +152,18 @@ def _run_ranks(blocks, d):
             except OSError:
                 pass
     procs = []
-    for r in range(world):     # fresh child processes (never a re-exec of a process that has touched the GPU)
-        log = open(os.path.join(d, "log_%d_%d.txt" % (world, r)), "w")
-        procs.append((subprocess.Popen([sys.executable, os.path.join(HERE, "peer_worker.py"), str(r), str(world), ",".join(map(str, blocks)), str(port), d],
-                                       stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT), log))
+    if per == 1:
+        for r in range(world):
+            log = open(os.path.join(d, "log_%d_%d.txt" % (world, r)), "w")
+            procs.append((subprocess.Popen([sys.executable, os.path.join(HERE, "peer_worker.py"), str(r), str(world), ",".join(map(str, blocks)), str(port), d],
+                                           stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT), log))
+    else:
+        assert world % per == 0
+        boot = tempfile.mkdtemp(prefix="examg_boot_")
+        for q in range(world // per):
+            log = open(os.path.join(d, "log_%d_%d.txt" % (world, q)), "w")
+            procs.append((subprocess.Popen([sys.executable, os.path.join(HERE, "ranks_host.py"), "worker", str(q), str(world // per), str(per),
+                                            ",".join(map(str, blocks)), boot, d], stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT), log))
     rcs = []
     for p, log in procs:
         try:
@@ -163,18 +175,30 @@ def _run_ranks(blocks, d):
         log.close()
     if any(rcs):
         tails = []
-        for r in range(world):
+        for r in range(len(procs)):
             with open(os.path.join(d, "log_%d_%d.txt" % (world, r))) as fh:
-                tails.append("---- rank %d (rc %s)\n%s" % (r, rcs[r], fh.read()[-3000:]))
+                tails.append("---- process %d (rc %s)\n%s" % (r, rcs[r], fh.read()[-3000:]))
         pytest.fail("peer workers failed:\n" + "\n".join(tails))
     return world
 
 
 @pytest.mark.parametrize("blocks", [(1, 1, 2), (1, 2, 2), (1, 1, 4)])
 def test_peer_transport_multi_process_on_one_gpu(single_block, blocks):
-    sb = single_block
+    _check_decomposition(single_block, blocks, 1)
+
+
+@pytest.mark.parametrize("blocks", [(2, 2, 2), (1, 2, 4)])
+def test_eight_ranks_as_on_a_full_node(single_block, blocks):
+    """The decompositions of an 8-GPU node -- 2 x 2 x 2 (domain/ir/IR_ConnectFragments.scala:46-52: every block has a
+    neighbour across an x, a y and a z face; corner ghosts travel through all three axes) and bench.py's default 1 x 2 x 4 (middle
+    blocks with neighbours on both sides of z) -- as 8 ranks on the one GPU: 4 processes of 2 ranks each (the box's process guard
+    allows no 8 processes on its card), same checks as the 2- and 4-rank decompositions."""
+    _check_decomposition(single_block, blocks, 2)
+
+
+def _check_decomposition(sb, blocks, per):
     d = sb["dir"]
-    world = _run_ranks(blocks, d)
+    world = _run_ranks(blocks, d, per)
     nc = tuple(sb["nc"][k] // blocks[k] for k in range(3))
     ncc = tuple(sb["ncc"][k] // blocks[k] for k in range(3))
     outs = [json.load(open(os.path.join(d, "out_%d.json" % r))) for r in range(world)]

@@ -64,7 +64,14 @@ def main():
     cases = json.load(open(os.path.join(go, "pmcK_times_L%d%s.json" % (args.level, args.tag))))
     fetch = per_case(dispatches(os.path.join(go, "pmcK_FETCH" + args.tag), "FETCH_SIZE"), cases)
     write = per_case(dispatches(os.path.join(go, "pmcK_WRITE" + args.tag), "WRITE_SIZE"), cases)
-    out = {"note": __doc__.split("\n\n")[-1].replace("\n", " "), "level": args.level, "cells": "%d^3" % (1 << args.level),
+    import subprocess
+
+    try:      # the tree the profiled library was built from (gpurun ships no .git: build_commit.txt)
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:      # noqa: BLE001
+        stamp = os.path.join(ROOT, "build_commit.txt")      # written by tools/grun.sh before the snapshot leaves for the GPU box
+        commit = open(stamp).read().strip() if os.path.exists(stamp) else None
+    out = {"note": __doc__.split("\n\n")[-1].replace("\n", " "), "commit": commit, "level": args.level, "cells": "%d^3" % (1 << args.level),
            "align": cases[0].get("align", 0) if cases else 0, "kernels": []}
     for c, (fb, kn, nf), (wb, _, nw) in zip(cases, fetch, write):
         rec = dict(c)
