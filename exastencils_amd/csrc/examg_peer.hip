@@ -25,6 +25,10 @@
 #include <stdlib.h>
 #include <unistd.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+
 #include "examg_comm_internal.h"
 
 namespace examg {
@@ -296,9 +300,44 @@ unsigned copy_blocks(long long count) {      // few, grid-striding workgroups: a
   return (unsigned)nb;
 }
 
+// HIP IPC maps an exported region ONCE per process (a second hipIpcOpenMemHandle of the same handle fails with "invalid device
+// context"): the blocks of one process that share a neighbour in another process share its mapping, counted here.
+struct IpcMapping {
+  void *ptr;
+  int refs;
+};
+std::mutex g_ipc_mutex;
+std::map<std::string, IpcMapping> g_ipc_open;
+
+hipError_t ipc_open_shared(void **ptr, const hipIpcMemHandle_t &h) {
+  const std::string key(reinterpret_cast<const char *>(&h), sizeof(h));
+  std::lock_guard<std::mutex> lock(g_ipc_mutex);
+  auto it = g_ipc_open.find(key);
+  if (it != g_ipc_open.end()) {
+    ++it->second.refs;
+    *ptr = it->second.ptr;
+    return hipSuccess;
+  }
+  const hipError_t e = hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
+  if (e == hipSuccess) g_ipc_open[key] = IpcMapping{*ptr, 1};
+  return e;
+}
+
+void ipc_close_shared(void *ptr) {
+  std::lock_guard<std::mutex> lock(g_ipc_mutex);
+  for (auto it = g_ipc_open.begin(); it != g_ipc_open.end(); ++it) {
+    if (it->second.ptr != ptr) continue;
+    if (--it->second.refs == 0) {
+      (void)hipIpcCloseMemHandle(ptr);
+      g_ipc_open.erase(it);
+    }
+    return;
+  }
+}
+
 void release_mappings(PeerState *p, int me, int nranks) {
   for (int r = 0; r < nranks; ++r) {
-    if (r != me && p->remote[r] && p->remote_ipc[r]) (void)hipIpcCloseMemHandle(p->remote[r]);
+    if (r != me && p->remote[r] && p->remote_ipc[r]) ipc_close_shared(p->remote[r]);
     p->remote[r] = nullptr;
     p->remote_ipc[r] = false;
   }
@@ -474,7 +513,7 @@ extern "C" int examg_comm_peer_connect(examg_comm_t *comm, const void *all_handl
       continue;
     }
     void *ptr = nullptr;
-    if (check_hip(hipIpcOpenMemHandle(&ptr, w.mem, hipIpcMemLazyEnablePeerAccess), "examg_comm_peer_connect: hipIpcOpenMemHandle")) return 1;
+    if (check_hip(ipc_open_shared(&ptr, w.mem), "examg_comm_peer_connect: hipIpcOpenMemHandle")) return 1;
     p->remote[r] = (char *)ptr;
     p->remote_ipc[r] = true;
   }

@@ -4,6 +4,7 @@ set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r04_gputests.log 2>&1; rc=$?; tail -15 gpurun_out/r04_gputests.log
 if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 120 tools/barrier_probe.bin > gpurun_out/r04_barrier_probe.txt 2>&1; cat gpurun_out/r04_barrier_probe.txt
 timeout -k 10 200 python tools/exchange_faces.py > gpurun_out/r04_exchange_faces.json 2> gpurun_out/r04_exchange_faces.err || { tail -5 gpurun_out/r04_exchange_faces.err; exit 1; }
 cat gpurun_out/r04_exchange_faces.json
 LEVEL=8 ROUND=r04 bash tools/gpu_pmc.sh || exit 1
