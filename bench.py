@@ -39,7 +39,9 @@ if ROOT not in sys.path:
 
 BYTES_PER_LU = 24.0
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")      # tools/gpu_pmc.sh; the commit it was taken at is inside
+# counter profiles, newest first (tools/gpu_pmc.sh; the commit and, per kernel, the digest of its sources are inside); level 8 / padded
+# layouts: <name>_L8.json / <name>_align16.json
+PMC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_kernels.json", "r03_pmc_kernels.json")]
 
 
 def parse(argv=None):
@@ -94,6 +96,9 @@ def cpu_baseline(seconds: float):
 
     from oracle import mg
 
+    # every loop nest in the generator's default shape: `#pragma omp parallel for schedule(static)` on the OUTER loop only
+    # (omp_useCollapse = false, parallelization/api/omp/OMP_Loop.scala:47,103-110) -- oracle/libexamg_oracle_gen.so
+    mg.generator_shape(True)
     L = mg.lib()
     L.orc_set_num_threads(min(int(L.orc_num_threads()), mg.cpu_budget()))   # affinity mask capped by the cgroup CPU quota
     n = 512
@@ -145,6 +150,7 @@ def cpu_baseline(seconds: float):
         "unit": "LU/s",
         "cores": int(L.orc_num_threads()),
         "kind": "port",
+        "loop_shape": "z-y-x nest, OpenMP pragma on the outer loop only (the generator's default, omp_useCollapse = false), -O3 -fopenmp -ffp-contract=off",
         "sample": "%d Jacobi 7-pt sweeps of 512^3 cells (511^3 updates each), restated generator-shaped OpenMP loop, %.1f s; "
                   "per kernel ~2 s each; one V(3,3) cycle (levels 4..9) of the Benchmark/Poisson3D program" % (k, dt),
     }
@@ -167,18 +173,31 @@ def cpu_baseline(seconds: float):
 
 
 def pmc_traffic(case, level, align):
-    """Fabric-side bytes per launch from the committed counter profile -- only for this kernel case, block size and layout."""
-    try:
-        prof = json.load(open(PMC_PROFILE if not align else PMC_PROFILE.replace(".json", "_align%d.json" % align)))
-    except (OSError, ValueError):
-        return None
-    if prof.get("level") != level or prof.get("align", 0) != align:
-        return None
-    for k in prof.get("kernels", []):
-        if k.get("case") == case and "traffic" in k:
-            return {"traffic": k["traffic"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
-                    "source": "profiles/" + os.path.basename(PMC_PROFILE if not align else PMC_PROFILE.replace(".json", "_align%d.json" % align)),
-                    "source_commit": prof.get("commit"), "source_kernel": k.get("kernel_name")}
+    """Fabric-side bytes per launch from the committed counter profile -- only for this kernel case, block size and layout, and only
+    while the kernel's sources are the ones that were profiled (tools/pmc_reduce.py: kernel_source_digest): counters taken on another
+    build of the kernel describe another kernel, and are reported as stale instead of as `traffic`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_reduce
+
+    for path in PMC_PROFILES:
+        if level != 9:
+            path = path.replace(".json", "_L%d.json" % level)
+        if align:
+            path = path.replace(".json", "_align%d.json" % align)
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if prof.get("level") != level or prof.get("align", 0) != align:
+            continue
+        for k in prof.get("kernels", []):
+            if k.get("case") == case and "traffic" in k:
+                rec = {"traffic": k["traffic"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
+                       "source": "profiles/" + os.path.basename(path), "source_commit": prof.get("commit"), "source_kernel": k.get("kernel_name")}
+                digest = k.get("source_digest")
+                if digest is None or digest != pmc_reduce.kernel_source_digest(case):
+                    rec["stale"] = True      # the kernel changed since (or the profile predates the digests): not this build's traffic
+                return rec
     return None
 
 
@@ -443,7 +462,7 @@ def run(args, world, rank, local_rank, dist, injected=False):
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc["traffic"] if pmc else None,
+                "traffic": pmc["traffic"] if (pmc and not pmc.get("stale")) else None,
                 "kernel": kernel_name,
                 "kernel_ms": kernel_ms,
                 "compulsory_bytes_per_launch": compulsory,
@@ -453,9 +472,11 @@ def run(args, world, rank, local_rank, dist, injected=False):
                 # statement, not a roofline fraction
                 "lu_equivalent_gbs": BYTES_PER_LU * lus / (kernel_ms * 1e-3) / 1e9,
                 "lu_equivalent_frac": BYTES_PER_LU * lus / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic_over_compulsory": (pmc["traffic"] / compulsory) if pmc else None,
+                "traffic_over_compulsory": (pmc["traffic"] / compulsory) if (pmc and not pmc.get("stale")) else None,
                 "traffic_source": pmc["source"] if pmc else None,
                 "traffic_source_commit": pmc.get("source_commit") if pmc else None,     # the tree the counter profile was taken at
+                # True: the kernel's sources changed since that profile -- its counters are not reported as this build's traffic
+                "traffic_source_stale": bool(pmc.get("stale")) if pmc else None,
             },
         }
         if dup_check is not None:
@@ -513,6 +534,11 @@ def run(args, world, rank, local_rank, dist, injected=False):
                 more.update(helmholtz27_cycle(ops, L))
             except Exception as ex:
                 more["helmholtz27_error"] = repr(ex)[:300]
+            try:
+                torch.cuda.empty_cache()
+                more.update(shim_cycle(L))
+            except Exception as ex:
+                more["shim_error"] = repr(ex)[:300]
         done.set()
         if rank == 0:
             if "roofline_kernels" in more and "vcycle_ms" in more:
@@ -597,7 +623,7 @@ def kernel_table(ops, level, align):
         row = {"case": name, "kernel": pattern, "ms": ms, "compulsory_bytes": comp, "lattice_updates": lus,
                "frac": comp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         pmc = pmc_traffic(name, level, align)
-        if pmc:
+        if pmc and not pmc.get("stale"):
             row["traffic"] = pmc["traffic"]
             row["traffic_over_compulsory"] = pmc["traffic"] / comp
         rows.append(row)
@@ -642,6 +668,10 @@ def config1(ops, world):
         out["jacobi_256cube_%s_kernel_ms" % name] = ms
         out["jacobi_256cube_%s_lups" % name] = steps * (n - 1) ** 3 / (ms * 1e-3)
         out["jacobi_256cube_%s_frac" % name] = 24.0 * (n - 1) ** 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        pmc = pmc_traffic("jacobi_1step" if steps == 1 else "jacobi_2step", 8, 0)      # profiles/<round>_pmc_kernels_L8.json
+        if pmc and not pmc.get("stale"):
+            out["jacobi_256cube_%s_traffic" % name] = pmc["traffic"]
+            out["jacobi_256cube_%s_traffic_over_compulsory" % name] = pmc["traffic"] / (24.0 * (n - 1) ** 3)
     return out
 
 
@@ -727,6 +757,29 @@ def vcycle(ops, dom, comm, L, world, align=0, check_dups=True):
         "vcycle_fused_rbgs": True,
         "vcycle_agglomerate_level": agg,
     }
+
+
+def shim_cycle(L):
+    """The V-cycle through the reference-named seam: shim/exa_poisson3d_<min>_<max> (generated-style C++ host that calls only
+    mgCycle_<L>_k<NNN>_wrapper / exch<F>_<L> / applyBCs<F>_<L>; cuda/CUDA_Kernel.scala:546-632) as a child process, once with the plain
+    wrappers (one libexamg call per wrapper) and once with EXA_DEFERRED_LAUNCH=1 (wrappers record, the completing wrapper launches the
+    one-pass kernel).  ms per cycle by the host's own clock around device-synchronised cycles, after its Solve."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "shim", "exa_poisson3d_%d_%d" % (L - 5, L))
+    if L - 5 < 1 or not os.path.exists(exe):
+        return {"shim_skipped": "no shim binary for levels %d..%d (build(): 2..6 and 4..9)" % (L - 5, L)}
+    out = {}
+    for mode, key in (("0", "plain"), ("1", "deferred")):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, EXA_DEFERRED_LAUNCH=mode, EXA_TIME_CYCLES="10"))
+        if r.returncode != 0:
+            return {"shim_error": ("%s wrappers: rc %d: %s" % (key, r.returncode, r.stderr[-200:]))}
+        t = [l for l in r.stdout.splitlines() if l.startswith("vcycle_ms")][0].split()
+        out["shim_vcycle_ms_" + key] = float(t[1])
+        out["shim_launches_per_cycle_" + key] = int(t[3])
+        out["shim_solve_iterations_" + key] = int([l for l in r.stdout.splitlines() if l.startswith("iterations")][0].split()[1])
+    out["shim_levels"] = [L - 5, L]
+    return out
 
 
 def fmg_solve(ops, L, align=0):

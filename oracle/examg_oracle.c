@@ -28,6 +28,19 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Loop nests over (i2, i1): by default both loops are shared among the threads (collapse(2): 2-D fields and small coarse levels
+ * keep all cores busy in the tests).  The generator prints the pragma on the OUTER loop only -- `omp_useCollapse` defaults to
+ * false (config/Knowledge.scala:481, parallelization/api/omp/OMP_Loop.scala:47,103-110) -- and that shape is what bench.py times
+ * as the CPU baseline: libexamg_oracle_gen.so is this file compiled with -DORC_OUTER_ONLY (same arithmetic, same results). */
+#define ORC_PRAGMA(x) _Pragma(#x)
+#ifdef ORC_OUTER_ONLY
+#define ORC_PARFOR ORC_PRAGMA(omp parallel for schedule(static))
+#define ORC_PARFOR_RED(r) ORC_PRAGMA(omp parallel for schedule(static) reduction(r))
+#else
+#define ORC_PARFOR ORC_PRAGMA(omp parallel for schedule(static) collapse(2))
+#define ORC_PARFOR_RED(r) ORC_PRAGMA(omp parallel for schedule(static) collapse(2) reduction(r))
+#endif
+
 #define ORC_MAX_ENTRIES 27
 
 /* Per-dimension regions  pad | ghost | dup | inner | dup | ghost | pad
@@ -115,7 +128,7 @@ void orc_stencil_op(int mode, const orc_layout_t *lu, const double *u, const orc
   const double *cf = st->cfield;
   const ptrdiff_t cplane = cf ? lay_size(&st->clayout) : 0;
   const int b0 = begin[0], e0 = end[0];
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1) {
       const ptrdiff_t ubase = lay_idx(lu, 0, i1, i2);
@@ -176,7 +189,7 @@ void orc_restrict(const orc_layout_t *lfine, const double *rf, const orc_layout_
                   const int *begin, const int *end) {
   const int nd = lfine->nd;
   static const double w1[3] = {0.25, 0.5, 0.25};
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int I2 = begin[2]; I2 < end[2]; ++I2)
     for (int I1 = begin[1]; I1 < end[1]; ++I1)
       for (int I0 = begin[0]; I0 < end[0]; ++I0) {
@@ -211,7 +224,7 @@ void orc_restrict(const orc_layout_t *lfine, const double *rf, const orc_layout_
 void orc_prolong_add(const orc_layout_t *lc, const double *uc, const orc_layout_t *lfine, double *uf,
                      const int *begin, const int *end) {
   const int nd = lfine->nd;
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1)
       for (int i0 = begin[0]; i0 < end[0]; ++i0) {
@@ -243,7 +256,7 @@ void orc_prolong_add(const orc_layout_t *lc, const double *uc, const orc_layout_
 /* ------------------------------------------------------------------ */
 
 void orc_set(const orc_layout_t *l, double *x, double v, const int *begin, const int *end) {
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1)
       for (int i0 = begin[0]; i0 < end[0]; ++i0) x[lay_idx(l, i0, i1, i2)] = v;
@@ -255,7 +268,7 @@ void orc_set(const orc_layout_t *l, double *x, double v, const int *begin, const
  *   b == 1:  y + a*x        a == 1:  x + b*y        b == 0:  a*x */
 void orc_axpby(const orc_layout_t *lx, const double *x, const orc_layout_t *ly, double *y, double a, double b,
                const int *begin, const int *end) {
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1)
       for (int i0 = begin[0]; i0 < end[0]; ++i0) {
@@ -279,7 +292,7 @@ double orc_dot(const orc_layout_t *lx, const double *x, const orc_layout_t *ly, 
   if (n2 <= 0 || end[1] <= begin[1] || end[0] <= begin[0]) return 0.0;
   const int n1 = end[1] - begin[1];
   double *part = (double *)calloc((size_t)n2 * n1, sizeof(double));
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1) {
       double s = 0.0;
@@ -357,7 +370,7 @@ typedef struct {
  * over the index ranges of IR_ApplyBCFunction.scala:53-83), InitRHS, SetFuncDir. */
 void orc_fill_fn(const orc_layout_t *l, double *x, const orc_geom_t *g, int fn, const double *p, const int *begin,
                  const int *end) {
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1)
       for (int i0 = begin[0]; i0 < end[0]; ++i0) {
@@ -372,7 +385,7 @@ void orc_fill_fn(const orc_layout_t *l, double *x, const orc_geom_t *g, int fn, 
 double orc_max_err_fn(const orc_layout_t *l, const double *x, const orc_geom_t *g, int fn, const double *p,
                       const int *begin, const int *end) {
   double m = 0.0;
-#pragma omp parallel for schedule(static) collapse(2) reduction(max : m)
+ORC_PARFOR_RED(max : m)
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1)
       for (int i0 = begin[0]; i0 < end[0]; ++i0) {
@@ -392,7 +405,7 @@ void orc_init_varcoeff7(const orc_layout_t *lc, double *cf, const orc_geom_t *g,
                         const int *begin, const int *end) {
   const int nd = lc->nd;
   const ptrdiff_t plane = lay_size(lc);
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1)
       for (int i0 = begin[0]; i0 < end[0]; ++i0) {
@@ -429,7 +442,7 @@ void orc_init_varcoeff7(const orc_layout_t *lc, double *cf, const orc_geom_t *g,
 
 void orc_pack(const orc_layout_t *l, const double *x, double *buf, const int *begin, const int *end) {
   const ptrdiff_t n0 = end[0] - begin[0], n1 = end[1] - begin[1];
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1)
       for (int i0 = begin[0]; i0 < end[0]; ++i0)
@@ -438,7 +451,7 @@ void orc_pack(const orc_layout_t *l, const double *x, double *buf, const int *be
 
 void orc_unpack(const orc_layout_t *l, double *x, const double *buf, const int *begin, const int *end) {
   const ptrdiff_t n0 = end[0] - begin[0], n1 = end[1] - begin[1];
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1)
       for (int i0 = begin[0]; i0 < end[0]; ++i0)
@@ -495,7 +508,7 @@ void orc_init_helmholtz27(const orc_layout_t *lc, double *cf, const orc_geom_t *
                           const int *begin, const int *end) {
   const ptrdiff_t plane = lay_size(lc);
   const double ksq = p[1];
-#pragma omp parallel for schedule(static) collapse(2)
+ORC_PARFOR
   for (int i2 = begin[2]; i2 < end[2]; ++i2)
     for (int i1 = begin[1]; i1 < end[1]; ++i1)
       for (int i0 = begin[0]; i0 < end[0]; ++i0) {

@@ -58,22 +58,38 @@ class GeomC(C.Structure):
     _fields_ = [("pos_begin", C.c_double * 3), ("h", C.c_double * 3)]
 
 
+_GEN_LIB_PATH = os.path.join(_HERE, "libexamg_oracle_gen.so")
+
+
 def build(force: bool = False) -> str:
-    """Compile the C restatement with the committed Makefile."""
+    """Compile the C restatement with the committed Makefile: the checker's build and the generator-shaped one (pragma on the outer
+    loop only) that bench.py times as the CPU baseline."""
     src = os.path.join(_HERE, "examg_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libexamg_oracle.so"])
+    for path in (_LIB_PATH, _GEN_LIB_PATH):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", os.path.basename(path)])
     return _LIB_PATH
 
 
 _lib = None
+_shape = "collapse"
+
+
+def generator_shape(on: bool = True):
+    """Switch the process to the build whose loop nests carry the OpenMP pragma on the outer loop only -- what the generator prints
+    with its default `omp_useCollapse = false` (parallelization/api/omp/OMP_Loop.scala:47,103-110).  For timing (bench.py's
+    cpu_baseline); results are the same bits either way."""
+    global _lib, _shape
+    want = "outer" if on else "collapse"
+    if want != _shape:
+        _shape, _lib = want, None
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(_GEN_LIB_PATH if _shape == "outer" else _LIB_PATH)
         dp, ip, lp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(LayoutC)
         L.orc_stencil_op.argtypes = [C.c_int, lp, dp, lp, dp, lp, dp, C.POINTER(StencilC), C.c_double, C.c_int, ip, ip]
         L.orc_stencil_op.restype = None

@@ -58,6 +58,12 @@ void setupBuffers(void);
 void destroyGlobals(void);
 /* MPI_Allreduce(MPI_IN_PLACE, x, 1, MPI_DOUBLE, MPI_SUM) on a host value, as the generated host code does after a reduction */
 void exa_allreduce_sum(double *x);
+/* Deferred-launch mode of the wrappers (environment EXA_DEFERRED_LAUNCH=1, one block; exa_poisson3d_kernels.cpp): a wrapper whose loop
+ * a one-pass kernel of libexamg can absorb records its call, the wrapper that completes the pattern launches the one-pass kernel; any
+ * other entry point runs what is recorded first.  exa_shim_flush() does that explicitly (before the host touches a field array by
+ * other means); exa_shim_launches() counts the libexamg launches so far. */
+void exa_shim_flush(void);
+long exa_shim_launches(void);
 
 #define EXA_DECLARE_FINE(L)                                   \
   void EXA_CAT3(mgCycle_, L, _k000_wrapper)(void);            \

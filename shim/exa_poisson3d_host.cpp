@@ -177,6 +177,18 @@ int main(int argc, char **argv) {
     for (double r : g_history) std::printf("# %.17g\n", r);
     std::printf("iterations %d\n", g_iterations);
   }
+  if (const char *tc = std::getenv("EXA_TIME_CYCLES")) {
+    // the benchmark's timer around the cycle (benchmarkStart / benchmarkStop, ...exa4:263-276): n further cycles, device synchronised
+    const int n = std::atoi(tc);
+    EXA_CAT3(mgCycle_, EXA_MAX_LEVEL, )();
+    (void)hipDeviceSynchronize();
+    const long l0 = exa_shim_launches();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) EXA_CAT3(mgCycle_, EXA_MAX_LEVEL, )();
+    (void)hipDeviceSynchronize();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (n > 0 ? n : 1);
+    if (rank == 0) std::printf("vcycle_ms %.6f launches_per_cycle %ld\n", ms, n > 0 ? (exa_shim_launches() - l0) / n : 0);
+  }
   destroyGlobals();
   return 0;
 }

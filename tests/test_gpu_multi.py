@@ -80,7 +80,11 @@ def _bench_hosted(n, per, extra, level=6):
 
     boot = tempfile.mkdtemp(prefix="examg_boot_")
     outp = os.path.join(boot, "bench.json")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EXAMG_PEER_TIMEOUT_MS="60000")
+    # Two ranks per process = twice the streams (launch + side stream per rank, capture streams) of a product process.  HIP maps the
+    # streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams on one queue run in order, and a receive
+    # kernel that waits for the neighbour in the same process would block the very send it waits for.  One rank per process (the
+    # product's launch) stays within the default.
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EXAMG_PEER_TIMEOUT_MS="60000", GPU_MAX_HW_QUEUES="16")
     env.pop("EXAMG_TRANSPORT", None)
     args = ["--gpus", str(n), "--steps", "10", "--warmup", "2", "--level", str(level), "--no-cpu-baseline", "--sustained-seconds", "0.5",
             "--settle-steps", "10", "--backend", "file"] + extra

@@ -53,6 +53,28 @@ def test_shim_host_512_matches_full_size_fixture():
     assert "iterations %d" % rec["iterations"] in out.stdout
 
 
+@pytest.mark.parametrize("levels", [(2, 6), (4, 9)])
+def test_shim_deferred_launch_mode_prints_the_same_history(levels):
+    """EXA_DEFERRED_LAUNCH=1: the same host binary, the same reference-named wrappers -- k000 records, k001 launches ONE out-of-place
+    red-black sweep; k002 + k003 one residual + restriction pass; k004 / k005 ride on the first sweep after them
+    (shim/exa_poisson3d_kernels.cpp).  Every printed value, in full precision, equals the plain wrappers' bit for bit; fewer launches."""
+    import __graft_entry__ as ge
+
+    exe = ge.build_shim(*levels)
+    runs = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, EXA_DEFERRED_LAUNCH=mode, EXA_TIME_CYCLES="3")
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr
+        timing = [l for l in out.stdout.splitlines() if l.startswith("vcycle_ms")][0].split()
+        runs[mode] = (_history(out.stdout), [l for l in out.stdout.splitlines() if not l.startswith("vcycle_ms")], float(timing[1]), int(timing[3]))
+    assert runs["1"][0] == runs["0"][0], "full-precision histories differ between the deferred and the plain wrappers"
+    assert runs["1"][1] == runs["0"][1]
+    assert runs["1"][3] < runs["0"][3], "deferred mode should need fewer launches per cycle: %r" % ({k: v[2:] for k, v in runs.items()},)
+    if levels == (4, 9):
+        assert runs["1"][2] < runs["0"][2]
+
+
 def test_shim_two_blocks_over_rccl(tmp_path):
     """Two processes, one per GPU, blocks 1 x 1 x 2: exch<Field>_<L> = examg_exchange over RCCL, reductions through
     examg_allreduce; the root's history must be the oracle's for the same decomposition.  Needs two GPUs."""

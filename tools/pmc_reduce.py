@@ -18,6 +18,25 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK = 8000.0e9
 
+# the sources a case's kernel is compiled from: their digest travels with the counters, and bench.py reports `traffic` only for a
+# kernel whose sources are still the profiled ones (kernel_source_digest)
+COMMON_SOURCES = ["examg_common.h"]
+CASE_SOURCES = {"jacobi_2step": ["kernels_twostage.hip"], "rbgs_fused_sweep": ["kernels_twostage.hip"], "rbgs_fused_sweep_prolong": ["kernels_twostage.hip"],
+                "rbgs_fused_sweep_zero": ["kernels_twostage.hip"], "residual_restrict": ["kernels_transfer.hip"], "restrict": ["kernels_transfer.hip"],
+                "prolong_add": ["kernels_transfer.hip"], "dot_norm": ["kernels_blas.hip"], "jacobi_27entry_two_steps": ["kernels_sf27pair.hip"],
+                "jacobi_27entry_step_residual": ["kernels_sf27pair.hip"]}
+
+
+def kernel_source_digest(case):
+    """sha256 (16 hex digits) over the HIP sources the kernel of `case` is compiled from."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in COMMON_SOURCES + CASE_SOURCES.get(case, ["kernels_stencil.hip"]):
+        with open(os.path.join(ROOT, "exastencils_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
 
 def dispatches(directory, counter):
     rows = []
@@ -76,6 +95,7 @@ def main():
     for c, (fb, kn, nf), (wb, _, nw) in zip(cases, fetch, write):
         rec = dict(c)
         rec["kernel_name"] = kn
+        rec["source_digest"] = kernel_source_digest(c["case"])
         if fb is not None and wb is not None:
             rec.update(fetch_bytes=2.0 * fb, write_bytes=wb, traffic=2.0 * fb + wb, traffic_over_compulsory=(2.0 * fb + wb) / c["compulsory_bytes"],
                        dispatches_averaged=[nf, nw])
