@@ -395,6 +395,11 @@ def run(args, world, rank, local_rank, dist, injected=False):
     if args.sustained_seconds > 0:
         # ~0.25 s of steps between looks at the clock; dt is the all-reduced maximum here, so every rank forms the same chunks
         chunk = max(2, 2 * (int(0.25 / max(dt / args.steps, 1e-6)) // 2))
+        if injected:
+            # several ranks hosted by ONE process (tests/ranks_host.py): a host thread that runs hundreds of launches ahead of the device
+            # can block inside the HIP runtime (full queue) while the launch its kernels wait for belongs to the other thread of the
+            # same process.  One rank per process -- the product's launch -- has no such coupling.
+            chunk = min(chunk, 16)
         n_sus, t_sus = 0, 0.0
         barrier()
         t1 = time.perf_counter()

@@ -38,7 +38,7 @@ class FileDist:
 
     P2POp = P2POp
 
-    def __init__(self, directory: str, rank: int, world: int, timeout: float = 300.0):
+    def __init__(self, directory: str, rank: int, world: int, timeout: float = 150.0):
         self.dir, self.rank, self.world, self.timeout = directory, int(rank), int(world), timeout
         self._seq = 0
         self._sent, self._rcvd = {}, {}

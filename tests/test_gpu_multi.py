@@ -84,7 +84,7 @@ def _bench_hosted(n, per, extra, level=6):
     # streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams on one queue run in order, and a receive
     # kernel that waits for the neighbour in the same process would block the very send it waits for.  One rank per process (the
     # product's launch) stays within the default.
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EXAMG_PEER_TIMEOUT_MS="60000", GPU_MAX_HW_QUEUES="16")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EXAMG_PEER_TIMEOUT_MS="60000", GPU_MAX_HW_QUEUES="8")
     env.pop("EXAMG_TRANSPORT", None)
     args = ["--gpus", str(n), "--steps", "10", "--warmup", "2", "--level", str(level), "--no-cpu-baseline", "--sustained-seconds", "0.5",
             "--settle-steps", "10", "--backend", "file"] + extra

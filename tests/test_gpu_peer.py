@@ -148,7 +148,7 @@ def _run_ranks(blocks, d, per=1):
     if per > 1:
         # several ranks per process: every rank's streams need hardware queues of their own (HIP shares GPU_MAX_HW_QUEUES = 4 queues
         # among the streams of a process by default; a waiting receive kernel must never sit in front of the send it waits for)
-        env["GPU_MAX_HW_QUEUES"] = "16"
+        env["GPU_MAX_HW_QUEUES"] = "8"
     for r in range(world):
         for ext in ("npz", "json"):
             try:
