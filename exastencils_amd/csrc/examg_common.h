@@ -73,6 +73,15 @@ static inline bool box_inside(const examg_layout_t *l, const Box &b, int halo) {
 void set_error(const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
 
+// one-pass kernels of the launch-bound levels (kernels_small.hip), tried by the entry points when the large-level kernels decline
+bool small_two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box);
+int launch_small_two_stage(bool col, int var, const examg_layout_t *lu, const double *u_in, double *u_out, const examg_layout_t *lf, const double *rhs,
+                      const examg_stencil_t *st, double w, int first, const Box &box, const examg_layout_t *lc, const double *uc, hipStream_t s);
+bool small_residual_restrict_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const examg_layout_t *lc, const Box &fb,
+                                const Box &cb);
+int launch_small_residual_restrict(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs, const examg_layout_t *lc,
+                                   double *fc, const examg_stencil_t *st, double scale, const Box &cb, hipStream_t s);
+
 #define EXAMG_CHECK_LAUNCH(name)                                   \
   do {                                                             \
     hipError_t _e = hipGetLastError();                             \

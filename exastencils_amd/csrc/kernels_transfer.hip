@@ -453,6 +453,7 @@ static bool residual_restrict_one_pass(const examg_layout_t *lu_, const examg_la
   const bool inside = 2 * cb.b0 - 1 >= fb.b0 && 2 * (cb.e0 - 1) + 1 < fb.e0 && 2 * cb.b1 - 1 >= fb.b1 && 2 * (cb.e1 - 1) + 1 < fb.e1 &&
                       2 * cb.b2 - 1 >= fb.b2 && 2 * (cb.e2 - 1) + 1 < fb.e2;
   const bool left_ok = 2 * (cb.b0 - 1) >= -(lu_->pad_l[0] + lu_->ghost_l[0]) && 2 * (cb.b0 - 1) >= -(lf_->pad_l[0] + lf_->ghost_l[0]);
+  if (small_residual_restrict_ok(lu_, lf_, st, lc_, fb, cb)) return true;      // launch-bound levels: kernels_small.hip
   return g_restrict_wide && lu_->nd == 3 && ord >= 0 && cb.n0() >= 32 && inside && left_ok && box_inside(lu_, fb, 1) && box_inside(lf_, fb, 0) &&
          box_inside(lc_, cb, 0);
 }
@@ -471,6 +472,8 @@ extern "C" int examg_residual_restrict(const examg_layout_t *lu_, const double *
   const Box cb = make_box(cbegin, cend);
   if (cb.count() == 0) return 0;
   const int ord = canonical_order7(st);
+  if (small_residual_restrict_ok(lu_, lf_, st, lc_, make_box(fbegin, fend), cb))
+    return launch_small_residual_restrict(lu_, u, lf_, rhs, lc_, fc, st, scale, cb, (hipStream_t)stream);
   if (residual_restrict_one_pass(lu_, lf_, st, lc_, fbegin, fend, cbegin, cend)) {
     const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_), lc = make_layout(lc_);
     Coef7 k;

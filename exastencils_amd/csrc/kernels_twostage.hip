@@ -716,6 +716,10 @@ extern "C" int examg_two_stage_eligible(const examg_layout_t *lu, const examg_la
   const Box box1 = make_box(begin1, end1), box2 = make_box(begin2, end2);
   if (box2.count() == 0) return 0;
   if (box2.b0 < box1.b0 || box2.b1 < box1.b1 || box2.b2 < box1.b2 || box2.e0 > box1.e0 || box2.e1 > box1.e1 || box2.e2 > box1.e2) return 0;
+  // launch-bound levels (rows shorter than 64 points): the small-level sweep, one box only (kernels_small.hip)
+  if (box1.b0 == box2.b0 && box1.b1 == box2.b1 && box1.b2 == box2.b2 && box1.e0 == box2.e0 && box1.e1 == box2.e1 && box1.e2 == box2.e2 &&
+      small_two_stage_ok(lu, lf, st, box2))
+    return 1;
   if (!(two_stage_ok(lu, lf, st, box2) && box_inside(lu, box1, 1) && box_inside(lf, box1, 0) && stage_boxes_ok(lf, box1, box2))) return 0;
   // launch_two_stage_lds: row offsets within a plane are 32-bit products
   const LayoutDev u = make_layout(lu), f = make_layout(lf);
@@ -732,6 +736,7 @@ extern "C" int examg_rbgs_sweep_fused(const examg_layout_t *lu, const double *u_
   const Box box = make_box(begin, end);
   if (box.count() == 0) return 0;
   if (two_stage_ok(lu, lf, st, box)) return launch_two_stage<true>(lu, u_in, lf, rhs, u_out, st, w, first, box, (hipStream_t)stream);
+  if (small_two_stage_ok(lu, lf, st, box)) return launch_small_two_stage(true, 0, lu, u_in, u_out, lf, rhs, st, w, first, box, nullptr, nullptr, (hipStream_t)stream);
   // general stencils / small boxes: bring the box and its one-stencil-reach shell over, then the two half
   // sweeps in place on the copy (the shell of u_out receives u_in's shell values -- see the header)
   const int reach = stencil_reach(st);
@@ -759,6 +764,7 @@ extern "C" int examg_rbgs_sweep_fused_zero(const examg_layout_t *lu, double *u_o
   if (box.count() == 0) return 0;
   if (two_stage_ok(lu, lf, st, box))
     return launch_two_stage<true>(lu, u_out, lf, rhs, u_out, st, w, first, box, (hipStream_t)stream, nullptr, nullptr, true);
+  if (small_two_stage_ok(lu, lf, st, box)) return launch_small_two_stage(true, 2, lu, nullptr, u_out, lf, rhs, st, w, first, box, nullptr, nullptr, (hipStream_t)stream);
   // general stencils / small boxes: zero the box and its one-stencil-reach shell, then the two half sweeps in place
   const int reach = stencil_reach(st);
   int32_t b2[3], e2[3];
@@ -791,6 +797,10 @@ extern "C" int examg_rbgs_sweep_fused_prolong(const examg_layout_t *lu, const do
     pr.lc = make_layout(lc);
     pr.uc = uc;
     return launch_two_stage<true>(lu, u_in, lf, rhs, u_out, st, w, first, box, (hipStream_t)stream, nullptr, &pr);
+  }
+  if (small_two_stage_ok(lu, lf, st, box)) {
+    if (!prolong_args_ok("examg_rbgs_sweep_fused_prolong", lc, box)) return 1;
+    return launch_small_two_stage(true, 1, lu, u_in, u_out, lf, rhs, st, w, first, box, lc, uc, (hipStream_t)stream);
   }
   // general stencils / small boxes: the three loops one after the other on a copy (box + one-stencil-reach shell)
   const int reach = stencil_reach(st);
@@ -826,6 +836,9 @@ extern "C" int examg_rbgs_sweep_fused_boxes(const examg_layout_t *lu, const doub
   }
   if (two_stage_ok(lu, lf, st, box2) && box_inside(lu, box1, 1) && box_inside(lf, box1, 0) && stage_boxes_ok(lf, box1, box2))
     return launch_two_stage<true>(lu, u_in, lf, rhs, u_out, st, w, first, box2, (hipStream_t)stream, &box1);
+  if (box1.b0 == box2.b0 && box1.b1 == box2.b1 && box1.b2 == box2.b2 && box1.e0 == box2.e0 && box1.e1 == box2.e1 && box1.e2 == box2.e2 &&
+      small_two_stage_ok(lu, lf, st, box2))
+    return launch_small_two_stage(true, 0, lu, u_in, u_out, lf, rhs, st, w, first, box2, nullptr, nullptr, (hipStream_t)stream);
   if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_rbgs_sweep_fused_boxes: fallback needs a distinct tmp array"); return 1; }
   const int reach = stencil_reach(st);
   int32_t b2[3], e2[3];
@@ -861,6 +874,9 @@ extern "C" int examg_jacobi2_boxes(const examg_layout_t *lu, const double *u_in,
   }
   if (two_stage_ok(lu, lf, st, box2) && box_inside(lu, box1, 1) && box_inside(lf, box1, 0) && stage_boxes_ok(lf, box1, box2))
     return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box2, (hipStream_t)stream, &box1);
+  if (box1.b0 == box2.b0 && box1.b1 == box2.b1 && box1.b2 == box2.b2 && box1.e0 == box2.e0 && box1.e1 == box2.e1 && box1.e2 == box2.e2 &&
+      small_two_stage_ok(lu, lf, st, box2))
+    return launch_small_two_stage(false, 0, lu, u_in, u_out, lf, rhs, st, w, 0, box2, nullptr, nullptr, (hipStream_t)stream);
   if (const int r27 = sf27_jacobi2_try(lu, u_in, u_out, lf, rhs, st, w, box1, box2, (hipStream_t)stream)) return r27 < 0 ? 1 : 0;
   if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2_boxes: fallback needs a distinct tmp array"); return 1; }
   const int reach = stencil_reach(st);
@@ -894,6 +910,10 @@ extern "C" int examg_jacobi2_prolong(const examg_layout_t *lu, const double *u_i
     pr.uc = uc;
     return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box, (hipStream_t)stream, nullptr, &pr);
   }
+  if (small_two_stage_ok(lu, lf, st, box)) {
+    if (!prolong_args_ok("examg_jacobi2_prolong", lc, box)) return 1;
+    return launch_small_two_stage(false, 1, lu, u_in, u_out, lf, rhs, st, w, 0, box, lc, uc, (hipStream_t)stream);
+  }
   if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2_prolong: fallback needs a distinct tmp array"); return 1; }
   const int reach = stencil_reach(st);
   int32_t b2[3], e2[3];
@@ -924,6 +944,7 @@ extern "C" int examg_jacobi2(const examg_layout_t *lu, const double *u_in, doubl
   const Box box = make_box(begin, end);
   if (box.count() == 0) return 0;
   if (two_stage_ok(lu, lf, st, box)) return launch_two_stage<false>(lu, u_in, lf, rhs, u_out, st, w, 0, box, (hipStream_t)stream);
+  if (small_two_stage_ok(lu, lf, st, box)) return launch_small_two_stage(false, 0, lu, u_in, u_out, lf, rhs, st, w, 0, box, nullptr, nullptr, (hipStream_t)stream);
   if (const int r27 = sf27_jacobi2_try(lu, u_in, u_out, lf, rhs, st, w, box, box, (hipStream_t)stream)) return r27 < 0 ? 1 : 0;
   if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi2: fallback needs a distinct tmp array"); return 1; }
   // the intermediate sweep needs the box's shell (Dirichlet / halo values) in tmp

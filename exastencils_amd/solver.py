@@ -364,7 +364,9 @@ class SolverFromL4(_Program):
             return False
         S = self.Solution[l]
         b, e = self.bounds(S)
-        if (e[0] - b[0]) * (e[1] - b[1]) * (e[2] - b[2]) < cfg.fused_prolong_min_points:
+        # the fold pays where the pass is bandwidth-bound and large (a read-modify-write loop less) and where the level is launch-bound
+        # (rows shorter than 64 points: one kernel less, csrc/kernels_small.hip); in between the separate correction is faster
+        if (e[0] - b[0]) * (e[1] - b[1]) * (e[2] - b[2]) < cfg.fused_prolong_min_points and (e[0] - b[0]) >= 64:
             return False
         # the kernel layer decides whether its one-pass kernel takes these arguments; without it the entry point runs the plain
         # loops on a copy, which costs more than the separate calls
@@ -788,7 +790,9 @@ class SolverFromL3(_Program):
             return False
         S = self.Solution[l]
         b, e = self.bounds(S)
-        if (e[0] - b[0]) * (e[1] - b[1]) * (e[2] - b[2]) < cfg.fused_prolong_min_points:
+        # the fold pays where the pass is bandwidth-bound and large (a read-modify-write loop less) and where the level is launch-bound
+        # (rows shorter than 64 points: one kernel less, csrc/kernels_small.hip); in between the separate correction is faster
+        if (e[0] - b[0]) * (e[1] - b[1]) * (e[2] - b[2]) < cfg.fused_prolong_min_points and (e[0] - b[0]) >= 64:
             return False
         return self._one_pass_sweep(l)
 

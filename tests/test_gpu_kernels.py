@@ -243,6 +243,95 @@ def test_two_stage_kernel_bit_exact(orc, two_stage_variant, kind, order, n, firs
     assert_same([hip.to_host(t) for t in g], c, "two-stage " + kind)
 
 
+SMALL_BOXES = [
+    ((64, 64, 64), None, None),                         # level 6 of config 3: 63-point rows, 16 x 16 tiles of 4 x 4 rows
+    ((32, 32, 32), None, None),                         # level 5
+    ((16, 16, 16), None, None),
+    ((8, 8, 8), None, None),
+    ((4, 4, 4), None, None),                            # 3 x 3 x 3 points: one partly filled tile
+    ((62, 30, 22), None, None),                         # ragged tiles in y and z
+    ((50, 21, 13), [0, 1, 0], [51, 21, 14]),            # interior faces: loop over duplicate planes, input halo in the ghost layer
+    ((40, 20, 20), [3, 2, 5], [38, 17, 18]),            # box inside the inner points, mixed parities
+]
+
+
+@pytest.mark.parametrize("order", ["mp", "pm"])
+@pytest.mark.parametrize("first", [0, 1])
+@pytest.mark.parametrize("shape,b,e", SMALL_BOXES)
+def test_small_level_sweep_bit_exact(hip, orc, shape, b, e, first, order):
+    """Rows shorter than 64 points (the launch-bound levels): examg_rbgs_sweep_fused runs k_small_rbgs -- both colour loops of a
+    sweep in one launch, staged through LDS (csrc/kernels_small.hip) -- and must leave in u_out, on the box, the bits of the two
+    colour loops run one after the other; u_out outside the box and u_in stay as they were."""
+    st = laplace_fd(3, tuple(1.0 / s for s in shape), order)
+    if b is None:
+        b, e = [1, 1, 1], list(shape)
+    assert hip.two_stage_eligible(FieldLayout.node(3, shape, 1).c_struct(), FieldLayout.node(3, shape, 0).c_struct(), st, b, e, b, e)
+    g = _two_stage_case(hip, "rbgs", shape, st, b, e, first)
+    hip.synchronize()
+    c = _two_stage_reference(orc, "rbgs", shape, st, b, e, first)
+    assert_same([hip.to_host(t) for t in g], c, "small-level sweep")
+
+
+@pytest.mark.parametrize("first", [0, 1])
+@pytest.mark.parametrize("shape,b,e", SMALL_BOXES[:6] + SMALL_BOXES[7:])
+def test_small_level_folded_forms_bit_exact(hip, orc, shape, b, e, first):
+    """The folded forms on the launch-bound levels: correction + sweep (examg_rbgs_sweep_fused_prolong) and the sweep of the zero field
+    (examg_rbgs_sweep_fused_zero) as ONE k_small_rbgs launch each, against the separate loops of the oracle; box values and everything
+    outside the box."""
+    st = laplace_fd(3, tuple(1.0 / s for s in shape))
+    if b is None:
+        b, e = [1, 1, 1], list(shape)
+    g = _prolong_fold_case(hip, True, "rbgs", shape, st, b, e, first)
+    hip.synchronize()
+    c = _prolong_fold_case(orc, False, "rbgs", shape, st, b, e, first)
+    assert_same([hip.to_host(t) for t in g], [orc.to_host(t) for t in c], "small-level correction + sweep")
+    lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0, True, False)
+    w = 0.8 / st.diag
+
+    def zero_case(ops, fused):
+        f, out = ops.new_array(lf.size), ops.new_array(lu.size)
+        ops.fill_random(f, 4711)
+        if fused:
+            ops.rbgs_sweep_fused_zero(lu.c_struct(), out, lf.c_struct(), f, st, w, first, b, e)
+        else:
+            for col in (first, 1 - first):
+                ops.stencil_op(SMOOTH, lu.c_struct(), out, lf.c_struct(), f, lu.c_struct(), out, st, w, col, b, e)
+        return [out]
+
+    g = zero_case(hip, True)
+    hip.synchronize()
+    assert_same([hip.to_host(t) for t in g], [orc.to_host(t) for t in zero_case(orc, False)], "small-level sweep of the zero field")
+
+
+@pytest.mark.parametrize("order", ["mp", "pm"])
+@pytest.mark.parametrize("shape,scale", [((64, 64, 64), 1.0), ((32, 32, 32), 1.0), ((16, 16, 16), 4.0), ((8, 8, 8), 1.0), ((60, 28, 20), 1.0)])
+def test_small_level_residual_restrict_bit_exact(hip, orc, shape, scale, order):
+    """Coarse rows shorter than 32 points: examg_residual_restrict runs k_small_residual_restrict (one coarse point per thread, the 27
+    residuals recomputed, none stored) -- the oracle's residual loop + restriction loop, bit for bit."""
+    st = laplace_fd(3, tuple(1.0 / s for s in shape), order)
+    cs = tuple(s // 2 for s in shape)
+    lu, lf, lc = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0, True, False), FieldLayout.node(3, cs, 0, True, False)
+    fb, fe, cb, ce = [1, 1, 1], list(shape), [1, 1, 1], list(cs)
+    import ctypes as C
+
+    from exastencils_amd.lib import ivec
+
+    sc = st.c_struct(hip.ptr)
+    assert hip.L.examg_residual_restrict_one_pass(C.byref(lu.c_struct()), C.byref(lf.c_struct()), C.byref(sc), C.byref(lc.c_struct()), ivec(fb), ivec(fe),
+                                                  ivec(cb), ivec(ce)) == 1
+
+    def f(ops):
+        u, fr, r, fc = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lc.size)
+        ops.fill_random(u, 21)
+        ops.fill_random(fr, 22)
+        ops.fill_random(fc, 23)
+        ops.residual_restrict(lu.c_struct(), u, lf.c_struct(), fr, lu.c_struct(), r, st, lc.c_struct(), fc, scale, fb, fe, cb, ce)
+        return [fc]
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "small-level residual + restriction")
+
+
 @pytest.mark.parametrize("kind", ["rbgs", "jacobi2"])
 def test_two_stage_interior_faces_anisotropic(orc, two_stage_variant, kind):
     """Block with neighbours on some faces: the loop includes the duplicate planes (begin 0 / end n+1), so the

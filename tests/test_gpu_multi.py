@@ -103,6 +103,8 @@ def _bench_hosted(n, per, extra, level=6):
     return json.load(open(outp))
 
 
+@pytest.mark.skipif(os.environ.get("EXAMG_HOSTED_RANKS") != "1",
+                    reason="several ranks per process (threads): opt-in, EXAMG_HOSTED_RANKS=1 (tools/gpu_rehearse_multi.sh)")
 @pytest.mark.parametrize("blocks", ["2,2,2", "1,2,4"])
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_eight_ranks_on_one_gpu(blocks, scaling):
