@@ -119,7 +119,10 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
         # (fixed) order, so iterates agree with the statement-by-statement run to rounding, not bit for bit.
         self.fuse_coarse_solver = fuse if fuse_coarse_solver is None else fuse_coarse_solver
         self._cg_plans: Dict[Tuple[str, int], object] = {}
-        self.fuse_min_row = 64      # rows shorter than one wavefront's tile stay on the per-colour kernels
+        # shortest row the one-pass forms are used on: the kernel layer has them for every row length (two-stage kernel from 64 points,
+        # csrc/kernels_small.hip below), blocks with neighbours keep 64 (interior + shell split)
+        self.fuse_min_row = 3
+        self.fuse_min_row_blocks = 64
         self._alt: Dict[Tuple[str, int, int], object] = {}
         self._alt_shell: Dict[Tuple[str, int, int], int] = {}
         self._bc_epoch: Dict[Tuple[str, int], int] = {}

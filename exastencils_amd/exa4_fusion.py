@@ -68,7 +68,7 @@ class LazyFusions:
             F, fs = self._field(r[0], fr)
             U, us = self._field(r[2], fr)
             A = r[1]
-            if U is D or F is D or not self._canonical7(A, self.nd) or D.layout.inner[0] < 32:
+            if U is D or F is D or not self._canonical7(A, self.nd) or D.layout.inner[0] < self.fuse_min_row:
                 return False
             self._pending = dict(kind="residual", D=D, ds=ds, U=U, us=us, F=F, fs=fs, A=A, b=b, e=e)
             return True
@@ -80,7 +80,10 @@ class LazyFusions:
             pts = 1
             for d in range(3):
                 pts *= max(1, e[d] - b[d])
-            if X.level != D.level - 1 or pts < self.fused_prolong_min_points or (D.bc_fn is not None and (D.name, D.level, ds) not in self._bc_valid):
+            # the fold pays on large levels (one read-modify-write pass less) and on launch-bound ones (rows shorter than 64 points: one
+            # kernel less); in between the separate correction is faster
+            if X.level != D.level - 1 or (pts < self.fused_prolong_min_points and D.layout.inner[0] >= 64) or \
+                    (D.bc_fn is not None and (D.name, D.level, ds) not in self._bc_valid):
                 return False
             self._pending = dict(kind="prolong", D=D, ds=ds, X=X, xs=xs, b=b, e=e)
             return True

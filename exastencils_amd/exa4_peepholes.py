@@ -64,7 +64,7 @@ class Peepholes:
         if m is None:
             return False
         D, ds, U, us, F, fs, A, w = m
-        if D is not U or ds != us or not self._canonical7(A, self.nd) or U.layout.inner[0] < self.fuse_min_row:
+        if D is not U or ds != us or not self._canonical7(A, self.nd) or U.layout.inner[0] < (self.fuse_min_row_blocks if multi else self.fuse_min_row):
             return False
         if only_field is not None and U is not only_field:
             return False        # a pending `u = 0` / `u += P * uc` rides along with the sweep of the same field only

@@ -691,7 +691,7 @@ def _worker(rank, world, port, out_dir):
     ops = OracleOps()
     dom = RectDomain(3, (2, 1, 1), rank, (1, 2, 2))
     P = example("poisson3d_rbgs.exa4", 1, 4, ops=ops, domain=dom, comm=Communicator(dom, ops))
-    P.fuse_min_row = 8          # red-black sweeps of the two finest levels as fused interior + shell (smoothers.rbgs_sweep)
+    P.fuse_min_row_blocks = 8   # red-black sweeps of the two finest levels as fused interior + shell (smoothers.rbgs_sweep)
     P.run()
     json.dump({"values": P.printed_values, "messages": P.comm.stats["messages"]}, open(os.path.join(out_dir, "r%d.json" % rank), "w"))
     dist.barrier()

@@ -72,7 +72,9 @@ def test_config3_512_history_vs_own_oracle(hip, fused):
     cfg = ConfigL4(**rec["config"], fused_rbgs=fused, fused_residual_restrict=fused, fused_prolong_min_points=10_000_000 if fused else 0, fused_zero_start=fused, fused_residual_norm=fused)
     P = SolverFromL4(cfg, hip)
     P.setup()
+    # folded where the pass is large (>= 10^7 points) and where the level is launch-bound (rows shorter than 64 points); not in between
     assert P._folds_prolongation(cfg.max_level) == fused and P._folds_prolongation(cfg.max_level - 1) == fused and not P._folds_prolongation(cfg.max_level - 2)
+    assert P._folds_prolongation(cfg.max_level - 3) == fused
     P.Solve()
     assert P.iterations == rec["iterations"]
     _check_history(P.res_history, rec["res"])

@@ -459,7 +459,8 @@ def test_fmg_driver_one_pass_forms_on_gpu(hip):
         P.Solve()
         runs[name] = (P.iterations, P.res_history, hip.to_host(P.Solution[8].data()).copy(), P)
     P = runs["all"][3]
-    assert P._folds_prolongation(8) and P._folds_prolongation(7) and P._starts_from_zero(7) and not P._starts_from_zero(6)      # 64^3 has rows of 63 points
+    # every level above the coarsest: the two-stage kernel from 64-point rows, the small-level kernel (csrc/kernels_small.hip) below
+    assert P._folds_prolongation(8) and P._folds_prolongation(7) and P._starts_from_zero(7) and P._starts_from_zero(6) and P._folds_prolongation(4)
     assert runs["fold_zero"][1] == runs["sweeps"][1] and np.array_equal(runs["fold_zero"][2], runs["sweeps"][2])
     O = mg.ProgramB(mg.ConfigB(**kw))
     O.setup()
@@ -494,7 +495,7 @@ def test_folded_prolongation_changes_no_bit(hip):
         hist.append(P.res_history)
         sols.append(hip.to_host(P.Solution[8].data()).copy())
         folds.append([P._folds_prolongation(l) for l in range(3, 9)])
-    assert folds == [[False] * 6, [False, False, False, False, True, True]]       # 128^3 has rows of 127 points, 64^3 of 63
+    assert folds == [[False] * 6, [True] * 6]       # rows of 64 points and more: the two-stage kernel; shorter rows: the small-level kernel
     assert hist[0] == hist[1] and len(hist[0]) > 4
     assert np.array_equal(sols[0].view(np.uint64), sols[1].view(np.uint64))
     from exastencils_amd.solver import ConfigL3, SolverFromL3
@@ -505,7 +506,7 @@ def test_folded_prolongation_changes_no_bit(hip):
                                   fused_prolong_min_points=min_points), hip)
         P.setup()
         P.Solve()
-        assert P._folds_prolongation(7) == bool(min_points) and not P._folds_prolongation(6)
+        assert P._folds_prolongation(7) == bool(min_points) and P._folds_prolongation(6) == bool(min_points)
         hist.append(P.res_history)
         S = P.Solution[7]
         sols.append(hip.to_host(S.data(S.active)).copy())
