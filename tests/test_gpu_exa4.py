@@ -36,7 +36,7 @@ def test_rbgs_program_on_gpu(hip):
     P.run()
     O = _oracle_a(2, 7)
     _close(P.printed_values, O.res_history, O.res_history[0])   # norms: the device reduction tree sums in another order
-    assert P.launches > 300
+    assert P.launches > 100                                      # every launch a kernel-layer call (6 cycles of ~40 launches)
     plain = example("poisson3d_rbgs.exa4", 2, 7, ops=hip, fuse=False)
     plain.run()
     assert plain.printed_values == P.printed_values              # fused sweeps / cross-statement fusions change no bit
