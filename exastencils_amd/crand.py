@@ -43,7 +43,7 @@ def fill_boxes(ops, targets: Sequence[Tuple[object, Optional[int]]], fills: List
     """targets: (field, slot) per statement of the loop body, in statement order (same layout); fills: (generator, begin, end)
     boxes in the order they are to be written.  Every point draws len(targets) values in a row."""
     lay = targets[0][0].layout
-    hosts = [np.ascontiguousarray(ops.to_host(f.data(s)), dtype=np.float64).copy().reshape(lay.shape_zyx) for f, s in targets]
+    hosts = [np.ascontiguousarray(f.host_array(ops, s), dtype=np.float64).copy() for f, s in targets]
     k = len(targets)
     for gen, b, e in fills:
         n = [max(0, e[d] - b[d]) for d in range(3)]
@@ -54,7 +54,7 @@ def fill_boxes(ops, targets: Sequence[Tuple[object, Optional[int]]], fills: List
         for j in range(k):
             hosts[j][sl] = vals[..., j]
     for (f, s), h in zip(targets, hosts):
-        f.data(s).copy_(ops.from_host(h.reshape(-1)))
+        f.set_host_array(ops, h, s)
 
 
 def random_start(ops, field, slot: Optional[int], domain: RectDomain, former_processes: Optional[Sequence[int]] = None,

@@ -13,14 +13,17 @@ namespace examg {
 struct LayoutDev {
   int tot0, tot1, tot2;
   int ref0, ref1, ref2;
-  long long s1, s2;    // strides of dim 1, dim 2 (dim 0 stride = 1)
+  long long s1, s2;    // strides of dim 1, dim 2 (dim 0 stride = 1); under the colour split: strides within a half array
   long long size;      // doubles per (scalar) field
-  long long origin;    // linear index of iterator (0,0,0)
+  long long origin;    // linear index of iterator (0,0,0) (plain layouts)
+  long long half;      // colour split (EXAMG_LAYOUT_SPLIT_X): doubles per half array, 0 for a plain layout
 };
 
 static inline int lay_tot(const examg_layout_t *l, int d) {
   return l->pad_l[d] + l->ghost_l[d] + l->dup_l[d] + l->inner[d] + l->dup_r[d] + l->ghost_r[d] + l->pad_r[d];
 }
+
+static inline bool lay_split(const examg_layout_t *l) { return l->transform == EXAMG_LAYOUT_SPLIT_X; }
 
 static inline LayoutDev make_layout(const examg_layout_t *l) {
   LayoutDev d;
@@ -30,14 +33,29 @@ static inline LayoutDev make_layout(const examg_layout_t *l) {
   d.ref0 = l->pad_l[0] + l->ghost_l[0];
   d.ref1 = l->pad_l[1] + l->ghost_l[1];
   d.ref2 = l->pad_l[2] + l->ghost_l[2];
+  if (lay_split(l)) {
+    // [x, y, z] => [x / 2, y, z, x % 2] on array indices (layoutTransformation/ir/IR_LayoutTransformStatement.scala): extents
+    // ceil(TOTx / 2), TOTy, TOTz, 2 -- first index fastest
+    d.s1 = (d.tot0 + 1) / 2;
+    d.s2 = d.s1 * d.tot1;
+    d.half = d.s2 * d.tot2;
+    d.size = 2 * d.half;
+    d.origin = 0;
+    return d;
+  }
   d.s1 = d.tot0;
   d.s2 = (long long)d.tot0 * d.tot1;
   d.size = d.s2 * d.tot2;
   d.origin = d.ref0 + d.s1 * d.ref1 + d.s2 * d.ref2;
+  d.half = 0;
   return d;
 }
 
 __host__ __device__ static inline long long lidx(const LayoutDev &l, int i0, int i1, int i2) {
+  if (l.half) {
+    const int ax = i0 + l.ref0;
+    return (ax >> 1) + l.s1 * (i1 + l.ref1) + l.s2 * (i2 + l.ref2) + (long long)(ax & 1) * l.half;
+  }
   return l.origin + i0 + l.s1 * i1 + l.s2 * i2;
 }
 

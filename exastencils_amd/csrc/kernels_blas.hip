@@ -400,7 +400,7 @@ extern "C" int examg_dot(const examg_layout_t *lx_, const double *x, const examg
   if (box.count() == 0) return check_hip(hipMemsetAsync(result, 0, sizeof(double), s), "examg_dot memset");
   if (!box_inside(lx_, box, 0) || !box_inside(ly_, box, 0)) { set_error("examg_dot: box leaves an allocation"); return 1; }
   const int nb = red_blocks(box.count());
-  if (box.n0() >= 128)
+  if (box.n0() >= 128 && !lay_split(lx_) && !lay_split(ly_))
     hipLaunchKernelGGL(k_dot_rows, dim3(nb), dim3(RED_BLOCK), 0, s, make_layout(lx_), x, make_layout(ly_), y, box, (double *)work);
   else
     hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(RED_BLOCK), 0, s, make_layout(lx_), x, make_layout(ly_), y, box, (double *)work);
@@ -582,6 +582,23 @@ static int external_box(const examg_layout_t *li, const examg_layout_t *le, int3
   }
   return 0;
 }
+
+// The same field under another layout transformation: a copy over the whole allocation, every point through both index maps.
+extern "C" int examg_transform_field(const examg_layout_t *lsrc, const double *src, const examg_layout_t *ldst, double *dst, examg_stream_t stream) {
+  if (!lsrc || !src || !ldst || !dst) { set_error("examg_transform_field: null argument"); return 1; }
+  if (src == dst) { set_error("examg_transform_field: out of place only"); return 1; }
+  examg_layout_t a = *lsrc, b = *ldst;
+  a.transform = b.transform = EXAMG_LAYOUT_PLAIN;
+  if (memcmp(&a, &b, sizeof(a)) != 0) { set_error("examg_transform_field: the two layouts must differ in their transformation only"); return 1; }
+  int32_t begin[3], end[3];
+  for (int d = 0; d < 3; ++d) {
+    begin[d] = -(lsrc->pad_l[d] + lsrc->ghost_l[d]);
+    end[d] = begin[d] + lay_tot(lsrc, d);
+  }
+  return examg_axpby(lsrc, src, ldst, dst, 1.0, 0.0, begin, end, stream);
+}
+
+extern "C" int64_t examg_layout_size(const examg_layout_t *l) { return l ? (int64_t)make_layout(l).size : 0; }
 
 extern "C" int examg_copy_to_external(const examg_layout_t *l_int, const double *x_int, const examg_layout_t *l_ext,
                                       double *dest, examg_stream_t stream) {

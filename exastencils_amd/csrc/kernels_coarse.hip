@@ -338,6 +338,10 @@ extern "C" int examg_cg_coarse_variant(const examg_layout_t *lu_, double *sol, c
     return 1;
   }
   if (flags & ~(EXAMG_CG_ALPHA_FROM_NORM | EXAMG_CG_NO_BC)) { set_error("examg_cg_coarse_variant: unknown flag"); return 1; }
+  if (lay_split(lu_) || lay_split(lf_) || lay_split(lr_) || lay_split(lp_) || lay_split(lq_)) {
+    set_error("examg_cg_coarse: fields under a layout transformation are not supported by the one-kernel solver (examg_transform_field)");
+    return 1;
+  }
   const uint32_t all = (1u << (2 * lu_->nd)) - 1;
   if ((face_mask & all) != all) {
     set_error("examg_cg_coarse: fused coarse solve needs every face on the physical boundary (single fragment)");

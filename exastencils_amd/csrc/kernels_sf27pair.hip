@@ -188,7 +188,7 @@ k_sf27_two_stage(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
 
 // Can the pair kernel take these arguments?  (entry order, layouts, weight form, boxes)
 static bool sf27_pair_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box1, const Box &box2) {
-  if (g_s27_disable || !st->cfield || st->nent != 27 || st->diag != 0 || st->ctransform != EXAMG_CLAYOUT_ENTRY_FASTEST ||
+  if (g_s27_disable || lay_split(lu) || lay_split(lf) || !st->cfield || st->nent != 27 || st->diag != 0 || st->ctransform != EXAMG_CLAYOUT_ENTRY_FASTEST ||
       st->wform != EXAMG_WEIGHT_INV_TIMES || lu->nd != 3)
     return false;
   for (int k = 0; k < 27; ++k)

@@ -20,7 +20,7 @@
 
 namespace examg {
 
-constexpr int SM_THREADS = 256;
+constexpr int SM_THREADS = 1024;    // 16 waves: a wave owns whole rows of the tile
 constexpr int SM_SY = 4, SM_SZ = 4;      // output rows of a workgroup; staged: (SY + 4) x (SZ + 4) rows of n0 + 2 points
 constexpr int SM_MAX_ENT = 7;
 
@@ -74,120 +74,149 @@ __device__ __forceinline__ double small_prolong(const LayoutDev &lc, const doubl
 }
 
 // COL: the two colour loops of a red-black sweep (else two Jacobi steps).  VAR 0: plain; 1: correction folded in; 2: zero input (COL)
+// Launch-bound work: what counts is the length of the dependent chain, not the bytes.  16 waves per workgroup; a wave owns whole rows of
+// the tile (lane = x, no index divisions) and issues all loads of its rows before the first use; the right-hand sides of both loops are
+// in flight from the start.
 template <bool COL, int VAR>
 __global__ void __launch_bounds__(SM_THREADS)
 k_small_two_stage(LayoutDev lu, const double *__restrict__ u_in, double *__restrict__ u_out, LayoutDev lf, const double *__restrict__ rhs,
                   SmallStencil st, double w, Box box, int first, int tiles_y, LayoutDev lc, const double *__restrict__ uc) {
   extern __shared__ double T[];
   const int n0 = box.n0(), LX = n0 + 2;
-  constexpr int RY = SM_SY + 4, RZ = SM_SZ + 4;
-  double *T2 = T + LX * RY * RZ;                                      // Jacobi: the first step's values (same indexing as T)
+  constexpr int RY = SM_SY + 4, RZ = SM_SZ + 4, NW = SM_THREADS / 64;
+  constexpr int ROWS0 = RY * RZ, ROWS1 = (SM_SY + 2) * (SM_SZ + 2), ROWS2 = SM_SY * SM_SZ;
+  double *T2 = T + LX * ROWS0;                                        // Jacobi: the first step's values (same indexing as T)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ty = blockIdx.x % tiles_y, tz = blockIdx.x / tiles_y;
   const int oy = box.b1 + ty * SM_SY, oz = box.b2 + tz * SM_SZ;       // first output row of this workgroup
   const int x0 = box.b0 - 1, y0 = oy - 2, z0 = oz - 2;               // iterator coordinates of T[0]
-  // ---- stage 0: the input tile (VAR 1: with the correction on the points of the box) --------------------------------------------
-  for (int t = threadIdx.x; t < LX * RY * RZ; t += SM_THREADS) {
-    const int xl = t % LX, r = t / LX, yl = r % RY, zl = r / RY;
-    const int x = x0 + xl, y = y0 + yl, z = z0 + zl;
-    double v = 0.0;
-    if (VAR != 2) {
+  // ---- stage 0: the input tile (VAR 1: with the correction on the points of the box); rows r = wv, wv + NW, .. ---------------------
+  {
+    constexpr int NR = (ROWS0 + NW - 1) / NW;
+    double v[NR][2];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int r = wv + j * NW;
+      const int y = y0 + r % RY, z = z0 + r / RY;
       // rows beyond the box's one-point shell are never read (a row outside the box is not updated, so its neighbours are not needed)
-      const bool need = y >= box.b1 - 1 && y <= box.e1 && z >= box.b2 - 1 && z <= box.e2;
-      if (need) {
-        v = u_in[lidx(lu, x, y, z)];
-        if (VAR == 1 && x >= box.b0 && x < box.e0 && y >= box.b1 && y < box.e1 && z >= box.b2 && z < box.e2) v = v + small_prolong(lc, uc, x, y, z);
+      const bool need = VAR != 2 && r < ROWS0 && y >= box.b1 - 1 && y <= box.e1 && z >= box.b2 - 1 && z <= box.e2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int xl = lane + 64 * h;
+        double val = 0.0;
+        if (need && xl < LX) {
+          const int x = x0 + xl;
+          val = u_in[lidx(lu, x, y, z)];
+          if (VAR == 1 && x >= box.b0 && x < box.e0 && y >= box.b1 && y < box.e1 && z >= box.b2 && z < box.e2) val = val + small_prolong(lc, uc, x, y, z);
+        }
+        v[j][h] = val;
       }
     }
-    T[t] = v;
-    if (!COL) T2[t] = v;                                               // points the first step does not update keep the input value
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int r = wv + j * NW;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int xl = lane + 64 * h;
+        if (r < ROWS0 && xl < LX) {
+          T[r * LX + xl] = v[j][h];
+          if (!COL) T2[r * LX + xl] = v[j][h];                         // points the first step does not update keep the input value
+        }
+      }
+    }
   }
   __syncthreads();
   if (COL) {
-    // ---- colour `first` on the tile grown by one row, then the other colour on the tile: in place (a star reads the other colour) -----
-    const int row_w = (n0 + 1) / 2;
+    // ---- colour `first` on the tile grown by one row, then the other colour on the tile: in place (a star reads the other colour).
+    //      Half a wave per row: lanes 0..31 / 32..63 take the points of the colour in two consecutive rows of the stage. ------------
+    const int hl = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int stage = 0; stage < 2; ++stage) {
       const int colour = stage == 0 ? first : 1 - first;
       const int g = stage == 0 ? 1 : 0;                                // rows beyond the tile on each side
-      const int ny = SM_SY + 2 * g, nz = SM_SZ + 2 * g;
-      for (int t = threadIdx.x; t < ny * nz * row_w; t += SM_THREADS) {
-        const int c0 = t % row_w, r = t / row_w;
+      const int ny = SM_SY + 2 * g, nrows = stage == 0 ? ROWS1 : ROWS2;
+      for (int r = 2 * wv + hh; r < nrows; r += 2 * NW) {
         const int y = oy - g + r % ny, z = oz - g + r / ny;
         if (y < box.b1 || y >= box.e1 || z < box.b2 || z >= box.e2) continue;
-        const int x = box.b0 + (((box.b0 + y + z) & 1) != colour ? 1 : 0) + 2 * c0;
-        if (x >= box.e0) continue;
-        const int it = (x - x0) + LX * ((y - y0) + RY * (z - z0));
-        double acc = st.coef[0] * T[it + st.lo[0]];
-        for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * T[it + st.lo[k]];
-        T[it] = T[it] + w * (rhs[lidx(lf, x, y, z)] - acc);
+        const int xf = box.b0 + (((box.b0 + y + z) & 1) != colour ? 1 : 0);
+        for (int x = xf + 2 * hl; x < box.e0; x += 64) {
+          const int it = (x - x0) + LX * ((y - y0) + RY * (z - z0));
+          const double f = rhs[lidx(lf, x, y, z)];
+          double acc = st.coef[0] * T[it + st.lo[0]];
+          for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * T[it + st.lo[k]];
+          T[it] = T[it] + w * (f - acc);
+        }
       }
       __syncthreads();
     }
   } else {
     // ---- first Jacobi step on the tile grown by one row: T -> T2; second step on the tile: T2 -> T ------------------------------------
-    for (int t = threadIdx.x; t < (SM_SY + 2) * (SM_SZ + 2) * n0; t += SM_THREADS) {
-      const int xl = t % n0, r = t / n0;
-      const int x = box.b0 + xl, y = oy - 1 + r % (SM_SY + 2), z = oz - 1 + r / (SM_SY + 2);
+    for (int r = wv; r < ROWS1; r += NW) {
+      const int y = oy - 1 + r % (SM_SY + 2), z = oz - 1 + r / (SM_SY + 2);
       if (y < box.b1 || y >= box.e1 || z < box.b2 || z >= box.e2) continue;
-      const int it = (x - x0) + LX * ((y - y0) + RY * (z - z0));
-      double acc = st.coef[0] * T[it + st.lo[0]];
-      for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * T[it + st.lo[k]];
-      T2[it] = T[it] + w * (rhs[lidx(lf, x, y, z)] - acc);
+      for (int x = box.b0 + lane; x < box.e0; x += 64) {
+        const int it = (x - x0) + LX * ((y - y0) + RY * (z - z0));
+        const double f = rhs[lidx(lf, x, y, z)];
+        double acc = st.coef[0] * T[it + st.lo[0]];
+        for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * T[it + st.lo[k]];
+        T2[it] = T[it] + w * (f - acc);
+      }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < SM_SY * SM_SZ * n0; t += SM_THREADS) {
-      const int xl = t % n0, r = t / n0;
-      const int x = box.b0 + xl, y = oy + r % SM_SY, z = oz + r / SM_SY;
+    for (int r = wv; r < ROWS2; r += NW) {
+      const int y = oy + r % SM_SY, z = oz + r / SM_SY;
       if (y >= box.e1 || z >= box.e2) continue;
-      const int it = (x - x0) + LX * ((y - y0) + RY * (z - z0));
-      double acc = st.coef[0] * T2[it + st.lo[0]];
-      for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * T2[it + st.lo[k]];
-      T[it] = T2[it] + w * (rhs[lidx(lf, x, y, z)] - acc);
+      for (int x = box.b0 + lane; x < box.e0; x += 64) {
+        const int it = (x - x0) + LX * ((y - y0) + RY * (z - z0));
+        const double f = rhs[lidx(lf, x, y, z)];
+        double acc = st.coef[0] * T2[it + st.lo[0]];
+        for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * T2[it + st.lo[k]];
+        T[it] = T2[it] + w * (f - acc);
+      }
     }
     __syncthreads();
   }
   // ---- the tile's rows, box points only ---------------------------------------------------------------------------------------------
-  for (int t = threadIdx.x; t < SM_SY * SM_SZ * n0; t += SM_THREADS) {
-    const int xl = t % n0, r = t / n0;
+  for (int r = wv; r < ROWS2; r += NW) {
     const int y = oy + r % SM_SY, z = oz + r / SM_SY;
     if (y >= box.e1 || z >= box.e2) continue;
-    const int x = box.b0 + xl;
-    u_out[lidx(lu, x, y, z)] = T[(x - x0) + LX * ((y - y0) + RY * (z - z0))];
+    for (int x = box.b0 + lane; x < box.e0; x += 64) u_out[lidx(lu, x, y, z)] = T[(x - x0) + LX * ((y - y0) + RY * (z - z0))];
   }
 }
 
-// RHS@coarser = scale * R * (RHS - A * Solution): one coarse point per thread (k_stencil_generic<EXAMG_RESIDUAL> + k_restrict<3>)
-__global__ void __launch_bounds__(SM_THREADS)
+// RHS@coarser = scale * R * (RHS - A * Solution) (k_stencil_generic<EXAMG_RESIDUAL> + k_restrict<3>): 32 lanes per coarse point -- lane
+// j < 27 forms the residual of fine point j (x offset outermost, then y, then z: k_restrict's order) and its weighted term, all 27 in
+// flight at once; the terms are then added in that order (every lane of the group folds the same sequence, lane 0 stores).
+__global__ void __launch_bounds__(256)
 k_small_residual_restrict(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev lc,
                           double *__restrict__ fc, SmallStencil st, double scale, Box cb) {
   const long long total = cb.count();
   const int n0 = cb.n0(), n1 = cb.n1();
-  for (long long t = (long long)blockIdx.x * SM_THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * SM_THREADS) {
-    const int I0 = cb.b0 + (int)(t % n0);
-    const long long row = t / n0;
-    const int I1 = cb.b1 + (int)(row % n1);
-    const int I2 = cb.b2 + (int)(row / n1);
+  const int j = threadIdx.x & 31;
+  const long long t = ((long long)blockIdx.x * 256 + threadIdx.x) >> 5;       // coarse point of this half wave
+  const bool live = t < total;
+  const long long tt = live ? t : 0;
+  const int I0 = cb.b0 + (int)(tt % n0);
+  const long long row = tt / n0;
+  const int I1 = cb.b1 + (int)(row % n1);
+  const int I2 = cb.b2 + (int)(row / n1);
+  double tv = 0.0;
+  if (j < 27) {
+    const int a = j / 9 - 1, b = (j / 3) % 3 - 1, c = j % 3 - 1;
     const double w1[3] = {0.25, 0.5, 0.25};
-    double acc = 0.0;
-    bool first = true;
-#pragma unroll
-    for (int a = -1; a <= 1; ++a)
-#pragma unroll
-      for (int b = -1; b <= 1; ++b)
-#pragma unroll
-        for (int c = -1; c <= 1; ++c) {
-          const int i0 = 2 * I0 + a, i1 = 2 * I1 + b, i2 = 2 * I2 + c;
-          const long long iu = lidx(lu, i0, i1, i2);
-          double r = st.coef[0] * u[iu + st.uo[0]];
-          for (int k = 1; k < st.nent; ++k) r = r + st.coef[k] * u[iu + st.uo[k]];
-          r = rhs[lidx(lf, i0, i1, i2)] - r;
-          const double wgt = scale * ((w1[a + 1] * w1[b + 1]) * w1[c + 1]);
-          const double tv = wgt * r;
-          acc = first ? tv : acc + tv;
-          first = false;
-        }
-    fc[lidx(lc, I0, I1, I2)] = acc;
+    const int i0 = 2 * I0 + a, i1 = 2 * I1 + b, i2 = 2 * I2 + c;
+    const long long iu = lidx(lu, i0, i1, i2);
+    double r = st.coef[0] * u[iu + st.uo[0]];
+    for (int k = 1; k < st.nent; ++k) r = r + st.coef[k] * u[iu + st.uo[k]];
+    r = rhs[lidx(lf, i0, i1, i2)] - r;
+    const double wgt = scale * ((w1[a + 1] * w1[b + 1]) * w1[c + 1]);
+    tv = wgt * r;
   }
+  const int base = threadIdx.x & 32;          // first lane of this group within its wave
+  double acc = __shfl(tv, base);
+#pragma unroll
+  for (int k = 1; k < 27; ++k) acc = acc + __shfl(tv, base + k);
+  if (live && j == 0) fc[lidx(lc, I0, I1, I2)] = acc;
 }
 
 static thread_local int g_small_disable = 0;      // examg_debug_small(1): the plain loops instead (A/B and parity tests)
@@ -206,7 +235,7 @@ static SmallStencil small_stencil(const examg_stencil_t *st, const LayoutDev &lu
 // ---- dispatch hooks of the entry points in kernels_twostage.hip / kernels_transfer.hip ---------------------------------------------
 // Does the small-level pass take these arguments?  (rows shorter than the two-stage kernel's 64 points)
 bool small_two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
-  return !g_small_disable && lu->nd == 3 && lf->nd == 3 && small_star(st) && box.n0() >= 2 && box.n0() < 64 && box.n1() >= 1 && box.n2() >= 1 &&
+  return !g_small_disable && !lay_split(lu) && !lay_split(lf) && lu->nd == 3 && lf->nd == 3 && small_star(st) && box.n0() >= 2 && box.n0() < 64 && box.n1() >= 1 && box.n2() >= 1 &&
          box_inside(lu, box, 1) && box_inside(lf, box, 0);
 }
 
@@ -247,7 +276,7 @@ int launch_small_two_stage(bool col, int var, const examg_layout_t *lu_, const d
 // coarse rows shorter than the wide kernel's 32 points
 bool small_residual_restrict_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const examg_layout_t *lc, const Box &fb,
                                 const Box &cb) {
-  if (g_small_disable || lu->nd != 3 || lf->nd != 3 || lc->nd != 3 || !small_star(st) || cb.count() == 0 || cb.n0() >= 32) return false;
+  if (g_small_disable || lay_split(lu) || lay_split(lf) || lay_split(lc) || lu->nd != 3 || lf->nd != 3 || lc->nd != 3 || !small_star(st) || cb.count() == 0 || cb.n0() >= 32) return false;
   const bool inside = 2 * cb.b0 - 1 >= fb.b0 && 2 * (cb.e0 - 1) + 1 < fb.e0 && 2 * cb.b1 - 1 >= fb.b1 && 2 * (cb.e1 - 1) + 1 < fb.e1 &&
                       2 * cb.b2 - 1 >= fb.b2 && 2 * (cb.e2 - 1) + 1 < fb.e2;
   return inside && box_inside(lu, fb, 1) && box_inside(lf, fb, 0) && box_inside(lc, cb, 0);
@@ -257,8 +286,8 @@ int launch_small_residual_restrict(const examg_layout_t *lu_, const double *u, c
                                    double *fc, const examg_stencil_t *st, double scale, const Box &cb, hipStream_t s) {
   const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_), lc = make_layout(lc_);
   const SmallStencil ss = small_stencil(st, lu, 0, 0);
-  const long long nb = (cb.count() + SM_THREADS - 1) / SM_THREADS;
-  hipLaunchKernelGGL(k_small_residual_restrict, dim3((unsigned)nb), dim3(SM_THREADS), 0, s, lu, u, lf, rhs, lc, fc, ss, scale, cb);
+  const long long nb = (cb.count() * 32 + 255) / 256;       // 32 lanes per coarse point
+  hipLaunchKernelGGL(k_small_residual_restrict, dim3((unsigned)nb), dim3(256), 0, s, lu, u, lf, rhs, lc, fc, ss, scale, cb);
   EXAMG_CHECK_LAUNCH("k_small_residual_restrict");
   return 0;
 }

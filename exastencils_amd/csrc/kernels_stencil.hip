@@ -23,6 +23,7 @@ struct StencilDev {
   long long cplane;  // stride between the entries of a point: doubles per coefficient plane, or 1 under the entry-fastest transformation
   long long cpt;     // stride between points: 1, or nent under the entry-fastest transformation
   int wdiv;          // smoother weight of a stencil field: 0 (1.0 / diag) * w, 1 w / diag (EXAMG_WEIGHT_*)
+  signed char o[EXAMG_MAX_ENTRIES][3];   // entry offsets per dimension: u under a layout transformation has no linear entry offsets
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -50,7 +51,24 @@ k_stencil_generic(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
     if (i0 >= box.e0) continue;
     const long long iu = lidx(lu, i0, i1, i2);
     double acc;
-    if (st.cfield) {
+    if (lu.half) {
+      // u under the colour split (EXAMG_LAYOUT_SPLIT_X): every neighbour through the transformed index -- the points of one colour of a
+      // row, and their x neighbours in the other half array, are contiguous across the lanes.  Same products, same order.
+      if (st.cfield) {
+        const long long ic = lidx(lc, i0, i1, i2) * st.cpt;
+        acc = st.cfield[ic] * u[lidx(lu, i0 + st.o[0][0], i1 + st.o[0][1], i2 + st.o[0][2])];
+        for (int k = 1; k < st.nent; ++k) acc = acc + st.cfield[ic + k * st.cplane] * u[lidx(lu, i0 + st.o[k][0], i1 + st.o[k][1], i2 + st.o[k][2])];
+        if (MODE == EXAMG_SMOOTH) {
+          const double dg = st.cfield[ic + st.diag * st.cplane];
+          const double ww = st.wdiv ? w / dg : (1.0 / dg) * w;
+          acc = u[iu] + ww * (rhs[lidx(lf, i0, i1, i2)] - acc);
+        }
+      } else {
+        acc = st.coef[0] * u[lidx(lu, i0 + st.o[0][0], i1 + st.o[0][1], i2 + st.o[0][2])];
+        for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * u[lidx(lu, i0 + st.o[k][0], i1 + st.o[k][1], i2 + st.o[k][2])];
+        if (MODE == EXAMG_SMOOTH) acc = u[iu] + w * (rhs[lidx(lf, i0, i1, i2)] - acc);
+      }
+    } else if (st.cfield) {
       const long long ic = lidx(lc, i0, i1, i2) * st.cpt;
       acc = st.cfield[ic] * u[iu + st.uo[0]];
       for (int k = 1; k < st.nent; ++k) acc = acc + st.cfield[ic + k * st.cplane] * u[iu + st.uo[k]];
@@ -781,9 +799,14 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   const LayoutDev lf = lf_ ? make_layout(lf_) : lu;
   hipStream_t s = (hipStream_t)stream;
 
+  // a field under a layout transformation (colour split): the generic kernel, which forms every address through the transformed
+  // index; the coefficient field of a stencil field has its own transformation (ctransform) and a plain clayout
+  const bool transformed = lay_split(lu_) || lay_split(ld_) || (lf_ && lay_split(lf_));
+  if (st->cfield && lay_split(&st->clayout)) { set_error("examg_stencil_op: the coefficient layout of a stencil field cannot be colour-split"); return 1; }
+  const bool force_generic = g_force_generic || transformed;
   const int ord = canonical_order7(st);
   const bool colour_ok = colour < 0 || (mode == EXAMG_SMOOTH && u == dst && memcmp(lu_, ld_, sizeof(*lu_)) == 0);
-  if (!g_force_generic && lu_->nd == 3 && ord >= 0 && colour_ok && box.n0() >= 64) {
+  if (!force_generic && lu_->nd == 3 && ord >= 0 && colour_ok && box.n0() >= 64) {
     Coef7 k;
     for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
 #define EXAMG_ZM(M, O) launch_zmarch<M, O>(lu, u, lf, rhs, ld, dst, k, w, box, s, colour)
@@ -801,12 +824,12 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
     return 0;
   }
 
-  if (!g_force_generic && stencilfield7_ok(lu_, st, box, colour)) {
+  if (!force_generic && stencilfield7_ok(lu_, st, box, colour)) {
     const LayoutDev lcf = make_layout(&st->clayout);
     return launch_stencilfield7(mode, lu, u, lf, rhs, ld, dst, lcf, st->cfield, w, box, s);
   }
 
-  if (!g_force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
+  if (!force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
       st->off[0][1] == 0 && st->off[0][2] == 0 && st->ctransform == EXAMG_CLAYOUT_ENTRY_FASTEST && lu_->nd == 3 &&
       (mode != EXAMG_SMOOTH || st->wform == EXAMG_WEIGHT_INV_TIMES) &&
       // the 16-byte loads of the record stream are clamped to the allocation; a pair that starts on the very last double of the
@@ -831,7 +854,7 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
     return 0;
   }
 
-  if (!g_force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
+  if (!force_generic && g_sf27_unrolled && st->cfield && st->nent == 27 && colour < 0 && st->diag == 0 && st->off[0][0] == 0 &&
       st->off[0][1] == 0 && st->off[0][2] == 0 && st->ctransform == EXAMG_CLAYOUT_PLANES &&
       (mode != EXAMG_SMOOTH || st->wform == EXAMG_WEIGHT_INV_TIMES)) {
     const LayoutDev lc27 = make_layout(&st->clayout);
@@ -855,6 +878,7 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   for (int k = 0; k < st->nent; ++k) {
     sd.uo[k] = st->off[k][0] + lu.s1 * st->off[k][1] + lu.s2 * st->off[k][2];
     sd.coef[k] = st->coef[k];
+    for (int d = 0; d < 3; ++d) sd.o[k][d] = (signed char)st->off[k][d];
   }
   sd.cfield = st->cfield;
   LayoutDev lc = lu;
@@ -890,7 +914,7 @@ extern "C" int examg_residual_norm2(const examg_layout_t *lu_, const double *u, 
   hipStream_t s = (hipStream_t)stream;
   if (box.count() == 0) return check_hip(hipMemsetAsync(result, 0, sizeof(double), s), "examg_residual_norm2 memset");
   const int ord = canonical_order7(st);
-  if (!g_force_generic && lu_->nd == 3 && ord >= 0 && box.n0() >= 64 && box_inside(lu_, box, 1) && box_inside(lf_, box, 0)) {
+  if (!g_force_generic && !lay_split(lu_) && !lay_split(lf_) && lu_->nd == 3 && ord >= 0 && box.n0() >= 64 && box_inside(lu_, box, 1) && box_inside(lf_, box, 0)) {
     const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
     Coef7 k;
     for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];

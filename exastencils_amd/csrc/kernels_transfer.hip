@@ -32,14 +32,14 @@ k_restrict(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, double 
       for (int b = -1; b <= 1; ++b) {
         if (ND == 2) {
           const double wgt = scale * (w1[a + 1] * w1[b + 1]);
-          const double tv = wgt * rf[base + a + lfine.s1 * b];
+          const double tv = wgt * rf[lfine.half ? lidx(lfine, 2 * I0 + a, 2 * I1 + b, 0) : base + a + lfine.s1 * b];
           acc = first ? tv : acc + tv;
           first = false;
         } else {
 #pragma unroll
           for (int c = -1; c <= 1; ++c) {
             const double wgt = scale * ((w1[a + 1] * w1[b + 1]) * w1[c + 1]);
-            const double tv = wgt * rf[base + a + lfine.s1 * b + lfine.s2 * c];
+            const double tv = wgt * rf[lfine.half ? lidx(lfine, 2 * I0 + a, 2 * I1 + b, 2 * I2 + c) : base + a + lfine.s1 * b + lfine.s2 * c];
             acc = first ? tv : acc + tv;
             first = false;
           }
@@ -411,7 +411,8 @@ extern "C" int examg_restrict(const examg_layout_t *lfine_, const double *rf, co
   if (!box_inside(lfine_, fb, 1)) { set_error("examg_restrict: fine footprint leaves the fine allocation"); return 1; }
   const LayoutDev lf = make_layout(lfine_), lc = make_layout(lc_);
   hipStream_t s = (hipStream_t)stream;
-  if (lfine_->nd == 3 && box.n0() >= 32 && g_restrict_wide) {
+  const bool transformed = lay_split(lfine_) || lay_split(lc_);      // colour-split fields: the generic kernel (transformed index per point)
+  if (lfine_->nd == 3 && box.n0() >= 32 && g_restrict_wide && !transformed) {
     const int ntx = (box.n0() + 63) / 64;
     const int rw = g_restrict_rows == 1 ? 1 : 2;      // coarse rows per wave
     const long long cols = (long long)ntx * ((box.n1() + rw - 1) / rw);
@@ -453,6 +454,7 @@ static bool residual_restrict_one_pass(const examg_layout_t *lu_, const examg_la
   const bool inside = 2 * cb.b0 - 1 >= fb.b0 && 2 * (cb.e0 - 1) + 1 < fb.e0 && 2 * cb.b1 - 1 >= fb.b1 && 2 * (cb.e1 - 1) + 1 < fb.e1 &&
                       2 * cb.b2 - 1 >= fb.b2 && 2 * (cb.e2 - 1) + 1 < fb.e2;
   const bool left_ok = 2 * (cb.b0 - 1) >= -(lu_->pad_l[0] + lu_->ghost_l[0]) && 2 * (cb.b0 - 1) >= -(lf_->pad_l[0] + lf_->ghost_l[0]);
+  if (lay_split(lu_) || lay_split(lf_) || lay_split(lc_)) return false;         // colour-split fields: the two loops
   if (small_residual_restrict_ok(lu_, lf_, st, lc_, fb, cb)) return true;      // launch-bound levels: kernels_small.hip
   return g_restrict_wide && lu_->nd == 3 && ord >= 0 && cb.n0() >= 32 && inside && left_ok && box_inside(lu_, fb, 1) && box_inside(lf_, fb, 0) &&
          box_inside(lc_, cb, 0);
@@ -472,7 +474,7 @@ extern "C" int examg_residual_restrict(const examg_layout_t *lu_, const double *
   const Box cb = make_box(cbegin, cend);
   if (cb.count() == 0) return 0;
   const int ord = canonical_order7(st);
-  if (small_residual_restrict_ok(lu_, lf_, st, lc_, make_box(fbegin, fend), cb))
+  if (!lay_split(lu_) && !lay_split(lf_) && !lay_split(lc_) && small_residual_restrict_ok(lu_, lf_, st, lc_, make_box(fbegin, fend), cb))
     return launch_small_residual_restrict(lu_, u, lf_, rhs, lc_, fc, st, scale, cb, (hipStream_t)stream);
   if (residual_restrict_one_pass(lu_, lf_, st, lc_, fbegin, fend, cbegin, cend)) {
     const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_), lc = make_layout(lc_);
@@ -524,7 +526,7 @@ extern "C" int examg_prolong_add(const examg_layout_t *lc_, const double *uc, co
   if (!box_inside(lc_, cb, 0)) { set_error("examg_prolong_add: coarse footprint leaves the coarse allocation"); return 1; }
   const LayoutDev lf = make_layout(lfine_), lc = make_layout(lc_);
   hipStream_t s = (hipStream_t)stream;
-  if (lfine_->nd == 3 && box.n0() >= 32) {
+  if (lfine_->nd == 3 && box.n0() >= 32 && !lay_split(lfine_) && !lay_split(lc_)) {
     const int x0 = box.b0 & ~1;
     const int npairs = (box.e0 - x0 + 1) / 2;
     const int zb = g_prolong_zb > 0 ? g_prolong_zb : (box.count() >= 200000000LL ? 1 : 2);    // 768^3: 1.73 -> 1.68 ms with one plane pair per workgroup

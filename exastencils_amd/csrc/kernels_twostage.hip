@@ -666,7 +666,7 @@ static bool prolong_args_ok(const char *who, const examg_layout_t *lc, const Box
 }
 
 static bool two_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
-  return !g_ts_disable && lu->nd == 3 && canonical_order7(st) >= 0 && box.n0() >= 64 && box_inside(lu, box, 1) &&
+  return !g_ts_disable && !lay_split(lu) && !lay_split(lf) && lu->nd == 3 && canonical_order7(st) >= 0 && box.n0() >= 64 && box_inside(lu, box, 1) &&
          box_inside(lf, box, 0);
 }
 

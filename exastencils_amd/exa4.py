@@ -229,9 +229,12 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
         """`LayoutTransformations { transform <field>@<levels> with [x, y, z, i] => [i, x, y, z] }` on the coefficient field of a
         stencil field (Compiler/src/exastencils/layoutTransformation/l4/L4_LayoutSection.scala; Testing/LayoutTrafo/*.exa4): the
         entries of a point become contiguous -- APPLIED: loops read the coefficients through the transformed index
-        (EXAMG_CLAYOUT_ENTRY_FASTEST), one stream instead of one per entry.  The other directives of the reference's test programs
-        (colour splits, axis permutations, concat / rename of scalar fields) change no value either and stay recorded only: scalar
-        fields keep the reference layout, the library's contract with its callers."""
+        (EXAMG_CLAYOUT_ENTRY_FASTEST), one stream instead of one per entry.  `transform <field> with [x, y, z] => [x / 2, y, z, x % 2]`
+        (the colour split of Testing/LayoutTrafo/rbgs.exa4:2; 2-D: `[x, y] => [x / 2, y, x % 2]`) on a scalar field -- APPLIED on the
+        HIP kernel layer: the field's arrays are allocated under EXAMG_LAYOUT_SPLIT_X and every loop reaches it through the
+        transformed index (the points of one red-black colour of a row are contiguous: 32 B per update for a half sweep instead
+        of 48); one-pass peepholes keep to plain fields.  The other directives of the reference's test programs (axis permutations,
+        concat / rename of scalar fields) change no value either and stay recorded only."""
         import re
 
         self._sf_entry_fastest, self._sf_rec, self._sf_dirty = set(), {}, {}
@@ -241,8 +244,15 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
         coef_of = {}
         for sf in self.ast.sfields:
             coef_of.setdefault(sf.field, []).append(sf)
+        axes = "xyz"[:nd]
+        split_src = ",".join(axes)
+        split_dst = ",".join(["x/2"] + list(axes[1:]) + ["x%2"])
+        self._split_fields = set()
         for text in getattr(self.ast, "layout_transformations", []):
             m = re.match(r"^transform (.+?) with \[(.+?)\] => \[(.+?)\]$", text.strip())
+            if m and m.group(2).replace(" ", "") == split_src and m.group(3).replace(" ", "") == split_dst:
+                self._apply_colour_split(m.group(1))
+                continue
             if not m or m.group(2).replace(" ", "") != src or m.group(3).replace(" ", "") != dst:
                 continue
             items, depth, cur = [], 0, []
@@ -264,6 +274,38 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
                     for lvl in lvls:
                         if (sf.name, lvl) in self.stencils:
                             self._sf_entry_fastest.add((sf.name, lvl))
+
+    def _transform_items(self, text: str):
+        """(field name, levels) of the items of a `transform a@(..), b with ..` directive (items are separated by commas outside level lists)."""
+        items, depth, cur = [], 0, []
+        for tok in text.split(" "):
+            depth += tok == "("
+            depth -= tok == ")"
+            if tok == "," and depth == 0:
+                items.append(cur)
+                cur = []
+            else:
+                cur.append(tok)
+        items.append(cur)
+        for it in items:
+            if it:
+                yield it[0], self.levels_of(self._parse_level_text(" ".join(it[2:]) if len(it) > 2 and it[1] == "@" else "all"))
+
+    def _apply_colour_split(self, items: str):
+        """The named scalar fields under `[x, y, z] => [x / 2, y, z, x % 2]`: their (still zero) arrays are re-allocated in the split
+        layout.  Only where the kernel layer has transformed layouts (HipOps: examg_transform_field); the CPU stand-in of the tests
+        keeps the directive recorded."""
+        if not hasattr(self.ops, "transform_field"):
+            return
+        for fname, lvls in self._transform_items(items):
+            for lvl in lvls:
+                f = self.fields.get((fname, lvl))
+                if f is None or f.layout.transform:
+                    continue
+                f.layout = f.layout.split_x()
+                f.lc = f.layout.c_struct()
+                f.slots = [self.ops.new_array(f.layout.size) for _ in range(f.num_slots)]
+                self._split_fields.add((fname, lvl))
 
     def _parse_level_text(self, spec: str):
         """Level specification of a LayoutTransformations item (`all`, `finest`, `4`, `(4 to finest)`) as the parser's level node."""

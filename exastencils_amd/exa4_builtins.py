@@ -249,8 +249,8 @@ class Builtins:
         # a point beyond the tolerance exists SOMEWHERE (the verdict is all-reduced, so that every block leaves the function together
         # when the `if` returns): the first one in loop order (x fastest) on THIS block, if it has one, for the program's messages
         self._cmp_point = None
-        ha = self.ops.to_host(A.data(sa)).reshape(A.layout.shape_zyx)
-        hb = self.ops.to_host(B.data(sb)).reshape(B.layout.shape_zyx)
+        ha = A.host_array(self.ops, sa)
+        hb = B.host_array(self.ops, sb)
         for b, e in boxes:
             sl = tuple(slice(A.layout.ref(d) + b[d], A.layout.ref(d) + e[d]) for d in (2, 1, 0))
             bad = np.argwhere(np.abs(ha[sl] - hb[sl]) > tol if op == ">" else np.abs(ha[sl] - hb[sl]) >= tol)
@@ -289,7 +289,7 @@ class Builtins:
             if key not in env["_fields"]:
                 lay = f.layout
                 sl = tuple(slice(lay.ref(d) + box[0][d], lay.ref(d) + box[1][d]) for d in (2, 1, 0))
-                env["_fields"][key] = self.ops.to_host(f.data(slot)).reshape(lay.shape_zyx)[sl]
+                env["_fields"][key] = f.host_array(self.ops, slot)[sl]
             return env["_fields"][key]
         if k == "id":
             if e[1] in env:

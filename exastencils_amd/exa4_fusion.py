@@ -49,7 +49,7 @@ class LazyFusions:
             return False
         op, lhs, rhs = st[1], st[2], st[3]
         D, ds = self._field(lhs, fr)
-        if D is not target or D.num_slots != 1:
+        if D is not target or D.num_slots != 1 or D.layout.transform:
             return False
         b, e = box
         fb, fe = self.domain.loop_bounds(D.layout)
@@ -68,6 +68,8 @@ class LazyFusions:
             F, fs = self._field(r[0], fr)
             U, us = self._field(r[2], fr)
             A = r[1]
+            if U.layout.transform or F.layout.transform:
+                return False
             if U is D or F is D or not self._canonical7(A, self.nd) or D.layout.inner[0] < self.fuse_min_row:
                 return False
             self._pending = dict(kind="residual", D=D, ds=ds, U=U, us=us, F=F, fs=fs, A=A, b=b, e=e)
@@ -77,6 +79,8 @@ class LazyFusions:
             if m is None or m[1] != "prolongation" or m[0] != 1.0 or not hasattr(self.ops, "rbgs_sweep_fused_prolong") or self.nd != 3:
                 return False
             X, xs = self._field(m[4], fr)
+            if X.layout.transform:
+                return False
             pts = 1
             for d in range(3):
                 pts *= max(1, e[d] - b[d])

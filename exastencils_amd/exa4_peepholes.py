@@ -40,6 +40,8 @@ class Peepholes:
         U, us = self._field(src, fr)
         F, fs = self._field(r[0], fr)
         wv, A = self._smoother_weight(wexpr, r[1], fr)
+        if D.layout.transform or U.layout.transform or F.layout.transform:
+            return None         # fields under a layout transformation: the plain loops (the kernel layer's one-pass forms take plain layouts)
         return D, ds, U, us, F, fs, A, wv
 
     @staticmethod
@@ -448,6 +450,8 @@ class Peepholes:
                     return None
         if any(x.num_slots != 1 for x in (F, R, P, Q)) or (U.num_slots != 1 and not flags & CG_NO_BC):
             return None
+        if any(x.layout.transform for x in (U, F, R, P, Q)):
+            return None         # the one-kernel solver takes plain layouts
         return U, F, R, P, Q, A, max_it, tol, tail, flags
 
     def _run_coarse_cg(self, plan):

@@ -49,6 +49,26 @@ class Field:
     def data(self, slot: Optional[int] = None):
         return self.slots[self.current_slot if slot is None else slot]
 
+    # -- host copies in the UNTRANSFORMED layout, [z, y, x] (field I/O, host-side fills): a field under a layout transformation is
+    #    brought to the plain layout on the device first (examg_transform_field) -------------------------------------------------------
+    def host_array(self, ops, slot: Optional[int] = None):
+        x = self.data(slot)
+        if self.layout.transform:
+            plain = self.layout.plain()
+            tmp = ops.new_array(plain.size)
+            ops.transform_field(self.lc, x, plain.c_struct(), tmp)
+            x = tmp
+        return ops.to_host(x).reshape(self.layout.shape_zyx)
+
+    def set_host_array(self, ops, a, slot: Optional[int] = None):
+        import numpy as np
+
+        t = ops.from_host(np.ascontiguousarray(a, dtype=np.float64).reshape(-1))
+        if self.layout.transform:
+            ops.transform_field(self.layout.plain().c_struct(), t, self.lc, self.data(slot))
+        else:
+            self.data(slot).copy_(t)
+
 
 @dataclass
 class Stencil:

@@ -38,7 +38,7 @@ def print_field(filename: str, field: Field, ops, domain, slot: Optional[int] = 
     point -- `std::scientific, value, sep, newline`; the precision is set once per file (IR_FileAccess_Locking.scala:154-160).
     Every value, the last one too, is followed by the separator."""
     b, e, sl = _region(field, include_ghost)
-    a = ops.to_host(field.data(slot)).reshape(field.layout.shape_zyx)[sl]
+    a = field.host_array(ops, slot)[sl]
     g = domain.geom(field.level)
     nd = field.layout.nd
     p = 6 if precision < 0 else int(precision)
@@ -58,7 +58,7 @@ def read_field_ascii(filename: str, field: Field, ops, slot: Optional[int] = Non
     """readField_lock in ascii mode: the inverse of print_field for the same region and condition (positions are skipped, the
     last number of a line is the value); points outside keep their values."""
     b, e, sl = _region(field, include_ghost)
-    full = ops.to_host(field.data(slot)).reshape(field.layout.shape_zyx).copy()
+    full = field.host_array(ops, slot).copy()
     view = full[sl]
     with open(filename) as f:
         lines = [ln for ln in f.read().splitlines() if ln.strip()]
@@ -74,23 +74,23 @@ def read_field_ascii(filename: str, field: Field, ops, slot: Optional[int] = Non
                     raise ValueError("%s ends before the field region is filled" % filename)
                 toks = [t for t in (ln.split(separator) if separator.strip() else ln.split()) if t.strip()]
                 view[k, j, i] = float(toks[-1])
-    field.data(slot).copy_(ops.from_host(full.reshape(-1)))
+    field.set_host_array(ops, full, slot)
 
 
 def write_field(filename: str, field: Field, ops, slot: Optional[int] = None, include_ghost: bool = False):
     """writeField ( filename, field ) in binary mode: raw doubles of DLB..DRE (or GLB..GRE), x fastest."""
     _, _, sl = _region(field, include_ghost)
-    a = ops.to_host(field.data(slot)).reshape(field.layout.shape_zyx)[sl]
+    a = field.host_array(ops, slot)[sl]
     np.ascontiguousarray(a, dtype=np.float64).tofile(filename)
 
 
 def read_field(filename: str, field: Field, ops, slot: Optional[int] = None, include_ghost: bool = False):
     """readField ( filename, field ): the inverse of write_field; points outside the region keep their values."""
     _, _, sl = _region(field, include_ghost)
-    full = ops.to_host(field.data(slot)).reshape(field.layout.shape_zyx).copy()
+    full = field.host_array(ops, slot).copy()
     want = full[sl].shape
     a = np.fromfile(filename, dtype=np.float64)
     if a.size != int(np.prod(want)):
         raise ValueError("%s holds %d values, the field region needs %d" % (filename, a.size, int(np.prod(want))))
     full[sl] = a.reshape(want)
-    field.data(slot).copy_(ops.from_host(full.reshape(-1)))
+    field.set_host_array(ops, full, slot)

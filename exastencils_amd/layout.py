@@ -24,6 +24,10 @@ class FieldLayout:
     pad_r: Tuple[int, int, int] = (0, 0, 0)
     communicates_dup: bool = True      # `duplicateLayers = [...] with communication`
     communicates_ghost: bool = True    # `ghostLayers = [...] with communication`
+    # layout transformation of the program's `LayoutTransformations` block (include/examg.h: EXAMG_LAYOUT_*): 1 = the colour split
+    # `[x, y, z] => [x / 2, y, z, x % 2]` (Testing/LayoutTrafo/rbgs.exa4:2).  Regions, iterator coordinates and boxes stay those of the
+    # untransformed layout; only where a value lives changes.
+    transform: int = 0
 
     @staticmethod
     def node(nd: int, ncells: Sequence[int], ghost: int, communicates_dup: bool = True,
@@ -53,7 +57,28 @@ class FieldLayout:
 
     @property
     def size(self) -> int:
+        if self.transform == 1:
+            return 2 * ((self.tot(0) + 1) // 2) * self.tot(1) * self.tot(2)
         return self.tot(0) * self.tot(1) * self.tot(2)
+
+    def split_x(self) -> "FieldLayout":
+        """This layout under the colour split `[x, y, z] => [x / 2, y, z, x % 2]`."""
+        from dataclasses import replace
+
+        return replace(self, transform=1)
+
+    def plain(self) -> "FieldLayout":
+        from dataclasses import replace
+
+        return replace(self, transform=0)
+
+    def linear(self, i0: int, i1: int = 0, i2: int = 0) -> int:
+        """Array index of iterator point (i0, i1, i2) -- the restatement of the library's index map (csrc/examg_common.h: lidx)."""
+        a = (i0 + self.ref(0), i1 + self.ref(1), i2 + self.ref(2))
+        if self.transform == 1:
+            hx = (self.tot(0) + 1) // 2
+            return a[0] // 2 + hx * (a[1] + self.tot(1) * (a[2] + self.tot(2) * (a[0] % 2)))
+        return a[0] + self.tot(0) * (a[1] + self.tot(1) * a[2])
 
     @property
     def shape_zyx(self) -> Tuple[int, int, int]:
@@ -76,4 +101,5 @@ class FieldLayout:
             s.ghost_l[d] = s.ghost_r[d] = self.ghost[d]
             s.dup_l[d] = s.dup_r[d] = self.dup[d]
             s.inner[d] = self.inner[d]
+        s.transform = self.transform
         return s

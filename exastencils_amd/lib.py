@@ -16,7 +16,7 @@ MAXE = 27
 class LayoutC(C.Structure):
     _fields_ = [("nd", C.c_int32)] + [
         (n, C.c_int32 * 3) for n in ("pad_l", "ghost_l", "dup_l", "inner", "dup_r", "ghost_r", "pad_r")
-    ]
+    ] + [("transform", C.c_int32)]
 
 
 class StencilC(C.Structure):
@@ -77,7 +77,7 @@ SYMBOLS = [
     "examg_comm_unique_id", "examg_comm_create", "examg_comm_destroy", "examg_comm_rank", "examg_comm_size",
     "examg_exchange_workspace_bytes", "examg_exchange", "examg_allreduce", "examg_allgather",
     "examg_jacobi2_blocks", "examg_rbgs_sweep_blocks", "examg_crand_seed", "examg_crand_draw_host",
-    "examg_transform_stencilfield", "examg_residual_restrict_one_pass", "examg_residual_restrict_blocks", "examg_prolong_add_blocks",
+    "examg_transform_stencilfield", "examg_transform_field", "examg_layout_size", "examg_residual_restrict_one_pass", "examg_residual_restrict_blocks", "examg_prolong_add_blocks",
     "examg_comm_create_peer", "examg_comm_peer_alloc", "examg_comm_peer_connect", "examg_comm_peer_slab_bytes",
     "examg_comm_peer_gather_bytes", "examg_comm_status",
 ]
@@ -147,6 +147,9 @@ def load(path=None):
     L.examg_init_varcoeff7.argtypes = [lp, vp, gp, ep, ip, ip, vp]
     L.examg_init_helmholtz27.argtypes = [lp, vp, gp, ep, C.c_double, ip, ip, vp]
     L.examg_transform_stencilfield.argtypes = [lp, C.c_int, vp, vp, C.c_int, vp]
+    L.examg_transform_field.argtypes = [lp, vp, lp, vp, vp]
+    L.examg_layout_size.argtypes = [lp]
+    L.examg_layout_size.restype = C.c_int64
     L.examg_pack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_unpack.argtypes = [lp, vp, vp, ip, ip, vp]
     L.examg_cg_coarse.argtypes = [lp, vp, lp, vp, lp, vp, lp, vp, lp, vp, sp, gp, C.c_uint32, C.c_int, C.c_double, ip, ip, vp, vp]

@@ -206,6 +206,10 @@ class HipOps:
         check(self.L.examg_transform_stencilfield(C.byref(lc), int(nent), self.ptr(src), self.ptr(dst), 1 if to_entry_fastest else 0,
                                                   self._stream()), "examg_transform_stencilfield")
 
+    def transform_field(self, lsrc, src, ldst, dst):
+        """The same field under another layout transformation (`transform <field> with [x, y, z] => [x / 2, y, z, x % 2]` or back)."""
+        check(self.L.examg_transform_field(C.byref(lsrc), self.ptr(src), C.byref(ldst), self.ptr(dst), self._stream()), "examg_transform_field")
+
     # -- halo ------------------------------------------------------------------------------------------
     def pack(self, l, x, buf, begin, end):
         check(self.L.examg_pack(C.byref(l), self.ptr(x), self.ptr(buf), ivec(begin), ivec(end), self._stream()), "examg_pack")

@@ -19,10 +19,16 @@ import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
+import threading as _threading
+
 from .comm import Communicator
 from .domain import RectDomain
 from .field import (FN_POLY3D, FN_ZERO, Field, Stencil, laplace_fd, laplace_unit, stencil_field_offsets)
 from .layout import FieldLayout
+
+# stream captures of one process run one at a time (a host with several blocks per process -- one thread each -- captures per block;
+# nothing executes during a capture, so no block waits for another inside it)
+_CAPTURE_LOCK = _threading.Lock()
 
 APPLY, RESIDUAL, SMOOTH = 0, 1, 2
 
@@ -567,7 +573,7 @@ class SolverFromL4(_Program):
         torch.cuda.current_stream(self.ops.device).wait_stream(s)
         g = torch.cuda.CUDAGraph()
         # thread_local: other threads of the process (RCCL's proxy threads at N > 1) may issue HIP calls during the capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with _CAPTURE_LOCK, torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.mgCycle(hi)
         self._graphs["cycle"] = g
         self._graph_generation = getattr(self.comm, "generation", 0)
@@ -1077,7 +1083,7 @@ class SolverFromL3(_Program):
         torch.cuda.current_stream(dev).wait_stream(side)
         for name, fn in phases():
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with _CAPTURE_LOCK, torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             self._graphs[name] = g
         self.reset()

@@ -43,10 +43,20 @@ extern "C" {
 
 #define EXAMG_MAX_ENTRIES 27
 
-/* field/ir/IR_FieldLayout.scala:103-129 (IR_FieldLayoutPerDim). Unused dims: inner = 1, rest 0. */
+/* field/ir/IR_FieldLayout.scala:103-129 (IR_FieldLayoutPerDim). Unused dims: inner = 1, rest 0.
+ * transform: the field under a layout transformation of the program's `LayoutTransformations` block (layoutTransformation/ir/
+ * IR_LayoutTransformStatement.scala; Testing/LayoutTrafo/rbgs.exa4:2).  EXAMG_LAYOUT_SPLIT_X is the colour split
+ * `transform <field> with [x, y, z] => [x / 2, y, z, x % 2]`: with ax = array index in x (iterator + referenceOffset) the value of a
+ * point lives at  ax / 2 + H * (ay + TOTy * (az + TOTz * (ax % 2))),  H = ceil(TOTx / 2): the even and the odd columns of every row
+ * are two contiguous half rows in two half arrays, so the points of one red-black colour of a row -- and their x neighbours -- are
+ * contiguous (32 B per update for a half sweep instead of 48).  A transformation changes where a value lives, never a value; regions,
+ * iterator coordinates and boxes are those of the untransformed layout.  Entry points that have no form for a transformed layout
+ * refuse it (examg_last_error); examg_transform_field converts. */
+enum { EXAMG_LAYOUT_PLAIN = 0, EXAMG_LAYOUT_SPLIT_X = 1 };
 typedef struct examg_layout {
   int32_t nd;
   int32_t pad_l[3], ghost_l[3], dup_l[3], inner[3], dup_r[3], ghost_r[3], pad_r[3];
+  int32_t transform; /* EXAMG_LAYOUT_* */
 } examg_layout_t;
 
 /* operator/ir/IR_Stencil.scala:34-211 (constant coefficients, entry order significant) or a
@@ -313,6 +323,11 @@ int examg_init_helmholtz27(const examg_layout_t *lc, double *cfield, const examg
  * coefficient array: dst[linear * nent + k] <-> src[k * size(lc) + linear] over the whole allocation; src != dst. */
 int examg_transform_stencilfield(const examg_layout_t *lc, int nent, const double *src, double *dst, int to_entry_fastest,
                                  examg_stream_t stream);
+
+/* Copy a field between two layouts that differ in `transform` only (same regions): dst[index under ldst] = src[index under lsrc] over
+ * the whole allocation; src != dst.  doubles of an array: examg_layout_size. */
+int examg_transform_field(const examg_layout_t *lsrc, const double *src, const examg_layout_t *ldst, double *dst, examg_stream_t stream);
+int64_t examg_layout_size(const examg_layout_t *l);
 
 /* ---- K9: halo pack / unpack (communication/ir/IR_NoInterpPacking.scala:53-83): box <-> contiguous
  * buffer, x fastest; ranges from IR_PackInfoDuplicate.scala:15-39 / IR_PackInfoGhost.scala:13-60. */

@@ -51,7 +51,7 @@ def test_debug_build_adds_only_debug_hooks():
 def test_struct_mirrors_match_header_sizes():
     from exastencils_amd import lib
 
-    assert C.sizeof(lib.LayoutC) == 4 * 22
+    assert C.sizeof(lib.LayoutC) == 4 * 23          # nd, 7 x [3], transform
     assert C.sizeof(lib.GeomC) == 8 * 6
     # nent, diag, off[27][3] (int32) | coef[27] (double, 8-aligned) | pointer | layout (+ tail padding)
     assert lib.StencilC.coef.offset == 4 * (2 + 81) + 4

@@ -57,6 +57,16 @@ def cases(ops, level, with27=True, align=0):
         ("residual_norm", lambda: ops.residual_norm2(L, u, F, f, A, b, e, out=out), "k_stencil7_zmarch<3", 16 * pts, pts),
         ("dot_norm", lambda: ops.dot(L, r, L, r, b, e, out), "k_dot_rows", 8 * pts, pts),
     ]
+    if align == 0:
+        # the red-black half sweep with Solution and RHS under the colour split `[x, y, z] => [x / 2, y, z, x % 2]` (LayoutTransformations,
+        # Testing/LayoutTrafo/rbgs.exa4:2): the points of a colour and their x neighbours are contiguous -- 32 B per update instead of 48
+        lus, lfs = lu.split_x(), lf.split_x()
+        us, fs = ops.new_array(lus.size), ops.new_array(lfs.size)
+        ops.transform_field(L, u, lus.c_struct(), us)
+        ops.transform_field(F, f, lfs.c_struct(), fs)
+        Ls, Fs = lus.c_struct(), lfs.c_struct()
+        cs.insert(3, ("rbgs_half_sweep_colour_split", lambda: ops.stencil_op(2, Ls, us, Fs, fs, Ls, us, A, w, 0, b, e), "k_stencil_generic<2>",
+                      16 * pts, pts // 2))
     if align == 0 and level >= 8:
         # the one-step kernel on the padded layout the reference produces with data_alignFieldPointers (rows of 544 doubles at
         # 512^3, field/ir/IR_AddPaddingToFieldLayouts.scala:36-41): every 16-byte access aligned, no partial lines at window edges
