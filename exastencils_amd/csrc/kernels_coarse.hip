@@ -24,16 +24,45 @@ struct StencilCG {
   long long cpt;      // stride between points (1: reference layout, nent: entry-fastest transformation)
 };
 
-__device__ __forceinline__ double cg_block_sum(double v, double *sm) {
+// Block sums with ONE workgroup barrier each: the wave partials go to one of two buffers in turn (a wave can only write buffer k & 1 again,
+// for sum k + 2, after the barrier of sum k + 1, which every wave reaches after it has read buffer k & 1) -- the solver is a chain of
+// barriers, and these sums were 6 of its 7 per iteration.  Fixed tree: 6 shuffle steps per wave, then the 16 partials in wave order.
+constexpr int CG_SM = 4 * (CG_THREADS / 64);      // two buffers of up to two sums
+__device__ __forceinline__ double cg_block_sum(double v, double *sm, int &turn) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = v + __shfl_down(v, o);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __syncthreads();  // protect sm reuse
-  if (lane == 0) sm[wv] = v;
+  double *b = sm + (turn & 1) * 2 * (CG_THREADS / 64);
+  ++turn;
+  if (lane == 0) b[wv] = v;
   __syncthreads();
-  double r = sm[0];
-  for (int i = 1; i < CG_THREADS / 64; ++i) r = r + sm[i];
+  double r = b[0];
+  for (int i = 1; i < CG_THREADS / 64; ++i) r = r + b[i];
   return r;  // same value in every thread
+}
+
+// two sums behind one barrier (each with the tree of cg_block_sum: same bits as two calls)
+__device__ __forceinline__ void cg_block_sum2(double &v0, double &v1, double *sm, int &turn) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v0 = v0 + __shfl_down(v0, o);
+    v1 = v1 + __shfl_down(v1, o);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double *b = sm + (turn & 1) * 2 * (CG_THREADS / 64);
+  ++turn;
+  if (lane == 0) {
+    b[wv] = v0;
+    b[CG_THREADS / 64 + wv] = v1;
+  }
+  __syncthreads();
+  double r0 = b[0], r1 = b[CG_THREADS / 64];
+  for (int i = 1; i < CG_THREADS / 64; ++i) {
+    r0 = r0 + b[i];
+    r1 = r1 + b[CG_THREADS / 64 + i];
+  }
+  v0 = r0;
+  v1 = r1;
 }
 
 __device__ __forceinline__ void cg_unflatten(const Box &box, int t, int &i0, int &i1, int &i2) {
@@ -81,7 +110,8 @@ __global__ void __launch_bounds__(CG_THREADS)
 k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDev lr, double *res, LayoutDev lp, double *p,
             LayoutDev lq, double *ap, LayoutDev lc, StencilCG st, FaceBoxesCG fbr, FaceBoxesCG fbp, FaceBoxesCG fbs, int max_it,
             double rel_tol, Box box, double *info, unsigned flags) {
-  __shared__ double sm[CG_THREADS / 64];
+  __shared__ double sm[CG_SM];
+  int turn = 0;
   const bool from_norm = flags & EXAMG_CG_ALPHA_FROM_NORM, bc = !(flags & EXAMG_CG_NO_BC);
   const int total = (int)box.count();
   int i0, i1, i2;
@@ -95,7 +125,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
     s = s + r * r;
   }
   if (bc) cg_zero_faces(fbr, lr, res);
-  double curRes = sqrt(cg_block_sum(s, sm));
+  double curRes = sqrt(cg_block_sum(s, sm, turn));
   const double initRes = curRes;
   // cgTmp0 = Residual ; apply bc to cgTmp0
   for (int t = threadIdx.x; t < total; t += CG_THREADS) {
@@ -119,8 +149,14 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
       sn = sn + r * r;
       sd = sd + p[lidx(lp, i0, i1, i2)] * q;
     }
-    const double alphaNom = from_norm ? curRes * curRes : cg_block_sum(sn, sm);
-    const double alphaDenom = cg_block_sum(sd, sm);
+    double alphaNom, alphaDenom = sd;
+    if (from_norm) {
+      alphaNom = curRes * curRes;
+      alphaDenom = cg_block_sum(sd, sm, turn);
+    } else {
+      alphaNom = sn;
+      cg_block_sum2(alphaNom, alphaDenom, sm, turn);
+    }
     const double alpha = alphaNom / alphaDenom;
     // Solution += alpha * cgTmp0 ; Residual -= alpha * cgTmp1 ; nextRes = ResNorm()
     double s2 = 0.0;
@@ -132,7 +168,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
       res[kr] = r;
       s2 = s2 + r * r;
     }
-    nextRes = sqrt(cg_block_sum(s2, sm));
+    nextRes = sqrt(cg_block_sum(s2, sm, turn));
     ++it;
     if (nextRes <= rel_tol * initRes) { converged = true; break; }  // uniform: every thread holds the same sums
     const double beta = (nextRes * nextRes) / (curRes * curRes);
@@ -173,7 +209,8 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
                 LayoutDev lq, double *ap, StencilCG st, StencilCGL sl, FaceBoxesCG fbr, FaceBoxesCG fbp, FaceBoxesCG fbs, int max_it,
                 double rel_tol, Box box, double *info, int ldx, int ldxy, int ldtot, unsigned flags) {
   extern __shared__ double P[];
-  __shared__ double sm[CG_THREADS / 64];
+  __shared__ double sm[CG_SM];
+  int turn = 0;
   const int total = (int)box.count();
   const bool from_norm = flags & EXAMG_CG_ALPHA_FROM_NORM, bc = !(flags & EXAMG_CG_NO_BC);
   // halo of the search direction: the boundary planes `apply bc` keeps at zero -- or, for a solver without `apply bc` statements,
@@ -214,7 +251,7 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
     cg_zero_faces(fbr, lr, res);   // apply bc to Residual / cgTmp0: their boundary planes in memory, as the statements leave them
     cg_zero_faces(fbp, lp, p);
   }
-  double curRes = sqrt(cg_block_sum(s, sm));
+  double curRes = sqrt(cg_block_sum(s, sm, turn));
   const double initRes = curRes;
 #pragma unroll
   for (int j = 0; j < CG_PPT; ++j) {
@@ -238,8 +275,14 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
         sd = sd + pv[j] * acc;
       }
     }
-    const double alphaNom = from_norm ? curRes * curRes : cg_block_sum(sn, sm);
-    const double alphaDenom = cg_block_sum(sd, sm);
+    double alphaNom, alphaDenom = sd;
+    if (from_norm) {
+      alphaNom = curRes * curRes;
+      alphaDenom = cg_block_sum(sd, sm, turn);
+    } else {
+      alphaNom = sn;
+      cg_block_sum2(alphaNom, alphaDenom, sm, turn);
+    }
     const double alpha = alphaNom / alphaDenom;
     double s2 = 0.0;
 #pragma unroll
@@ -250,7 +293,7 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
         s2 = s2 + r[j] * r[j];
       }
     }
-    nextRes = sqrt(cg_block_sum(s2, sm));
+    nextRes = sqrt(cg_block_sum(s2, sm, turn));
     ++it;
     if (nextRes <= rel_tol * initRes) { converged = true; break; }
     const double beta = (nextRes * nextRes) / (curRes * curRes);

@@ -448,13 +448,15 @@ struct RowMarchGeom {
   int remap;      // 2: bands of y-adjacent tiles per XCD within every z layer
 };
 
-constexpr int RM_NSEG = 4;                     // 4 x 128 points per row
-constexpr int RM_STRIP = RM_NSEG * 128 + 16;   // doubles of LDS per wave and row
-
-template <int MODE, int ORDER, int RY, int WY>
+// NSEG segments of 128 points per row: 4 for rows of 400 .. 512 points (level 9), 2 for rows of 144 .. 256 points (level 8: the 256^3
+// block of configs[1], and every block of a strong-scaled 512^3) -- there with RY = 4 rows per wave in the registers the shorter rows
+// leave (two halo rows per four own rows instead of per two)
+template <int MODE, int ORDER, int RY, int WY, int NSEG>
 __global__ void __launch_bounds__(64 * WY)
 k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev ld,
                     double *__restrict__ dst, Coef7 k, double w, Box box, RowMarchGeom g) {
+  constexpr int RM_NSEG = NSEG;
+  constexpr int RM_STRIP = RM_NSEG * 128 + 16;   // doubles of LDS per wave and row
   __shared__ __attribute__((aligned(16))) double strip[WY][RY][RM_STRIP];
   const int lane = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -585,7 +587,7 @@ k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, co
           d2 v;
           v.x = sb[p];
           v.y = sb[p + 1];
-          // 16-byte aligned: whole lines per wave.  Rows have at least 400 points (dispatch): only the last segment can end early
+          // 16-byte aligned: whole lines per wave.  Rows have more than 128 (NSEG - 1) + 15 points (dispatch): only the last segment can end early
           if (j < RM_NSEG - 1 || p + 1 < n0) __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(row + p));
           else if (p < n0) row[p] = v.x;
         }
@@ -629,20 +631,22 @@ int launch_stencilfield7(int mode, const LayoutDev &lu, const double *u, const L
                          double *dst, const LayoutDev &lc, const double *cf, double w, const Box &box, hipStream_t s);
 
 static thread_local int g_rm_on = -1, g_rm_zc = -1, g_rm_remap = -1;   // examg_debug_rowmarch (debug build): row-marching kernel off / on, planes per chunk, order
+static thread_local int g_rm_ry2 = -1;                                  // ... rows per wave of the two-segment form (on >= 10: on - 10 rows)
 #ifndef EXAMG_RM_RY
 #define EXAMG_RM_RY 2
 #define EXAMG_RM_WY 4
 #endif
 constexpr int RM_RY = EXAMG_RM_RY, RM_WY = EXAMG_RM_WY;
 
-// the row-marching kernel takes boxes whose rows fit one wave (385 .. 512 points: level 9) and that are long enough in y and z
+// the row-marching kernel takes boxes whose rows fit one wave -- 400 .. 512 points (level 9: four segments) or 144 .. 256 points (level 8:
+// two segments) -- and that are long enough in y and z; returns the segments per row, 0: not taken
 template <int MODE>
-static bool rowmarch_wanted(const Box &box, int colour) {
-  if (MODE == ZM_RESNORM || colour >= 0) return false;
-  if (g_rm_on == 0) return false;
-  const bool fits = box.n0() >= 400 && box.n0() <= RM_NSEG * 128;
-  if (g_rm_on == 1) return fits;
-  return fits && box.n1() >= 64 && box.n2() >= 16;
+static int rowmarch_wanted(const Box &box, int colour) {
+  if (MODE == ZM_RESNORM || colour >= 0) return 0;
+  if (g_rm_on == 0) return 0;
+  const int nseg = (box.n0() >= 400 && box.n0() <= 512) ? 4 : ((box.n0() >= 144 && box.n0() <= 256) ? 2 : 0);
+  if (g_rm_on == 1) return nseg;
+  return (box.n1() >= 64 && box.n2() >= 16) ? nseg : 0;
 }
 // padded layouts (even strides) keep the window kernel: it starts its windows on a 16-byte boundary there and every access is
 // aligned already (512^3, 544-double rows: 0.570 ms against 0.589 for the row-marching kernel)
@@ -652,19 +656,23 @@ static bool rowmarch_layout(const LayoutDev &lu, const LayoutDev &lf, const Layo
 }
 
 template <int MODE, int ORDER>
-static int launch_rowmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld, double *dst,
+static int launch_rowmarch(int nseg, const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld, double *dst,
                            const Coef7 &k, double w, const Box &box, hipStream_t s) {
   RowMarchGeom g;
-  g.nty = (box.n1() + RM_RY * RM_WY - 1) / (RM_RY * RM_WY);
+  const int ry = nseg == 4 ? RM_RY : (g_rm_ry2 > 0 ? g_rm_ry2 : 4);
+  g.nty = (box.n1() + ry * RM_WY - 1) / (ry * RM_WY);
   // 512^3 (64 tiles of 8 rows per layer): 64-plane chunks = 512 workgroups, two even rounds over the 256 CUs (one workgroup per CU at 256
-  // VGPRs): 0.565 / 0.578 ms on a fast / slow box; 32 or 128 planes +0.5 %, chunk lengths that leave a ragged last round (48, 86) +4..15 %
-  int zc = g_rm_zc > 0 ? g_rm_zc : 64;
+  // VGPRs): 0.565 / 0.578 ms on a fast / slow box; 32 or 128 planes +0.5 %, chunk lengths that leave a ragged last round (48, 86) +4..15 %.
+  // 256^3 (16 tiles of 16 rows per layer): 16-plane chunks = 256 workgroups, one round
+  int zc = g_rm_zc > 0 ? g_rm_zc : (nseg == 4 ? 64 : 16);
   if (zc > box.n2()) zc = box.n2();
   g.zc = zc;
   g.ntz = (box.n2() + zc - 1) / zc;
   g.remap = g_rm_remap >= 0 ? g_rm_remap : 2;
   dim3 block(64, RM_WY, 1), grid(g.nty * g.ntz, 1, 1);
-  hipLaunchKernelGGL((k_stencil7_rowmarch<MODE, ORDER, RM_RY, RM_WY>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  if (nseg == 4) hipLaunchKernelGGL((k_stencil7_rowmarch<MODE, ORDER, RM_RY, RM_WY, 4>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  else if (ry == 2) hipLaunchKernelGGL((k_stencil7_rowmarch<MODE, ORDER, 2, RM_WY, 2>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+  else hipLaunchKernelGGL((k_stencil7_rowmarch<MODE, ORDER, 4, RM_WY, 2>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
   return (int)grid.x * RM_WY;
 }
 
@@ -675,8 +683,8 @@ static thread_local int g_zm_blocks = -1, g_zm_minchunk = -1, g_zm_remap = -1, g
 template <int MODE, int ORDER>
 static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &lf, const double *rhs, const LayoutDev &ld,
                          double *dst, const Coef7 &k, double w, const Box &box, hipStream_t s, int colour = -1, int max_waves = 0) {
-  if (rowmarch_wanted<MODE>(box, colour) && rowmarch_layout(lu, lf, ld)) {
-    if (MODE != ZM_RESNORM) return launch_rowmarch<MODE == ZM_RESNORM ? EXAMG_RESIDUAL : MODE, ORDER>(lu, u, lf, rhs, ld, dst, k, w, box, s);
+  if (const int nseg = rowmarch_wanted<MODE>(box, colour); nseg && rowmarch_layout(lu, lf, ld)) {
+    if (MODE != ZM_RESNORM) return launch_rowmarch<MODE == ZM_RESNORM ? EXAMG_RESIDUAL : MODE, ORDER>(nseg, lu, u, lf, rhs, ld, dst, k, w, box, s);
   }
   ZMarchGeom g;
   // Padded layouts (`align`, field/ir/IR_AddPaddingToFieldLayouts.scala:36-41) have even row lengths and put the lower duplicate
@@ -749,6 +757,8 @@ extern "C" int examg_debug_zmarch(int blocks, int minchunk, int remap) {
   return 0;
 }
 extern "C" int examg_debug_rowmarch(int on, int zc, int remap) {
+  g_rm_ry2 = -1;
+  if (on >= 10) { g_rm_ry2 = on - 10; on = 1; }      // 12 / 14: the two-segment form with 2 / 4 rows per wave
   g_rm_on = on;
   g_rm_zc = zc;
   g_rm_remap = remap;

@@ -72,9 +72,13 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
     communicator.  `run()` executes `Function Application`; printed lines are collected in `self.out`."""
 
     def __init__(self, text: str, knowledge: Optional[Dict] = None, ops=None, domain: Optional[RectDomain] = None, comm=None,
-                 echo: bool = False, fuse: bool = True, fuse_coarse_solver: Optional[bool] = None):
+                 echo: bool = False, fuse: bool = True, fuse_coarse_solver: Optional[bool] = None, auto_graph: Optional[bool] = None):
         """fuse: run red-black sweeps and pairs of slotted Jacobi steps as single passes over HBM where the program's
-        statements allow it (bit-identical results; `fuse=False` issues exactly one launch per loop statement)."""
+        statements allow it (bit-identical results; `fuse=False` issues exactly one launch per loop statement).
+        auto_graph: a leveled function without parameters whose statements never return to the host (no reductions, prints or
+        builtins anywhere below it: typically the cycle function) is recorded into a hipGraph at its second call and replayed from
+        then on -- the launch sequence of such a call is fixed once the peepholes and fusions have run, so the interpreter's host
+        work is paid once (default: on with `fuse` on the HIP kernel layer, one block)."""
         self.ast = Parser(text).parse()
         self.k = dict(knowledge or {})
         d = _knowledge.derive(self.k)
@@ -123,6 +127,13 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
         # csrc/kernels_small.hip below), blocks with neighbours keep 64 (interior + shell split)
         self.fuse_min_row = 3
         self.fuse_min_row_blocks = 64
+        on_gpu = hasattr(ops, "torch") and getattr(getattr(ops, "device", None), "type", "cpu") != "cpu"
+        self.auto_graph = bool((fuse if auto_graph is None else auto_graph) and on_gpu and domain.world_size == 1 and not any(domain.periodic))
+        self._auto_graphs: Dict[Tuple[str, int], object] = {}     # (function, level) -> recorded graph | False (not capturable)
+        self._auto_calls: Dict[Tuple[str, int], int] = {}
+        self._host_free: Dict[Tuple[str, int], bool] = {}
+        self._graph_depth = 0
+        self.graph_replays = 0
         self._alt: Dict[Tuple[str, int, int], object] = {}
         self._alt_shell: Dict[Tuple[str, int, int], int] = {}
         self._bc_epoch: Dict[Tuple[str, int], int] = {}
@@ -507,6 +518,9 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
 
     def call(self, name: str, lvl: Optional[int] = None, args: Sequence = (), caller: Optional[_Frame] = None):
         fn = self._resolve(name, lvl)
+        if self.auto_graph and self._graph_depth == 0 and fn.levels is not None and not fn.params and not args and \
+                self._is_host_free(name, lvl) and self._call_through_graph(name, lvl):
+            return None
         if self.fuse_coarse_solver and fn.levels is not None and lvl == self.min_level and not fn.params:
             plan = self._coarse_cg_plan(fn, lvl)
             if plan is not None:
@@ -524,6 +538,113 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
             if not self._cont:
                 self._flush_pending()     # back at the caller of the interpreter: every field holds what the program says
         return None
+
+    # -- functions that never return to the host, replayed from a hipGraph (auto_graph) -----------------------------------------------
+    def _is_host_free(self, name: str, lvl: int) -> bool:
+        """Can a call of this leveled function be issued without ever looking at a device value or doing host-visible work?  Decided
+        from the program text: loops without reductions, `communicate` / `apply bc` / `advance`, repeats with literal counts, colour
+        blocks, conditions and scalar statements without calls or field accesses, calls of functions that qualify themselves -- and
+        the coarsest-level function when it is the generated CG solver (one kernel)."""
+        key = (name, lvl)
+        if key in self._host_free:
+            return self._host_free[key]
+        self._host_free[key] = False          # recursion at the same level: no
+        try:
+            fn = self._resolve(name, lvl)
+            ok = fn.levels is not None and not fn.params
+            if ok and self.fuse_coarse_solver and lvl == self.min_level and self._coarse_cg_plan(fn, lvl) is not None:
+                ok = True
+            elif ok:
+                ok = self._host_free_body(fn.body, lvl)
+        except (Exa4SyntaxError, Exa4Unsupported, KeyError, IndexError, TypeError):
+            ok = False
+        self._host_free[key] = ok
+        return ok
+
+    def _host_free_body(self, stmts, lvl: int) -> bool:
+        def pure(e) -> bool:      # an expression without calls and field accesses
+            if isinstance(e, (list, tuple)):
+                if len(e) >= 1 and e[0] in ("call", "fld") and len(e) >= 4:
+                    return False
+                return all(pure(x) for x in e)
+            return True
+
+        for s in stmts:
+            k = s[0]
+            if k == "loop":
+                if s[4] is not None:
+                    return False
+            elif k in ("comm", "applybc", "advance"):
+                continue
+            elif k == "repeat":
+                if s[1][0] != "num" or s[2] is not None or not self._host_free_body(s[3], lvl):
+                    return False
+            elif k == "color":
+                if not self._host_free_body(s[2], lvl):
+                    return False
+            elif k == "levelscope":
+                if lvl in self.levels_of(s[1], lvl) and not self._host_free_body(s[2], lvl):
+                    return False
+            elif k == "if":
+                if not pure(s[1]) or not self._host_free_body(s[2], lvl) or not self._host_free_body(s[3] or [], lvl):
+                    return False
+            elif k in ("decl", "assign"):
+                e = s[2] if k == "decl" else s[3]
+                if e is not None and not pure(e):
+                    return False
+            elif k == "callstmt":
+                c = s[1]
+                if c[0] != "call" or c[1] not in self.functions or c[3]:
+                    return False
+                clvl = self._level_of(c[2], _Frame(lvl, {})) if c[2] is not None else lvl
+                if not self._is_host_free(c[1], clvl):
+                    return False
+            else:
+                return False
+        return True
+
+    def _call_through_graph(self, name: str, lvl: int) -> bool:
+        """True if the call was issued as a graph replay.  First call: interpreted (lazily created arrays come into being); second
+        call: recorded -- the interpreter runs the function under a stream capture, nothing executes -- and replayed once;
+        afterwards: replayed, as long as every array is in the role it had when the graph was recorded."""
+        torch = self.ops.torch
+        key = (name, lvl)
+        rec = self._auto_graphs.get(key)
+        if rec is False or torch.cuda.is_current_stream_capturing():
+            return False
+        if rec is None:
+            n = self._auto_calls[key] = self._auto_calls.get(key, 0) + 1
+            if n < 2:
+                return False
+            self._flush_pending()
+            before, l0, f0 = self._roles(), self.launches, dict(self.fusions)
+            g = torch.cuda.CUDAGraph()
+            self._graph_depth += 1
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    fn = self._resolve(name, lvl)
+                    self._exec_block(fn.body, _Frame(lvl, {}), fn=True)
+                ok = self._pending is None and self._roles() == before
+            except (RuntimeError, Exa4Unsupported, _Return):
+                ok = False
+            finally:
+                self._graph_depth -= 1
+            recorded, fused = self.launches - l0, {k: v - f0.get(k, 0) for k, v in self.fusions.items()}
+            self.launches, self.fusions = l0, f0
+            if not ok:
+                self._pending = None          # whatever the aborted recording left pending was never issued: the real call follows
+                self._auto_graphs[key] = False
+                return False
+            rec = self._auto_graphs[key] = {"graph": g, "roles": before, "launches": recorded, "fusions": fused}
+        if self._roles() != rec["roles"]:
+            return False                      # arrays swapped roles since (an odd number of out-of-place sweeps elsewhere): interpret
+        self._flush_pending()
+        rec["graph"].replay()
+        self.launches += rec["launches"]
+        for k, v in rec["fusions"].items():
+            self.fusions[k] = self.fusions.get(k, 0) + v
+        self.graph_replays += 1
+        return True
 
     # -- hipGraph capture of a function call ----------------------------------------------------------------------------------
     def _roles(self):

@@ -102,6 +102,8 @@ def _st_const(nd, shape, kind):
 def test_stencil_loops_on_split_fields(hip, orc, nd, shape, kind, b, e, mode, colour):
     """`loop over` with a stencil convolution -- half sweeps of both colours, Jacobi step, residual, A * u -- with Solution, RHS and the
     destination under the colour split: transformed back, the bits of the oracle's loop on the plain layout."""
+    if kind == "27" and colour >= 0:
+        pytest.skip("an in-place colour loop of a 27-point stencil reads points of its own colour: order-dependent on any layout")
     lu, lf = FieldLayout.node(nd, shape, 1), FieldLayout.node(nd, shape, 0)
     if b is None:
         b = [1 if d < nd else 0 for d in range(3)]

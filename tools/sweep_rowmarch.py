@@ -44,7 +44,10 @@ for n in [int(a) for a in sys.argv[1:]] or [512]:
     for _ in range(150):
         ops.stencil_op(2, Ls, u, Fs, f, Ls, un, A, w, -1, b, e)
     res = {}
-    cfgs = [(0, -1, -1)] + [(1, zc, rm) for zc in (32, 48, 64, 86, 128, 171) for rm in (2, 0)]
+    if n > 300:
+        cfgs = [(0, -1, -1)] + [(1, zc, rm) for zc in (32, 48, 64, 86, 128, 171) for rm in (2, 0)]
+    else:      # two-segment form (rows of 144 .. 256 points): on = 12 / 14 -> 2 / 4 rows per wave
+        cfgs = [(0, -1, -1)] + [(on, zc, rm) for on in (12, 14) for zc in (8, 16, 32, 64, 128) for rm in (2, 0)]
     for rnd in range(3):
         for cfg in cfgs:
             L.examg_debug_rowmarch(*cfg)
