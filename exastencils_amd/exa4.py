@@ -603,6 +603,25 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
                 return False
         return True
 
+    def _host_state(self):
+        """What executing statements changes on the HOST side (boundary bookkeeping, second arrays, slots): saved before a function is
+        recorded, put back if the recording is discarded (its launches were never issued)."""
+        return {"bc_valid": set(self._bc_valid), "bc_epoch": dict(self._bc_epoch), "alt": dict(self._alt), "alt_shell": dict(self._alt_shell),
+                "pair_tmp": dict(self._pair_tmp), "sf_dirty": dict(self._sf_dirty), "sf_rec": dict(self._sf_rec),
+                "fields": {k: (list(f.slots), f.current_slot) for k, f in self.fields.items()},
+                "cg": (getattr(self, "_cg_tail", None), getattr(self, "_cg_info", None))}
+
+    def _restore_host_state(self, st):
+        self._bc_valid, self._bc_epoch, self._alt, self._alt_shell = st["bc_valid"], st["bc_epoch"], st["alt"], st["alt_shell"]
+        self._pair_tmp, self._sf_dirty, self._sf_rec = st["pair_tmp"], st["sf_dirty"], st["sf_rec"]
+        for k, (slots, cur) in st["fields"].items():
+            self.fields[k].slots, self.fields[k].current_slot = slots, cur
+        for attr, v in zip(("_cg_tail", "_cg_info"), st["cg"]):
+            if v is None and hasattr(self, attr):
+                delattr(self, attr)
+            elif v is not None:
+                setattr(self, attr, v)
+
     def _call_through_graph(self, name: str, lvl: int) -> bool:
         """True if the call was issued as a graph replay.  First call: interpreted (lazily created arrays come into being); second
         call: recorded -- the interpreter runs the function under a stream capture, nothing executes -- and replayed once;
@@ -618,21 +637,25 @@ class Exa4Program(LazyFusions, Peepholes, Builtins):
                 return False
             self._flush_pending()
             before, l0, f0 = self._roles(), self.launches, dict(self.fusions)
+            saved = self._host_state()
             g = torch.cuda.CUDAGraph()
             self._graph_depth += 1
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     fn = self._resolve(name, lvl)
                     self._exec_block(fn.body, _Frame(lvl, {}), fn=True)
-                ok = self._pending is None and self._roles() == before
+                    self._flush_pending()     # a loop the function leaves pending for its caller's next statement: issued here
+                ok = self._roles() == before
             except (RuntimeError, Exa4Unsupported, _Return):
                 ok = False
             finally:
                 self._graph_depth -= 1
             recorded, fused = self.launches - l0, {k: v - f0.get(k, 0) for k, v in self.fusions.items()}
             self.launches, self.fusions = l0, f0
-            if not ok:
-                self._pending = None          # whatever the aborted recording left pending was never issued: the real call follows
+            if not ok or recorded == 0:
+                # nothing of the recording was issued: the interpreter's bookkeeping goes back to where it was, the real call follows
+                self._pending = None
+                self._restore_host_state(saved)
                 self._auto_graphs[key] = False
                 return False
             rec = self._auto_graphs[key] = {"graph": g, "roles": before, "launches": recorded, "fusions": fused}

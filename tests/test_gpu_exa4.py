@@ -51,6 +51,24 @@ def test_rbgs_program_on_gpu(hip):
     assert np.array_equal(hip.to_host(N.fields[("u", 7)].data()), hip.to_host(P.fields[("u", 7)].data()))
 
 
+def test_cycle_function_replays_from_a_graph(hip):
+    """auto_graph: `Cycle@finest ( )` -- no reduction, print or builtin anywhere below it, the coarsest level's generated CG as one
+    kernel -- is recorded into a hipGraph at its second call of the Solve loop and replayed from the third on: the printed residuals and
+    the fields are those of the interpreted program, bit for bit; functions that return to the host (Norm) are never recorded."""
+    from test_exa4 import example
+
+    plain = example("poisson3d_rbgs.exa4", 2, 7, ops=hip, auto_graph=False)
+    plain.run()
+    P = example("poisson3d_rbgs.exa4", 2, 7, ops=hip)
+    assert P.auto_graph
+    P.run()
+    assert P.printed_values == plain.printed_values and len(P.printed_values) > 4
+    assert P.graph_replays >= len(P.printed_values) - 2
+    assert isinstance(P._auto_graphs.get(("Cycle", 7)), dict) and ("Norm", 7) not in P._auto_graphs
+    assert P.launches == plain.launches                  # the recorded launches are counted per replay
+    assert np.array_equal(hip.to_host(P.fields[("u", 7)].data()), hip.to_host(plain.fields[("u", 7)].data()))
+
+
 def test_native_rand_fill_on_gpu(hip):
     """The host-generated std::rand() start values (tests/test_exa4.py: glibc's sequence) reach the device field unchanged."""
     from oracle_ops import OracleOps
