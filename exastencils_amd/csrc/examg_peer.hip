@@ -530,9 +530,11 @@ extern "C" size_t examg_comm_peer_gather_bytes(const examg_comm_t *comm) { retur
 extern "C" int examg_comm_status(examg_comm_t *comm, examg_stream_t stream) {
   if (!comm) { set_error("examg_comm_status: null argument"); return 1; }
   if (!comm->peer) return 0;
-  if (check_hip(hipStreamSynchronize((hipStream_t)stream), "examg_comm_status")) return 1;
   unsigned long long err = 0;
-  if (check_hip(hipMemcpy(&err, &comm->peer->loc->err, sizeof(err), hipMemcpyDeviceToHost), "examg_comm_status")) return 1;
+  // on `stream`, not on the legacy stream: a host with several blocks per process may be recording a graph on another thread's stream
+  if (check_hip(hipMemcpyAsync(&err, &comm->peer->loc->err, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream), "examg_comm_status") ||
+      check_hip(hipStreamSynchronize((hipStream_t)stream), "examg_comm_status"))
+    return 1;
   if (err == 0) return 0;
   static const char *kind[] = {"?", "send waited for the acknowledgement of its slab", "receive waited for a message", "all-reduce waited for rank",
                                "all-gather send waited for the acknowledgement of rank", "all-gather waited for the piece of rank"};

@@ -24,6 +24,7 @@ struct StencilDev {
   long long cpt;     // stride between points: 1, or nent under the entry-fastest transformation
   int wdiv;          // smoother weight of a stencil field: 0 (1.0 / diag) * w, 1 w / diag (EXAMG_WEIGHT_*)
   signed char o[EXAMG_MAX_ENTRIES][3];   // entry offsets per dimension: u under a layout transformation has no linear entry offsets
+  long long ro[EXAMG_MAX_ENTRIES];       // ... the y / z part of an entry's offset (row and plane strides of the half arrays)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -35,11 +36,20 @@ k_stencil_generic(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
                   double *dst, LayoutDev lc, StencilDev st, double w, int colour, Box box, int row_w) {
   const long long rows = (long long)box.n1() * box.n2();
   const long long total = rows * row_w;
+  const bool small = total < (1LL << 31);      // 32-bit index arithmetic (wave-uniform choice; same indices)
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-    const long long row = t / row_w;
-    const int c0 = (int)(t - row * row_w);
-    const int i1 = box.b1 + (int)(row % box.n1());
-    const int i2 = box.b2 + (int)(row / box.n1());
+    int c0, i1, i2;
+    if (small) {
+      const unsigned tt = (unsigned)t, row = tt / (unsigned)row_w, q = row / (unsigned)box.n1();
+      c0 = (int)(tt - row * (unsigned)row_w);
+      i1 = box.b1 + (int)(row - q * (unsigned)box.n1());
+      i2 = box.b2 + (int)q;
+    } else {
+      const long long row = t / row_w;
+      c0 = (int)(t - row * row_w);
+      i1 = box.b1 + (int)(row % box.n1());
+      i2 = box.b2 + (int)(row / box.n1());
+    }
     int i0;
     if (colour >= 0) {
       // points of this row with (i0+i1+i2) % 2 == colour, no idle lanes
@@ -54,18 +64,25 @@ k_stencil_generic(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
     if (lu.half) {
       // u under the colour split (EXAMG_LAYOUT_SPLIT_X): every neighbour through the transformed index -- the points of one colour of a
       // row, and their x neighbours in the other half array, are contiguous across the lanes.  Same products, same order.
+      // index of entry k's point: x through the split (column ax + dx lives at (ax + dx) / 2 of half (ax + dx) % 2), y and z by strides
+      const int ax = i0 + lu.ref0;
+      const long long rowb = lu.s1 * (i1 + lu.ref1) + lu.s2 * (i2 + lu.ref2);
+      auto un = [&](int k) {
+        const int a = ax + st.o[k][0];
+        return u[(a >> 1) + (long long)(a & 1) * lu.half + rowb + st.ro[k]];
+      };
       if (st.cfield) {
         const long long ic = lidx(lc, i0, i1, i2) * st.cpt;
-        acc = st.cfield[ic] * u[lidx(lu, i0 + st.o[0][0], i1 + st.o[0][1], i2 + st.o[0][2])];
-        for (int k = 1; k < st.nent; ++k) acc = acc + st.cfield[ic + k * st.cplane] * u[lidx(lu, i0 + st.o[k][0], i1 + st.o[k][1], i2 + st.o[k][2])];
+        acc = st.cfield[ic] * un(0);
+        for (int k = 1; k < st.nent; ++k) acc = acc + st.cfield[ic + k * st.cplane] * un(k);
         if (MODE == EXAMG_SMOOTH) {
           const double dg = st.cfield[ic + st.diag * st.cplane];
           const double ww = st.wdiv ? w / dg : (1.0 / dg) * w;
           acc = u[iu] + ww * (rhs[lidx(lf, i0, i1, i2)] - acc);
         }
       } else {
-        acc = st.coef[0] * u[lidx(lu, i0 + st.o[0][0], i1 + st.o[0][1], i2 + st.o[0][2])];
-        for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * u[lidx(lu, i0 + st.o[k][0], i1 + st.o[k][1], i2 + st.o[k][2])];
+        acc = st.coef[0] * un(0);
+        for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * un(k);
         if (MODE == EXAMG_SMOOTH) acc = u[iu] + w * (rhs[lidx(lf, i0, i1, i2)] - acc);
       }
     } else if (st.cfield) {
@@ -646,7 +663,9 @@ static int rowmarch_wanted(const Box &box, int colour) {
   if (g_rm_on == 0) return 0;
   const int nseg = (box.n0() >= 400 && box.n0() <= 512) ? 4 : ((box.n0() >= 144 && box.n0() <= 256) ? 2 : 0);
   if (g_rm_on == 1) return nseg;
-  return (box.n1() >= 64 && box.n2() >= 16) ? nseg : 0;
+  // rows of 144 .. 256 points (256^3 blocks): measured, no gain -- 0.0715 ms (two rows per wave, 16-plane chunks) / 0.0731 (four rows)
+  // against 0.0713 for the window kernel (tools/sweep_rowmarch.py 256, profiles/NOTES.md): the two-segment form stays a debug variant
+  return (nseg == 4 && box.n1() >= 64 && box.n2() >= 16) ? nseg : 0;
 }
 // padded layouts (even strides) keep the window kernel: it starts its windows on a 16-byte boundary there and every access is
 // aligned already (512^3, 544-double rows: 0.570 ms against 0.589 for the row-marching kernel)
@@ -671,8 +690,12 @@ static int launch_rowmarch(int nseg, const LayoutDev &lu, const double *u, const
   g.remap = g_rm_remap >= 0 ? g_rm_remap : 2;
   dim3 block(64, RM_WY, 1), grid(g.nty * g.ntz, 1, 1);
   if (nseg == 4) hipLaunchKernelGGL((k_stencil7_rowmarch<MODE, ORDER, RM_RY, RM_WY, 4>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+#ifdef EXAMG_DEBUG_HOOKS
   else if (ry == 2) hipLaunchKernelGGL((k_stencil7_rowmarch<MODE, ORDER, 2, RM_WY, 2>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
   else hipLaunchKernelGGL((k_stencil7_rowmarch<MODE, ORDER, 4, RM_WY, 2>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, k, w, box, g);
+#else
+  else { (void)ry; return -1; }
+#endif
   return (int)grid.x * RM_WY;
 }
 
@@ -889,6 +912,7 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
     sd.uo[k] = st->off[k][0] + lu.s1 * st->off[k][1] + lu.s2 * st->off[k][2];
     sd.coef[k] = st->coef[k];
     for (int d = 0; d < 3; ++d) sd.o[k][d] = (signed char)st->off[k][d];
+    sd.ro[k] = lu.s1 * st->off[k][1] + lu.s2 * st->off[k][2];
   }
   sd.cfield = st->cfield;
   LayoutDev lc = lu;

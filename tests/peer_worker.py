@@ -187,6 +187,7 @@ def run_rank(rank, world, blocks, out, dist, dist_module):
     cfg = ConfigL4(nd=3, min_level=cy["min_level"], max_level=L, frag_len=flen, tol=cy["tol"], fused_rbgs=True, fused_residual_restrict=True,
                    agglomerate_level=cy["agglomerate_level"], fused_residual_norm=True, agglomerate_extra_levels=cy.get("extra", 0))
     P = SolverFromL4(cfg, ops, dom, comm)
+    dist.barrier()        # (hosted ranks: the constructor records the agglomerated levels' graph; no rank of the process goes on before all have)
     P.setup()
     its = P.Solve()
     comm.check()
@@ -194,6 +195,7 @@ def run_rank(rank, world, blocks, out, dist, dist_module):
     arrays["cycle_eager"] = owned(P.Solution[L].data(), P.Solution[L].layout, nc)
     P.reset()
     P.capture_cycle()
+    dist.barrier()
     P.reset()
     its = P.Solve(use_graph=True)
     comm.check()
