@@ -184,6 +184,10 @@ class Communicator:
         self.ops.synchronize()
         if self.dist is not None:
             self.dist.barrier(group=self.group)
+        # every rank unmaps its neighbours' regions BEFORE any rank frees its own
+        _lib.check(L.examg_comm_peer_release(self._c), "examg_comm_peer_release")
+        if self.dist is not None:
+            self.dist.barrier(group=self.group)
         hbuf = (C.c_ubyte * _lib.PEER_HANDLE_BYTES)()
         _lib.check(L.examg_comm_peer_alloc(self._c, new_s, new_g, hbuf), "examg_comm_peer_alloc")
         n = self.domain.world_size

@@ -492,6 +492,15 @@ extern "C" int examg_comm_peer_alloc(examg_comm_t *comm, size_t slab_bytes, size
   return 0;
 }
 
+// First step of growing the regions: give up the mappings of the OTHER ranks' regions.  Every rank calls it, then a host barrier, then
+// examg_comm_peer_alloc -- so that no region is freed by its owner while another process still has it mapped.
+extern "C" int examg_comm_peer_release(examg_comm_t *comm) {
+  if (!comm || !comm->peer) { set_error("examg_comm_peer_release: not a peer-write communicator"); return 1; }
+  if (check_hip(hipDeviceSynchronize(), "examg_comm_peer_release")) return 1;
+  release_mappings(comm->peer, comm->rank, comm->size);
+  return 0;
+}
+
 extern "C" int examg_comm_peer_connect(examg_comm_t *comm, const void *all_handles) {
   if (!comm || !comm->peer || !all_handles) { set_error("examg_comm_peer_connect: not a peer-write communicator / null argument"); return 1; }
   PeerState *p = comm->peer;

@@ -26,11 +26,37 @@ struct StencilCG {
 
 // Block sums with ONE workgroup barrier each: the wave partials go to one of two buffers in turn (a wave can only write buffer k & 1 again,
 // for sum k + 2, after the barrier of sum k + 1, which every wave reaches after it has read buffer k & 1) -- the solver is a chain of
-// barriers, and these sums were 6 of its 7 per iteration.  Fixed tree: 6 shuffle steps per wave, then the 16 partials in wave order.
+// barriers and cross-lane steps, ~32 iterations of it per cycle at config 3.  Fixed tree, the same on every call:
+//   row of 16 lanes: lane 0 += lanes 8, 4, 2, 1 apart (DPP row_shl: a few cycles per step; the ds_bpermute path of __shfl_down costs
+//   ~100 each); wave: the four row sums in row order (v_readlane); workgroup: the 16 wave sums in wave order.
 constexpr int CG_SM = 4 * (CG_THREADS / 64);      // two buffers of up to two sums
+
+__device__ __forceinline__ double cg_row_shl(double v, int n) {     // lane l of a row receives lane l + n of the same row, 0.0 beyond it
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  switch (n) {
+    case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x108, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x108, 0xF, 0xF, true); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xF, 0xF, true); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x102, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x102, 0xF, 0xF, true); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xF, 0xF, true); break;
+  }
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double cg_wave_sum(double v) {           // the same value in every lane
+  v = v + cg_row_shl(v, 8);
+  v = v + cg_row_shl(v, 4);
+  v = v + cg_row_shl(v, 2);
+  v = v + cg_row_shl(v, 1);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  double r = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  r = r + __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  r = r + __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  r = r + __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return r;
+}
+
 __device__ __forceinline__ double cg_block_sum(double v, double *sm, int &turn) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = v + __shfl_down(v, o);
+  v = cg_wave_sum(v);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double *b = sm + (turn & 1) * 2 * (CG_THREADS / 64);
   ++turn;
@@ -43,11 +69,8 @@ __device__ __forceinline__ double cg_block_sum(double v, double *sm, int &turn) 
 
 // two sums behind one barrier (each with the tree of cg_block_sum: same bits as two calls)
 __device__ __forceinline__ void cg_block_sum2(double &v0, double &v1, double *sm, int &turn) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    v0 = v0 + __shfl_down(v0, o);
-    v1 = v1 + __shfl_down(v1, o);
-  }
+  v0 = cg_wave_sum(v0);
+  v1 = cg_wave_sum(v1);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double *b = sm + (turn & 1) * 2 * (CG_THREADS / 64);
   ++turn;

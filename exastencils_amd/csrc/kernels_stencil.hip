@@ -635,6 +635,80 @@ k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Red-black half sweep on the COLOUR-SPLIT layout (EXAMG_LAYOUT_SPLIT_X: `transform Solution with [x, y, z] => [x / 2, y, z, x % 2]`,
+// Testing/LayoutTrafo/rbgs.exa4:2), 3-D 7-point constant stencil, in place.
+// The points of one colour of a row are the even OR the odd columns: one of the two half rows, contiguous -- and so are their x
+// neighbours (the other half row) and the values written.  A lane owns one column pair h (columns 2h, 2h + 1) of a row and marches in z
+// with both halves of its pair for the planes z-1, z, z+1 in registers; the half that is updated alternates from plane to plane.  Per
+// update: the pair of plane z+1 (16 B, streamed once), the two y neighbours of the updated half (L2: they are the pairs of the rows
+// above and below, loaded a plane earlier by their waves), the right-hand side and the store (8 B each): 32 B instead of the 48 B a
+// half sweep moves in the untransformed layout.  The x neighbour outside the pair comes from the adjacent lane (DPP wave shift).
+// Arithmetic: conv7 / finish<EXAMG_SMOOTH> -- the loop's own expression, bit-identical to the generic kernel on either layout.
+// ---------------------------------------------------------------------------------------------
+struct SplitGeom {
+  int hb, nh;        // first column pair of the box, number of column pairs (both parities)
+  int ntx, nty, zc;  // windows of 64 pairs, tiles of SP_WY rows, planes per chunk
+  int ax0, ax1;      // array x range of the box
+};
+constexpr int SP_WY = 4;
+
+template <int ORDER>
+__global__ void __launch_bounds__(64 * SP_WY)
+k_rbgs_half_split7(LayoutDev lu, double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs, Coef7 k, double w, Box box, int colour,
+                   SplitGeom g) {
+  const int lane = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  int t = blockIdx.x;
+  const int tx = t % g.ntx;
+  t /= g.ntx;
+  const int ty = t % g.nty, tz = t / g.nty;
+  const int y = box.b1 + ty * SP_WY + wv;
+  if (y >= box.e1) return;                       // wave-uniform
+  const int mb = box.b2 + tz * g.zc, me = min(mb + g.zc, box.e2);
+  const int h = g.hb + 64 * tx + lane;           // this lane's column pair
+  const int hc = min(h, (int)lu.s1 - 1);         // clamped for loads (lanes beyond the row are never stored)
+  double *E = u, *O = u + lu.half;
+  const long long rowy = lu.s1 * (y + lu.ref1);
+  auto at = [&](int z) { return rowy + lu.s2 * (z + lu.ref2) + hc; };
+  double Em = E[at(mb - 1)], Om = O[at(mb - 1)], Ec = E[at(mb)], Oc = O[at(mb)];
+  double Ep = E[at(mb + 1)], Op = O[at(mb + 1)];
+  const bool first_lane = lane == 0, last_lane = lane == 63;
+  for (int z = mb; z < me; ++z) {
+    // parity of the array column of this row's updated points: (i0 + y + z) % 2 == colour with i0 = ax - ref0
+    const int p = (colour + y + z + lu.ref0) & 1;          // wave-uniform
+    const long long a = at(z);
+    double *P = p ? O : E;
+    const double *Q = p ? E : O;
+    const double c = p ? Oc : Ec, q = p ? Ec : Oc, zm = p ? Om : Em, zp = p ? Op : Ep;
+    const double ym = P[a - lu.s1], yp = P[a + lu.s1];
+    // next plane's pair (in flight during this step)
+    const long long an = at(min(z + 2, box.e2));          // (the plane beyond the box's shell is never used)
+    const double En = E[an], On = O[an];
+    // x neighbours: even column 2h: columns 2h - 1 = O[h - 1], 2h + 1 = O[h]; odd column 2h + 1: columns 2h = E[h], 2h + 2 = E[h + 1]
+    double xm, xp;
+    if (p == 0) {
+      xm = lane_below(q);
+      if (first_lane) xm = Q[a - 1];
+      xp = q;
+    } else {
+      xm = q;
+      xp = lane_above(q);
+      if (last_lane) xp = Q[min(a + 1, rowy + lu.s2 * (z + lu.ref2) + lu.s1 - 1)];
+    }
+    const int ax = 2 * h + p;
+    if (ax >= g.ax0 && ax < g.ax1) {
+      const double f = rhs[lidx(lf, ax - lu.ref0, y, z)];
+      const double acc = conv7<ORDER>(k, c, xm, xp, ym, yp, zm, zp);
+      const double v = finish<EXAMG_SMOOTH>(c, acc, f, w);
+      P[a] = v;                                   // (no later step of this sweep reads a point of the colour it updates)
+    }
+    Em = Ec; Om = Oc;
+    Ec = Ep; Oc = Op;
+    Ep = En; Op = On;
+  }
+}
+
 static thread_local int g_force_generic = 0;  // test hook (debug build only): examg_debug_force_generic
 // workgroup cap of the unrolled stencil-field kernel: none.  One short-lived workgroup per 256 points, dispatched in order, keeps
 // the front that sweeps the 30 streams (27 coefficient planes, u, rhs, dst) narrow: 512^3, 27 entries: 7.8 ms with 16384
@@ -838,6 +912,29 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   if (st->cfield && lay_split(&st->clayout)) { set_error("examg_stencil_op: the coefficient layout of a stencil field cannot be colour-split"); return 1; }
   const bool force_generic = g_force_generic || transformed;
   const int ord = canonical_order7(st);
+  if (transformed && !g_force_generic && mode == EXAMG_SMOOTH && colour >= 0 && u == dst && lay_split(lu_) && memcmp(lu_, ld_, sizeof(*lu_)) == 0 &&
+      lu_->nd == 3 && ord >= 0 && box.n0() >= 32 && box_inside(lu_, box, 1)) {
+    // red-black half sweep on the colour-split layout: 32 B per update (k_rbgs_half_split7); the right-hand side on either layout
+    Coef7 k;
+    for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
+    SplitGeom g;
+    g.ax0 = box.b0 + lu.ref0;
+    g.ax1 = box.e0 + lu.ref0;
+    g.hb = g.ax0 >> 1;
+    g.nh = ((g.ax1 - 1) >> 1) - g.hb + 1;
+    g.ntx = (g.nh + 63) / 64;
+    g.nty = (box.n1() + SP_WY - 1) / SP_WY;
+    // planes per chunk: enough workgroups for the chip (>= 2048), chunks of at least 16 planes (two planes of start-up each)
+    int zc = box.n2();
+    while (zc > 16 && (long long)g.ntx * g.nty * ((box.n2() + zc - 1) / zc) < 2048) zc = (zc + 1) / 2;
+    g.zc = zc;
+    const int ntz = (box.n2() + zc - 1) / zc;
+    dim3 block(64, SP_WY, 1), grid((unsigned)(g.ntx * g.nty * ntz), 1, 1);
+    if (ord == 0) hipLaunchKernelGGL((k_rbgs_half_split7<0>), grid, block, 0, s, lu, dst, lf, rhs, k, w, box, colour, g);
+    else hipLaunchKernelGGL((k_rbgs_half_split7<1>), grid, block, 0, s, lu, dst, lf, rhs, k, w, box, colour, g);
+    EXAMG_CHECK_LAUNCH("k_rbgs_half_split7");
+    return 0;
+  }
   const bool colour_ok = colour < 0 || (mode == EXAMG_SMOOTH && u == dst && memcmp(lu_, ld_, sizeof(*lu_)) == 0);
   if (!force_generic && lu_->nd == 3 && ord >= 0 && colour_ok && box.n0() >= 64) {
     Coef7 k;

@@ -77,7 +77,7 @@ SYMBOLS = [
     "examg_comm_unique_id", "examg_comm_create", "examg_comm_destroy", "examg_comm_rank", "examg_comm_size",
     "examg_exchange_workspace_bytes", "examg_exchange", "examg_allreduce", "examg_allgather",
     "examg_jacobi2_blocks", "examg_rbgs_sweep_blocks", "examg_crand_seed", "examg_crand_draw_host",
-    "examg_transform_stencilfield", "examg_transform_field", "examg_layout_size", "examg_residual_restrict_one_pass", "examg_residual_restrict_blocks", "examg_prolong_add_blocks",
+    "examg_transform_stencilfield", "examg_transform_field", "examg_layout_size", "examg_comm_peer_release", "examg_residual_restrict_one_pass", "examg_residual_restrict_blocks", "examg_prolong_add_blocks",
     "examg_comm_create_peer", "examg_comm_peer_alloc", "examg_comm_peer_connect", "examg_comm_peer_slab_bytes",
     "examg_comm_peer_gather_bytes", "examg_comm_status",
 ]

@@ -458,14 +458,16 @@ int examg_allgather(examg_comm_t *comm, const double *send, double *recv, int64_
  *                                                                  gather_bytes >= the largest examg_allgather piece (0: none)
  *   <all-gather the EXAMG_PEER_HANDLE_BYTES of every rank by the host's own means: MPI_Allgather, torch.distributed, files>
  *   examg_comm_peer_connect(c, all_handles);
- * To grow the slabs later: synchronise the device on every rank, host barrier, then alloc / gather / connect again (sequence
- * numbers restart).  The workspace arguments of examg_exchange / examg_*_blocks are ignored (may be NULL).  A wait that sees no
+ * To grow the slabs later: synchronise the device on every rank, host barrier, examg_comm_peer_release on every rank (no region is
+ * freed while a neighbour still maps it), host barrier, then alloc / gather / connect again (sequence numbers restart).  The workspace arguments of examg_exchange / examg_*_blocks are ignored (may be NULL).  A wait that sees no
  * progress for EXAMG_PEER_TIMEOUT_MS (default 120000) gives up, makes every later wait return at once and is reported by
  * examg_comm_status() -- a lost neighbour never leaves a kernel spinning. */
 #define EXAMG_PEER_HANDLE_BYTES 128
 int examg_comm_create_peer(examg_comm_t **comm, int nranks, int rank);
 int examg_comm_peer_alloc(examg_comm_t *comm, size_t slab_bytes, size_t gather_bytes, void *handle_out /* EXAMG_PEER_HANDLE_BYTES */);
 int examg_comm_peer_connect(examg_comm_t *comm, const void *all_handles /* nranks x EXAMG_PEER_HANDLE_BYTES, rank order */);
+/* growing: examg_comm_peer_release on every rank (unmaps the other ranks' regions), host barrier, then alloc / gather / connect */
+int examg_comm_peer_release(examg_comm_t *comm);
 size_t examg_comm_peer_slab_bytes(const examg_comm_t *comm);
 size_t examg_comm_peer_gather_bytes(const examg_comm_t *comm);
 /* synchronises `stream`, then 0 if no wait of the peer-write transport has given up (always 0 for RCCL communicators) */

@@ -95,6 +95,8 @@ def _st_const(nd, shape, kind):
 @pytest.mark.parametrize("nd,shape,kind,b,e", [
     (3, (40, 20, 12), "star", None, None),            # 3-D 7-point
     (3, (33, 17, 9), "star", [0, 1, 0], [34, 17, 10]),  # odd rows, loop over duplicate planes (interior faces)
+    (3, (200, 12, 40), "star", None, None),           # several 64-pair windows, z chunks (k_rbgs_half_split7)
+    (3, (131, 9, 7), "star", [0, 0, 0], [132, 10, 8]),  # every face an interior face: first column pair at array index 1
     (3, (24, 12, 10), "27", None, None),              # 27-point constant stencil
     (2, (64, 48), "star", None, None),                # 2-D 5-point
     (3, (24, 14, 8), "field7", None, None),           # 7-entry stencil field (coefficients in the plain layout)

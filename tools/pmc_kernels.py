@@ -65,7 +65,7 @@ def cases(ops, level, with27=True, align=0):
         ops.transform_field(L, u, lus.c_struct(), us)
         ops.transform_field(F, f, lfs.c_struct(), fs)
         Ls, Fs = lus.c_struct(), lfs.c_struct()
-        cs.insert(3, ("rbgs_half_sweep_colour_split", lambda: ops.stencil_op(2, Ls, us, Fs, fs, Ls, us, A, w, 0, b, e), "k_stencil_generic<2>",
+        cs.insert(3, ("rbgs_half_sweep_colour_split", lambda: ops.stencil_op(2, Ls, us, Fs, fs, Ls, us, A, w, 0, b, e), "k_rbgs_half_split7",
                       16 * pts, pts // 2))
     if align == 0 and level >= 8:
         # the one-step kernel on the padded layout the reference produces with data_alignFieldPointers (rows of 544 doubles at
