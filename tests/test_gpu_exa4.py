@@ -37,10 +37,14 @@ def test_rbgs_program_on_gpu(hip):
     O = _oracle_a(2, 7)
     _close(P.printed_values, O.res_history, O.res_history[0])   # norms: the device reduction tree sums in another order
     assert P.launches > 100                                      # every launch a kernel-layer call (6 cycles of ~40 launches)
-    plain = example("poisson3d_rbgs.exa4", 2, 7, ops=hip, fuse=False)
+    plain = example("poisson3d_rbgs.exa4", 2, 7, ops=hip, fuse=False, fuse_coarse_solver=True)
     plain.run()
     assert plain.printed_values == P.printed_values              # fused sweeps / cross-statement fusions change no bit
     assert plain.launches > P.launches
+    # the coarsest level's CG statement by statement (its dots through examg_dot: another, equally fixed summation tree): to rounding
+    stmt = example("poisson3d_rbgs.exa4", 2, 7, ops=hip, fuse=False)
+    stmt.run()
+    _close(stmt.printed_values, P.printed_values, P.printed_values[0])
     assert P.fusions["residual_restrict"] > 0
     # opt-in: residual + norm in one pass -- the squares are summed in the residual kernel's order: same fields, norms to rounding
     N = example("poisson3d_rbgs.exa4", 2, 7, ops=hip)
@@ -93,7 +97,7 @@ def test_jacobi_program_on_gpu(hip):
     O = _oracle_b(1, 6)
     _close(P.printed_values, O.res_history, O.res_history[0])
     assert P.out == O.log
-    plain = example("jacobi3d_slots.exa4", 1, 6, ops=hip, fuse=False)
+    plain = example("jacobi3d_slots.exa4", 1, 6, ops=hip, fuse=False, fuse_coarse_solver=True)      # the same coarse solver on both sides
     plain.run()
     assert plain.printed_values == P.printed_values              # paired Jacobi steps change no bit
 

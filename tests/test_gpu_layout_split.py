@@ -237,7 +237,7 @@ def test_program_with_the_colour_split_prints_the_same_values(hip):
     with open(os.path.join(ROOT, "examples", "exa4", "poisson3d_rbgs.exa4")) as fh:
         text = fh.read()
     k = dict(dimensionality=3, minLevel=2, maxLevel=5)
-    plain = exa4.Exa4Program(text, k, ops=hip, fuse=False)
+    plain = exa4.Exa4Program(text, k, ops=hip, fuse=False, fuse_coarse_solver=True)
     plain.run()
     P = exa4.Exa4Program(SPLIT_BLOCK + text, k, ops=hip)
     assert P._split_fields == {("u", 5), ("u", 4), ("f", 5)}
