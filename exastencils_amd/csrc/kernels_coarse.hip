@@ -111,6 +111,13 @@ __device__ __forceinline__ double cg_apply(const StencilCG &st, const LayoutDev 
   return acc;
 }
 
+// A * 0: the convolution's own expression on the constant 0.0 (constant coefficients; a stencil field's zero-start is not offered)
+__device__ __forceinline__ double cg_apply_zero(const StencilCG &st) {
+  double acc = st.coef[0] * 0.0;
+  for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * 0.0;
+  return acc;
+}
+
 struct FaceBoxesCG {
   Box box[6];
   int n;
@@ -143,7 +150,8 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
   double s = 0.0;
   for (int t = threadIdx.x; t < total; t += CG_THREADS) {
     cg_unflatten(box, t, i0, i1, i2);
-    const double r = rhs[lidx(lf, i0, i1, i2)] - cg_apply(st, lu, sol, lc, i0, i1, i2);
+    const double r = rhs[lidx(lf, i0, i1, i2)] - ((flags & EXAMG_CG_ZERO_START) ? cg_apply_zero(st) : cg_apply(st, lu, sol, lc, i0, i1, i2));
+    if (flags & EXAMG_CG_ZERO_START) sol[lidx(lu, i0, i1, i2)] = 0.0;
     res[lidx(lr, i0, i1, i2)] = r;
     s = s + r * r;
   }
@@ -265,8 +273,9 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
       kp[j] = lidx(lp, i0, i1, i2);
       kq[j] = lidx(lq, i0, i1, i2);
       li[j] = (i0 - box.b0 + 1) + (i1 - box.b1 + 1) * ldx + (i2 - box.b2 + 1) * ldxy;
-      r[j] = rhs[lidx(lf, i0, i1, i2)] - cg_apply(st, lu, sol, lu, i0, i1, i2);   // Residual = RHS - Laplace * Solution
-      x[j] = sol[ku[j]];
+      const bool zero = flags & EXAMG_CG_ZERO_START;      // the start is the zero field: nothing of `sol` is read
+      r[j] = rhs[lidx(lf, i0, i1, i2)] - (zero ? cg_apply_zero(st) : cg_apply(st, lu, sol, lu, i0, i1, i2));   // Residual = RHS - Laplace * Solution
+      x[j] = zero ? 0.0 : sol[ku[j]];
       s = s + r[j] * r[j];
     }
   }
@@ -403,7 +412,7 @@ extern "C" int examg_cg_coarse_variant(const examg_layout_t *lu_, double *sol, c
     set_error("examg_cg_coarse: null argument");
     return 1;
   }
-  if (flags & ~(EXAMG_CG_ALPHA_FROM_NORM | EXAMG_CG_NO_BC)) { set_error("examg_cg_coarse_variant: unknown flag"); return 1; }
+  if (flags & ~(EXAMG_CG_ALPHA_FROM_NORM | EXAMG_CG_NO_BC | EXAMG_CG_ZERO_START)) { set_error("examg_cg_coarse_variant: unknown flag"); return 1; }
   if (lay_split(lu_) || lay_split(lf_) || lay_split(lr_) || lay_split(lp_) || lay_split(lq_)) {
     set_error("examg_cg_coarse: fields under a layout transformation are not supported by the one-kernel solver (examg_transform_field)");
     return 1;
@@ -413,6 +422,7 @@ extern "C" int examg_cg_coarse_variant(const examg_layout_t *lu_, double *sol, c
     set_error("examg_cg_coarse: fused coarse solve needs every face on the physical boundary (single fragment)");
     return 1;
   }
+  if ((flags & EXAMG_CG_ZERO_START) && st->cfield) { set_error("examg_cg_coarse_variant: EXAMG_CG_ZERO_START needs constant coefficients"); return 1; }
   const Box box = make_box(begin, end);
   hipStream_t s = (hipStream_t)stream;
   if (box.count() == 0) {  // e.g. minLevel 0 on one fragment: CG is a no-op

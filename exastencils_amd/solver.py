@@ -429,7 +429,7 @@ class SolverFromL4(_Program):
         if self._agg is not None and l == self.cfg.agglomerate_level:
             return self._agg_cycle(l)
         if l == self.cfg.min_level:
-            return self.mgCycle_coarsest(l)
+            return self.mgCycle_coarsest(l, solution_is_zero)
         ops = self.ops
         self._smooth(l, zero_input=solution_is_zero)
         R, Fc = self.Residual[l], self.RHS[l - 1]
@@ -466,7 +466,7 @@ class SolverFromL4(_Program):
         # functions of the position, written once by setup() -- `apply bc` would re-write the same bits (as in _smooth)
         static_bc = self.cfg.fused_rbgs and self._single_block()
         # ... and a coarser level that starts with a one-pass sweep reads its zero Solution as a constant (its boundary values are 0)
-        zero_start = self._starts_from_zero(l - 1)
+        zero_start = self._starts_from_zero(l - 1) or (l - 1 == self.cfg.min_level and self._coarsest_starts_from_zero())
         if not zero_start:
             ops.set(Sc.lc, Sc.data(), 0.0, b, e)
         if not static_bc:
@@ -501,14 +501,25 @@ class SolverFromL4(_Program):
         self._smooth(l)
 
     # Function mgCycle@coarsest (...exa4:152-201)
-    def mgCycle_coarsest(self, l: int):
+    def _coarsest_starts_from_zero(self) -> bool:
+        """Is `Solution@coarsest = 0` (in mgCycle of the level above) left to the one-kernel coarse solve (EXAMG_CG_ZERO_START)?"""
+        cfg = self.cfg
+        lo = cfg.min_level
+        return bool(cfg.fused_zero_start and cfg.fused_coarse and cfg.fused_rbgs and self._single_block() and self.Solution[lo].bc_fn == FN_ZERO and
+                    self.Laplace[lo].cfield is None and not (self._agg is not None and lo == cfg.agglomerate_level))
+
+    def mgCycle_coarsest(self, l: int, solution_is_zero: bool = False):
         ops, A = self.ops, self.Laplace[l]
         Sol, Res, F, p_, Ap = self.Solution[l], self.Residual[l], self.RHS[l], self.cgTmp0, self.cgTmp1
         if self.cfg.fused_coarse and self._single_block():
+            from .lib import CG_ZERO_START
+
             b, e = self.bounds(Sol)
             ops.cg_coarse(Sol.lc, Sol.data(), F.lc, F.data(), Res.lc, Res.data(), p_.lc, p_.data(), Ap.lc, Ap.data(), A,
-                          self.domain.geom(l), self.domain.face_mask(), self.cfg.cg_max, self.cfg.cg_tol, b, e, self._cg_info)
+                          self.domain.geom(l), self.domain.face_mask(), self.cfg.cg_max, self.cfg.cg_tol, b, e, self._cg_info,
+                          flags=CG_ZERO_START if solution_is_zero else 0)
             return
+        assert not solution_is_zero
         self._update_residual(l)
         # `alphaNom = sum(Residual^2)` of an iteration is the sum under the square root of the norm taken just before it
         # (same kernel, same data, same all-reduce): it is carried over instead of being reduced a second time -- one

@@ -353,6 +353,10 @@ int examg_cg_coarse(const examg_layout_t *lu, double *sol, const examg_layout_t 
  * the FMG start there). */
 #define EXAMG_CG_ALPHA_FROM_NORM 1u
 #define EXAMG_CG_NO_BC 2u
+/* `Solution@coarsest = 0` (mgCycle of the next finer level, ...exa4:225-229) rides along: the solver takes the zero field as its start --
+ * `sol` is not read (inner points; its boundary planes hold 0 already) and the zeroing loop need not run.  Same expressions on the
+ * constant 0.0: bit-identical to examg_set + the solver. */
+#define EXAMG_CG_ZERO_START 4u
 int examg_cg_coarse_variant(const examg_layout_t *lu, double *sol, const examg_layout_t *lf, const double *rhs,
                             const examg_layout_t *lr, double *res, const examg_layout_t *lp, double *p,
                             const examg_layout_t *lq, double *ap, const examg_stencil_t *st, const examg_geom_t *g,

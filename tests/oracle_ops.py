@@ -154,7 +154,8 @@ class OracleOps:
 
     def cg_coarse(self, lu, sol, lf, rhs, lr, res, lp, p, lq, ap, st, geom, face_mask, max_it, rel_tol, begin, end, info, flags=0):
         """The statements examg_cg_coarse fuses (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:152-201), one oracle loop each;
-        flags 1: alpha = res * res / alphaDenom, 2: no `apply bc` (the layer-3 generator's form, Testing/Smoothers/Jac.exa4:75-109)."""
+        flags 1: alpha = res * res / alphaDenom, 2: no `apply bc` (the layer-3 generator's form, Testing/Smoothers/Jac.exa4:75-109), 4: the zero field
+        as the start."""
         import math
 
         def bc(l, x):
@@ -164,6 +165,8 @@ class OracleOps:
         def norm():
             return math.sqrt(self.scalar_value(self.dot(lr, res, lr, res, begin, end)))
 
+        if flags & 4:        # EXAMG_CG_ZERO_START: `Solution = 0` rides along
+            self.set(lu, sol, 0.0, begin, end)
         self.stencil_op(1, lu, sol, lf, rhs, lr, res, st, 0.0, -1, begin, end)
         bc(lr, res)
         cur = init = norm()

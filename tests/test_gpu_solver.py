@@ -442,6 +442,45 @@ def test_coarse_cg_variant_of_the_layer3_generator():
     hip.L.examg_debug_cg(1)
 
 
+def test_coarse_solver_starting_from_the_zero_field():
+    """EXAMG_CG_ZERO_START: `Solution@coarsest = 0` rides along with the one-kernel coarse solve -- the solver does not read `sol` and the
+    zeroing loop does not run: the same bits as examg_set + the solver, in both forms of the kernel (search direction in LDS / global)."""
+    from exastencils_amd import lib
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.field import laplace_fd
+    from exastencils_amd.layout import FieldLayout
+    from exastencils_amd.ops import HipOps
+
+    hip = HipOps(0, lib.DBG_LIB_PATH)      # debug build: examg_debug_cg selects the form of the solver
+    n = 16
+    lu, ln = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0)
+    A = laplace_fd(3, (1.0 / n,) * 3)
+    geom, b, e = RectDomain(3).geom(4), [1, 1, 1], [n, n, n]
+    for lds in (1, 0):
+        hip.L.examg_debug_cg(lds)
+        outs = []
+        for zero_flag in (False, True):
+            sol, rhs, res, p, ap, info = (hip.new_array(lu.size), hip.new_array(ln.size), hip.new_array(ln.size), hip.new_array(lu.size),
+                                          hip.new_array(ln.size), hip.new_array(4))
+            hip.fill_random(rhs, 6)
+            if zero_flag:
+                hip.fill_random(sol, 9)          # garbage at the inner points: never read
+                hip.set(lu.c_struct(), sol, 0.0, [-1, -1, -1], [n + 2, n + 2, 1])      # boundary planes hold 0 (coarse levels: homogeneous Dirichlet)
+                hip.set(lu.c_struct(), sol, 0.0, [-1, -1, n], [n + 2, n + 2, n + 2])
+                hip.set(lu.c_struct(), sol, 0.0, [-1, -1, 1], [n + 2, 1, n])
+                hip.set(lu.c_struct(), sol, 0.0, [-1, n, 1], [n + 2, n + 2, n])
+                hip.set(lu.c_struct(), sol, 0.0, [-1, 1, 1], [1, n, n])
+                hip.set(lu.c_struct(), sol, 0.0, [n, 1, 1], [n + 2, n, n])
+            hip.cg_coarse(lu.c_struct(), sol, ln.c_struct(), rhs, ln.c_struct(), res, lu.c_struct(), p, ln.c_struct(), ap, A, geom, 63, 128, 1e-3, b, e,
+                          info, flags=lib.CG_ZERO_START if zero_flag else 0)
+            hip.synchronize()
+            outs.append([hip.to_host(t).copy() for t in (sol, res, p, info)])
+        for x, y in zip(*outs):
+            assert np.array_equal(x, y)
+        assert outs[0][3][0] >= 1
+    hip.L.examg_debug_cg(1)
+
+
 def test_fmg_driver_one_pass_forms_on_gpu(hip):
     """The FMG driver with every one-pass form (tests/test_host_logic.py::test_fmg_driver_with_one_pass_forms) on the HIP kernels at
     256^3: folded correction and zero-field sweeps change no bit; residual + norm and the one-call coarse solve sum in another order --
