@@ -268,7 +268,7 @@ template <> struct Ptr<true> { typedef double *out; typedef const double *in; };
 // COL: red-black half sweep in place (dst == u): of the two points a lane holds per row exactly one has
 //   (i0+i1+i2) % 2 == g.colour; it is updated, the other is written back unchanged (whole 16-byte stores).
 //   Race-free: only values of the other colour (never written in this sweep) and the lane's own centre are used.
-// Configuration from tools/stencil_lab.hip on MI355X at 512^3: 2 rows per wave, 4 waves per workgroup,
+// Configuration from tools/lab/stencil_lab.hip on MI355X at 512^3: 2 rows per wave, 4 waves per workgroup,
 // ~512 workgroups (two per CU), prefetch depth 1, edge values prefetched with the stage (they were the one load whose
 // latency every step waited for: -4 % at 512^3, -10 % at 256^3), non-temporal 16-byte stores.
 template <int MODE, int ORDER, int RY, int WY, bool COL>
@@ -436,7 +436,7 @@ k_stencil7_zmarch(LayoutDev lu, typename Ptr<COL>::in u, LayoutDev lf, const dou
 //   * every output row is in ONE wave, so it can be stored as whole, 128-byte-aligned lines: the outputs pass through a
 //     wave-private LDS strip (ds_write_b128, then ds_read2_b64 at the row's offset to the next line boundary -- no barrier,
 //     LDS operations of one wave execute in order) and leave as 16-byte-aligned non-temporal stores of full lines; only the
-//     two ends of a row are partial lines.  Measured in tools/stencil_lab.hip (stores moved to line boundaries, timing only):
+//     two ends of a row are partial lines.  Measured in tools/lab/stencil_lab.hip (stores moved to line boundaries, timing only):
 //     0.618 -> 0.590 ms at 512^3, the difference between the verbatim and the padded layout;
 //   * no window edges inside a row: x-neighbours across segments come from the neighbouring lane by a wave rotate (DPP
 //     wave_rol / wave_ror), edge loads only at the two ends of the row; no partial lines are fetched twice.
@@ -787,7 +787,7 @@ static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &
   // Padded layouts (`align`, field/ir/IR_AddPaddingToFieldLayouts.scala:36-41) have even row lengths and put the lower duplicate
   // point on an even index: starting the windows one point to the left of an odd box makes every 16-byte load and store of
   // the sweep 16-byte aligned (the extra point is loaded, never stored).  Not possible in the verbatim layout, whose odd
-  // strides flip the parity from row to row.  512^3, rows of 544 doubles: 0.62 -> 0.57 ms (tools/stencil_lab.hip).
+  // strides flip the parity from row to row.  512^3, rows of 544 doubles: 0.62 -> 0.57 ms (tools/lab/stencil_lab.hip).
   const bool even = !(lu.s1 & 1) && !(lu.s2 & 1) && !(lf.s1 & 1) && !(lf.s2 & 1) && !(ld.s1 & 1) && !(ld.s2 & 1);
   const int pu = (int)((lu.origin + box.b0) & 1), pf = (int)((lf.origin + box.b0) & 1), pd = (int)((ld.origin + box.b0) & 1);
   const bool shift = even && pu == 1 && pd == 1 && (MODE == EXAMG_APPLY || pf == 1) && lu.ref0 + box.b0 >= 1 &&

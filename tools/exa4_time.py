@@ -36,7 +36,7 @@ l0 = P.launches
 for _ in range(3):      # first call interpreted, second recorded (auto_graph), then replays
     P.call("Cycle", hi)
 t_int = timed(lambda: P.call("Cycle", hi))
-per_cycle = (P.launches - l0) // 6
+per_cycle = (P.launches - l0) // 9
 g = P.capture("Cycle", hi)
 t_graph = timed(g.replay)
 S = SolverFromL4(ConfigL4(nd=3, min_level=lo, max_level=hi, tol=1e-6, fused_coarse=False), ops)

@@ -1,7 +1,7 @@
 // Cost of a device-wide barrier inside a persistent kernel on gfx950, against back-to-back launches: what one kernel for the launch-bound
 // coarse levels of the V-cycle (<= 64^3) can gain.  Every phase is a 7-point sweep over an n^3 array (ping-pong), G workgroups of 256
 // threads, separated by (a) a grid barrier with agent-scope release / acquire or (b) a kernel boundary (same stream; also from a hipGraph).
-//   hipcc --offload-arch=gfx950 -O3 -o tools/barrier_probe.bin tools/barrier_probe.hip && tools/barrier_probe.bin
+//   hipcc --offload-arch=gfx950 -O3 -o tools/lab/barrier_probe.bin tools/lab/barrier_probe.hip && tools/lab/barrier_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

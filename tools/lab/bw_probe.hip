@@ -1,5 +1,5 @@
 // Bandwidth probe for MI355X: what does a plain 2-read + 1-write stream reach, by access shape?
-// Build: hipcc --offload-arch=gfx950 -O3 -o gpurun_out/bw_probe tools/bw_probe.hip ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O3 -o gpurun_out/bw_probe tools/lab/bw_probe.hip ; run on the GPU box.
 // Used to place the Jacobi kernel against the practical streaming ceiling of this device.
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -2,7 +2,7 @@
 // transposed through a wave-private LDS strip (the shipped k_stencilfield27_rec, simplified), (b) BLOCKED: [x / 64][entry][x % 64] --
 // the transformation `[x, y, z, i] => [x % 64, i, x / 64, y, z]` -- where a lane reads its 27 entries with coalesced 8-byte loads and
 // nothing passes through LDS.  Same bytes, same u accesses; prints ms and GB/s of 240 B per point.
-//   hipcc --offload-arch=gfx950 -O3 -o tools/sf27_blocked_lab.bin tools/sf27_blocked_lab.hip && tools/sf27_blocked_lab.bin
+//   hipcc --offload-arch=gfx950 -O3 -o tools/lab/sf27_blocked_lab.bin tools/lab/sf27_blocked_lab.hip && tools/lab/sf27_blocked_lab.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

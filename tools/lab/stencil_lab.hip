@@ -1,7 +1,7 @@
 // Kernel laboratory for the single-step 7-point sweep (Jacobi / residual) on MI355X: variants and ablations of the z-march
 // kernel and an LDS-staged plane kernel, each timed with HIP events and compared bit for bit with a one-thread-per-point
 // kernel.  Stand-alone (HIP runtime only):
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -o gpurun_out/stencil_lab tools/stencil_lab.hip
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -o gpurun_out/stencil_lab tools/lab/stencil_lab.hip
 //   gpurun_out/stencil_lab [n=512] [align=0]
 // What wins here is ported into exastencils_amd/csrc/kernels_stencil.hip; results are summarised in DESIGN.md section 4.1.
 #include "../exastencils_amd/csrc/examg_common.h"

@@ -7,7 +7,7 @@ Reads gpurun_out/pmcK_FETCH, gpurun_out/pmcK_WRITE (counter_collection.csv; coun
 pass gpurun_out/pmcK_times_L<level>.json.  Cases are separated in the dispatch stream by the k_fill_random launch that
 follows each of them; within a case's segment the dispatches whose kernel name contains the case's pattern are averaged.
 FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md, HBM section;
-confirmed for these access shapes by `tools/bw_probe.hip cal`, profiles/README.md); WRITE_SIZE is taken as it is.  The
+confirmed for these access shapes by `tools/lab/bw_probe.hip cal`, profiles/README.md); WRITE_SIZE is taken as it is.  The
 counters sit at the L2's fabric side: Infinity-Cache hits are included, so `traffic` bounds HBM bytes from above."""
 import argparse
 import csv
