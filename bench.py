@@ -864,20 +864,26 @@ def helmholtz27_cycle(ops, L):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
     r1 = P._residual_and_norm(cfg.max_level)
-    # compulsory bytes per cycle and level above the coarsest: 6 Jacobi steps + the residual at 24 + 8 * 27 B per point, restriction
-    # (8 B per point + 8 B per coarse point), zeroing the coarse solution, prolongation + correction (16 B per point + 8 B per coarse point)
-    comp = 0.0
+    # compulsory bytes per cycle and level above the coarsest.  PER PASS (what the kernels of this cycle can at best move): the four
+    # passes over the coefficients -- pair of steps 240 B per point (216 coefficients + u + rhs + result), step + residual 248, pair 240,
+    # single step 240 -- plus restriction (8 B per point + 8 B per coarse point), zeroing the coarse solution, prolongation + correction
+    # (16 B per point + 8 B per coarse point).  PER UPDATE (SURVEY.md 8d's accounting: 24 + 8 * 27 B for each of the 7 loops): a throughput
+    # statement, above the per-pass figure because two loops share a pass.
+    comp_pass = comp_update = 0.0
     for l in range(cfg.min_level + 1, cfg.max_level + 1):
         lb, le = P.domain.loop_bounds(P.Solution[l].layout)
         cb, ce = P.domain.loop_bounds(P.Solution[l - 1].layout)
         p = float((le[0] - lb[0]) * (le[1] - lb[1]) * (le[2] - lb[2]))
         c = float((ce[0] - cb[0]) * (ce[1] - cb[1]) * (ce[2] - cb[2]))
-        comp += 7 * 240.0 * p + (8.0 * p + 8.0 * c) + 8.0 * c + (16.0 * p + 8.0 * c)
+        transfers = (8.0 * p + 8.0 * c) + 8.0 * c + (16.0 * p + 8.0 * c)
+        comp_pass += (240.0 + 248.0 + 240.0 + 240.0) * p + transfers
+        comp_update += 7 * 240.0 * p + transfers
     return {"helmholtz27_vcycle_ms": ms, "helmholtz27_levels": cfg.max_level - cfg.min_level + 1,
             "helmholtz27_coefficient_layout": "entry-fastest (LayoutTransformations [x,y,z,i] => [i,x,y,z])",
             "helmholtz27_passes_per_level": "pair, step + residual | pair, step (7 loops of 240 B per point in 4 passes over the coefficients)",
             "helmholtz27_residual_reduction_6_cycles": r1 / r0 if r0 else None,
-            "helmholtz27_vcycle_frac": comp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            "helmholtz27_vcycle_frac": comp_pass / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,                  # per-pass bytes: a roofline fraction
+            "helmholtz27_vcycle_lu_equivalent_frac": comp_update / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}  # per-update bytes: throughput, not a fraction
 
 
 if __name__ == "__main__":

@@ -111,18 +111,21 @@ static void smoother(int lvl, const Level *correctionFrom, bool zeroInput) {
 static void mgCycle(int lvl, bool solutionIsZero) {
   Level &v = L[lvl];
   if (lvl == minLevel) {
-    check(examg_cg_coarse(&v.withComm, v.Solution, &v.noGhost, v.RHS, v.resLayout, v.Residual, &v.withComm, cgTmp0, &v.noGhost, cgTmp1,
-                          &v.Laplace, &v.geom, 63u, 128, 0.001, v.begin, v.end, cgInfo, stream), "mgCycle@coarsest");
+    // the zero field as the start (`Solution@coarsest = 0` of the level above rides along: EXAMG_CG_ZERO_START)
+    check(examg_cg_coarse_variant(&v.withComm, v.Solution, &v.noGhost, v.RHS, v.resLayout, v.Residual, &v.withComm, cgTmp0, &v.noGhost, cgTmp1,
+                                  &v.Laplace, &v.geom, 63u, 128, 0.001, v.begin, v.end, solutionIsZero ? EXAMG_CG_ZERO_START : 0u, cgInfo, stream),
+          "mgCycle@coarsest");
     return;
   }
   Level &c = L[lvl - 1];
   smoother(lvl, nullptr, solutionIsZero);
   check(examg_residual_restrict(&v.withComm, v.Solution, &v.noGhost, v.RHS, v.resLayout, v.Residual, &v.Laplace, &c.noGhost, c.RHS, 1.0,
                                 v.begin, v.end, c.begin, c.end, stream), "residual + restriction");
-  const bool zeroStart = lvl - 1 != minLevel && c.onePass;
+  const bool zeroStart = lvl - 1 == minLevel || c.onePass;      // the coarsest level: the CG takes the zero field; others: their first sweep
   if (!zeroStart) check(examg_set(&c.withComm, c.Solution, 0.0, c.begin, c.end, stream), "Solution@coarser = 0");
   mgCycle(lvl - 1, zeroStart);
-  if (v.onePass && v.points >= foldMinPoints) {
+  // the fold pays on large levels (a read-modify-write pass less) and on launch-bound ones (rows shorter than 64 points: a kernel less)
+  if (v.onePass && (v.points >= foldMinPoints || (1 << lvl) - 1 < 64)) {
     smoother(lvl, &c, false);
   } else {
     check(examg_prolong_add(&c.withComm, c.Solution, &v.withComm, v.Solution, v.begin, v.end, stream), "prolongation");
