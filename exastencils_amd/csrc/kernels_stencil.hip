@@ -639,16 +639,16 @@ k_stencil7_rowmarch(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, co
 // Red-black half sweep on the COLOUR-SPLIT layout (EXAMG_LAYOUT_SPLIT_X: `transform Solution with [x, y, z] => [x / 2, y, z, x % 2]`,
 // Testing/LayoutTrafo/rbgs.exa4:2), 3-D 7-point constant stencil, in place.
 // The points of one colour of a row are the even OR the odd columns: one of the two half rows, contiguous -- and so are their x
-// neighbours (the other half row) and the values written.  A lane owns two adjacent column pairs h, h + 1 (columns 2h .. 2h + 3) of a row and
-// marches in z with both halves of them for the planes z-1, z, z+1 in registers (16-byte accesses); the half that is updated alternates
-// from plane to plane.  Per update: the pair of plane z+1 (16 B, streamed once), the two y neighbours of the updated half (L2: they are the pairs of the rows
+// neighbours (the other half row) and the values written.  A lane owns one column pair h (columns 2h, 2h + 1) of a row and marches in z
+// with both halves of its pair for the planes z-1, z, z+1 in registers; the half that is updated alternates from plane to plane.  Per
+// update: the pair of plane z+1 (16 B, streamed once), the two y neighbours of the updated half (L2: they are the pairs of the rows
 // above and below, loaded a plane earlier by their waves), the right-hand side and the store (8 B each): 32 B instead of the 48 B a
 // half sweep moves in the untransformed layout.  The x neighbour outside the pair comes from the adjacent lane (DPP wave shift).
 // Arithmetic: conv7 / finish<EXAMG_SMOOTH> -- the loop's own expression, bit-identical to the generic kernel on either layout.
 // ---------------------------------------------------------------------------------------------
 struct SplitGeom {
   int hb, nh;        // first column pair of the box, number of column pairs (both parities)
-  int ntx, nty, zc;  // windows of 128 pairs, tiles of SP_WY rows, planes per chunk
+  int ntx, nty, zc;  // windows of 64 pairs, tiles of SP_WY rows, planes per chunk
   int ax0, ax1;      // array x range of the box
 };
 constexpr int SP_WY = 4;
@@ -666,55 +666,43 @@ k_rbgs_half_split7(LayoutDev lu, double *__restrict__ u, LayoutDev lf, const dou
   const int y = box.b1 + ty * SP_WY + wv;
   if (y >= box.e1) return;                       // wave-uniform
   const int mb = box.b2 + tz * g.zc, me = min(mb + g.zc, box.e2);
-  // a lane owns TWO adjacent column pairs h, h + 1 (columns 2h .. 2h + 3): 16-byte accesses on both half rows
-  const int h = g.hb + 2 * (64 * tx + lane);
-  const bool oka = h < lu.s1, okb = h + 1 < lu.s1;    // pairs inside the half row (the others are neither loaded nor stored)
+  const int h = g.hb + 64 * tx + lane;           // this lane's column pair
+  const int hc = min(h, (int)lu.s1 - 1);         // clamped for loads (lanes beyond the row are never stored)
   double *E = u, *O = u + lu.half;
   const long long rowy = lu.s1 * (y + lu.ref1);
-  auto at = [&](int z) { return rowy + lu.s2 * (z + lu.ref2) + h; };
-  auto ld = [&](const double *p) { return load2g(p, oka, okb); };
-  d2 Em = ld(E + at(mb - 1)), Om = ld(O + at(mb - 1)), Ec = ld(E + at(mb)), Oc = ld(O + at(mb));
-  d2 Ep = ld(E + at(mb + 1)), Op = ld(O + at(mb + 1));
+  auto at = [&](int z) { return rowy + lu.s2 * (z + lu.ref2) + hc; };
+  double Em = E[at(mb - 1)], Om = O[at(mb - 1)], Ec = E[at(mb)], Oc = O[at(mb)];
+  double Ep = E[at(mb + 1)], Op = O[at(mb + 1)];
   const bool first_lane = lane == 0, last_lane = lane == 63;
   for (int z = mb; z < me; ++z) {
     // parity of the array column of this row's updated points: (i0 + y + z) % 2 == colour with i0 = ax - ref0
     const int p = (colour + y + z + lu.ref0) & 1;          // wave-uniform
-    const long long a = at(z), rowend = rowy + lu.s2 * (z + lu.ref2) + lu.s1 - 1;
+    const long long a = at(z);
     double *P = p ? O : E;
     const double *Q = p ? E : O;
-    const d2 c = p ? Oc : Ec, q = p ? Ec : Oc, zm = p ? Om : Em, zp = p ? Op : Ep;
-    const d2 ym = ld(P + a - lu.s1), yp = ld(P + a + lu.s1);
-    const int ax = 2 * h + p;                              // first of the lane's two updated columns; the second: ax + 2
-    const bool va = ax >= g.ax0 && ax < g.ax1, vb = ax + 2 >= g.ax0 && ax + 2 < g.ax1;
-    double fa = 0.0, fb = 0.0;
-    if (va) fa = rhs[lidx(lf, ax - lu.ref0, y, z)];
-    if (vb) fb = rhs[lidx(lf, ax + 2 - lu.ref0, y, z)];
-    // next plane's pairs (in flight during this step)
-    const long long an = at(min(z + 2, box.e2));           // (the plane beyond the box's shell is never used)
-    const d2 En = ld(E + an), On = ld(O + an);
-    // x neighbours.  Even columns (p = 0): 2h: O[h - 1], O[h];  2h + 2: O[h], O[h + 1].  Odd columns: 2h + 1: E[h], E[h + 1];  2h + 3: E[h + 1], E[h + 2]
-    double xm_a, xp_a, xm_b, xp_b;
+    const double c = p ? Oc : Ec, q = p ? Ec : Oc, zm = p ? Om : Em, zp = p ? Op : Ep;
+    const double ym = P[a - lu.s1], yp = P[a + lu.s1];
+    // next plane's pair (in flight during this step)
+    const long long an = at(min(z + 2, box.e2));          // (the plane beyond the box's shell is never used)
+    const double En = E[an], On = O[an];
+    // x neighbours: even column 2h: columns 2h - 1 = O[h - 1], 2h + 1 = O[h]; odd column 2h + 1: columns 2h = E[h], 2h + 2 = E[h + 1]
+    double xm, xp;
     if (p == 0) {
-      xm_a = lane_below(q.y);
-      if (first_lane && oka) xm_a = Q[a - 1];
-      xp_a = q.x;
-      xm_b = q.x;
-      xp_b = q.y;
+      xm = lane_below(q);
+      if (first_lane) xm = Q[a - 1];
+      xp = q;
     } else {
-      xm_a = q.x;
-      xp_a = q.y;
-      xm_b = q.y;
-      xp_b = lane_above(q.x);
-      if (last_lane && oka) xp_b = Q[min(a + 2, rowend)];
+      xm = q;
+      xp = lane_above(q);
+      if (last_lane) xp = Q[min(a + 1, rowy + lu.s2 * (z + lu.ref2) + lu.s1 - 1)];
     }
-    const double acc_a = conv7<ORDER>(k, c.x, xm_a, xp_a, ym.x, yp.x, zm.x, zp.x);
-    const double acc_b = conv7<ORDER>(k, c.y, xm_b, xp_b, ym.y, yp.y, zm.y, zp.y);
-    d2 v;
-    v.x = finish<EXAMG_SMOOTH>(c.x, acc_a, fa, w);
-    v.y = finish<EXAMG_SMOOTH>(c.y, acc_b, fb, w);
-    if (va && vb) store2(P + a, v);                        // (no later step of this sweep reads a point of the colour it updates)
-    else if (va) P[a] = v.x;
-    else if (vb) P[a + 1] = v.y;
+    const int ax = 2 * h + p;
+    if (ax >= g.ax0 && ax < g.ax1) {
+      const double f = rhs[lidx(lf, ax - lu.ref0, y, z)];
+      const double acc = conv7<ORDER>(k, c, xm, xp, ym, yp, zm, zp);
+      const double v = finish<EXAMG_SMOOTH>(c, acc, f, w);
+      P[a] = v;                                   // (no later step of this sweep reads a point of the colour it updates)
+    }
     Em = Ec; Om = Oc;
     Ec = Ep; Oc = Op;
     Ep = En; Op = On;
@@ -934,7 +922,7 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
     g.ax1 = box.e0 + lu.ref0;
     g.hb = g.ax0 >> 1;
     g.nh = ((g.ax1 - 1) >> 1) - g.hb + 1;
-    g.ntx = (g.nh + 127) / 128;      // 64 lanes x two column pairs
+    g.ntx = (g.nh + 63) / 64;
     g.nty = (box.n1() + SP_WY - 1) / SP_WY;
     // planes per chunk: enough workgroups for the chip (>= 2048), chunks of at least 16 planes (two planes of start-up each)
     int zc = box.n2();

@@ -177,3 +177,29 @@ def test_pairs_and_step_with_residual_under_an_fmg_start_change_no_bit():
     Q.setup()
     Q.Solve()
     assert Q.res_history == P.res_history and Q.err_history == P.err_history and Q.iterations == P.iterations
+
+
+def test_block_decompositions_of_a_node():
+    """bench.py --blocks: 'zy' (default: 8 -> 1 x 2 x 4, the unit-stride dimension undivided), 'cube' (8 -> 2 x 2 x 2, SURVEY.md 8e /
+    domain/ir/IR_ConnectFragments.scala:46-52) or explicit; rank = bx + nbx * (by + nby * bz); neighbours and iteration offsets follow."""
+    import pytest
+
+    from exastencils_amd.domain import RectDomain
+    from exastencils_amd.layout import FieldLayout
+
+    assert [RectDomain.parse_blocks("", n, 3) for n in (1, 2, 4, 8)] == [(1, 1, 1), (1, 1, 2), (1, 2, 2), (1, 2, 4)]
+    assert [RectDomain.parse_blocks("cube", n, 3) for n in (2, 4, 8)] == [(2, 1, 1), (2, 2, 1), (2, 2, 2)]
+    assert RectDomain.parse_blocks("2,2,2", 8, 3) == (2, 2, 2) and RectDomain.parse_blocks("1x2x4", 8, 3) == (1, 2, 4)
+    assert RectDomain.parse_blocks("4,2", 8, 2) == (4, 2, 1)
+    for bad, n, nd in (("2,2,2", 4, 3), ("3,3,1", 8, 3), ("2,2,2", 8, 2), ("a,b", 8, 3), ("0,8,1", 8, 3)):
+        with pytest.raises(ValueError):
+            RectDomain.parse_blocks(bad, n, nd)
+    # 2 x 2 x 2: rank 5 = (1, 0, 1): neighbours across all three axes, one physical face per axis
+    d = RectDomain(3, (2, 2, 2), 5)
+    assert d.pos == (1, 0, 1)
+    assert [d.neighbor(ax, s) for ax in range(3) for s in (-1, +1)] == [4, None, None, 7, 1, None]
+    lay = FieldLayout.node(3, d.ncells(4), 1)
+    b, e = d.loop_bounds(lay)
+    assert b == [0, 1, 0] and e == [16, 17, 16]           # iteration offsets 0 at interior faces, 1 / -1 at physical ones
+    rb, _ = d.loop_bounds(lay, reduction=True)
+    assert rb == [1, 1, 1]                                # reductions leave the lower duplicate planes to the neighbour
