@@ -51,6 +51,12 @@ static inline LayoutDev make_layout(const examg_layout_t *l) {
   return d;
 }
 
+// the index map of an UNTRANSFORMED layout: what the kernels use whose dispatch takes plain layouts only (the transformation test of lidx
+// costs registers in kernels that have none to spare: k_stencilfield27_rec went from two waves per SIMD to one with it)
+__host__ __device__ static inline long long lidx_plain(const LayoutDev &l, int i0, int i1, int i2) {
+  return l.origin + i0 + l.s1 * i1 + l.s2 * i2;
+}
+
 __host__ __device__ static inline long long lidx(const LayoutDev &l, int i0, int i1, int i2) {
   if (l.half) {
     const int ax = i0 + l.ref0;

@@ -98,10 +98,10 @@ __device__ __forceinline__ void cg_unflatten(const Box &box, int t, int &i0, int
 
 __device__ __forceinline__ double cg_apply(const StencilCG &st, const LayoutDev &lu, const double *u, const LayoutDev &lc,
                                            int i0, int i1, int i2) {
-  const long long iu = lidx(lu, i0, i1, i2);
+  const long long iu = lidx_plain(lu, i0, i1, i2);
   double acc;
   if (st.cfield) {
-    const long long ic = lidx(lc, i0, i1, i2);
+    const long long ic = lidx_plain(lc, i0, i1, i2);
     acc = st.cfield[ic * st.cpt] * u[iu + st.uo[0]];
     for (int k = 1; k < st.nent; ++k) acc = acc + st.cfield[ic * st.cpt + k * st.cplane] * u[iu + st.uo[k]];
   } else {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void cg_zero_faces(const FaceBoxesCG &fb, const Layou
     for (int t = threadIdx.x; t < total; t += CG_THREADS) {
       int i0, i1, i2;
       cg_unflatten(fb.box[f], t, i0, i1, i2);
-      x[lidx(l, i0, i1, i2)] = 0.0;
+      x[lidx_plain(l, i0, i1, i2)] = 0.0;
     }
   }
 }
@@ -150,9 +150,9 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
   double s = 0.0;
   for (int t = threadIdx.x; t < total; t += CG_THREADS) {
     cg_unflatten(box, t, i0, i1, i2);
-    const double r = rhs[lidx(lf, i0, i1, i2)] - ((flags & EXAMG_CG_ZERO_START) ? cg_apply_zero(st) : cg_apply(st, lu, sol, lc, i0, i1, i2));
-    if (flags & EXAMG_CG_ZERO_START) sol[lidx(lu, i0, i1, i2)] = 0.0;
-    res[lidx(lr, i0, i1, i2)] = r;
+    const double r = rhs[lidx_plain(lf, i0, i1, i2)] - ((flags & EXAMG_CG_ZERO_START) ? cg_apply_zero(st) : cg_apply(st, lu, sol, lc, i0, i1, i2));
+    if (flags & EXAMG_CG_ZERO_START) sol[lidx_plain(lu, i0, i1, i2)] = 0.0;
+    res[lidx_plain(lr, i0, i1, i2)] = r;
     s = s + r * r;
   }
   if (bc) cg_zero_faces(fbr, lr, res);
@@ -161,7 +161,7 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
   // cgTmp0 = Residual ; apply bc to cgTmp0
   for (int t = threadIdx.x; t < total; t += CG_THREADS) {
     cg_unflatten(box, t, i0, i1, i2);
-    p[lidx(lp, i0, i1, i2)] = res[lidx(lr, i0, i1, i2)];
+    p[lidx_plain(lp, i0, i1, i2)] = res[lidx_plain(lr, i0, i1, i2)];
   }
   if (bc) cg_zero_faces(fbp, lp, p);
   __syncthreads();
@@ -175,10 +175,10 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
     for (int t = threadIdx.x; t < total; t += CG_THREADS) {
       cg_unflatten(box, t, i0, i1, i2);
       const double q = cg_apply(st, lp, p, lc, i0, i1, i2);
-      ap[lidx(lq, i0, i1, i2)] = q;
-      const double r = res[lidx(lr, i0, i1, i2)];
+      ap[lidx_plain(lq, i0, i1, i2)] = q;
+      const double r = res[lidx_plain(lr, i0, i1, i2)];
       sn = sn + r * r;
-      sd = sd + p[lidx(lp, i0, i1, i2)] * q;
+      sd = sd + p[lidx_plain(lp, i0, i1, i2)] * q;
     }
     double alphaNom, alphaDenom = sd;
     if (from_norm) {
@@ -193,9 +193,9 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
     double s2 = 0.0;
     for (int t = threadIdx.x; t < total; t += CG_THREADS) {
       cg_unflatten(box, t, i0, i1, i2);
-      const long long ks = lidx(lu, i0, i1, i2), kr = lidx(lr, i0, i1, i2);
-      sol[ks] = sol[ks] + alpha * p[lidx(lp, i0, i1, i2)];
-      const double r = res[kr] - alpha * ap[lidx(lq, i0, i1, i2)];
+      const long long ks = lidx_plain(lu, i0, i1, i2), kr = lidx_plain(lr, i0, i1, i2);
+      sol[ks] = sol[ks] + alpha * p[lidx_plain(lp, i0, i1, i2)];
+      const double r = res[kr] - alpha * ap[lidx_plain(lq, i0, i1, i2)];
       res[kr] = r;
       s2 = s2 + r * r;
     }
@@ -206,8 +206,8 @@ k_cg_coarse(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, LayoutDe
     // cgTmp0 = Residual + beta * cgTmp0
     for (int t = threadIdx.x; t < total; t += CG_THREADS) {
       cg_unflatten(box, t, i0, i1, i2);
-      const long long kp = lidx(lp, i0, i1, i2);
-      p[kp] = res[lidx(lr, i0, i1, i2)] + beta * p[kp];
+      const long long kp = lidx_plain(lp, i0, i1, i2);
+      p[kp] = res[lidx_plain(lr, i0, i1, i2)] + beta * p[kp];
     }
     curRes = nextRes;
     __syncthreads();
@@ -250,7 +250,7 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
     double v = 0.0;
     if (!bc) {
       const int a = t % ldx, rw = t / ldx, b2 = rw % (ldxy / ldx), c = rw / (ldxy / ldx);
-      v = p[lidx(lp, box.b0 - 1 + a, box.b1 - 1 + b2, box.b2 - 1 + c)];
+      v = p[lidx_plain(lp, box.b0 - 1 + a, box.b1 - 1 + b2, box.b2 - 1 + c)];
     }
     P[t] = v;
   }
@@ -268,13 +268,13 @@ k_cg_coarse_lds(LayoutDev lu, double *sol, LayoutDev lf, const double *rhs, Layo
     if (t < total) {
       int i0, i1, i2;
       cg_unflatten(box, t, i0, i1, i2);
-      ku[j] = lidx(lu, i0, i1, i2);
-      kr[j] = lidx(lr, i0, i1, i2);
-      kp[j] = lidx(lp, i0, i1, i2);
-      kq[j] = lidx(lq, i0, i1, i2);
+      ku[j] = lidx_plain(lu, i0, i1, i2);
+      kr[j] = lidx_plain(lr, i0, i1, i2);
+      kp[j] = lidx_plain(lp, i0, i1, i2);
+      kq[j] = lidx_plain(lq, i0, i1, i2);
       li[j] = (i0 - box.b0 + 1) + (i1 - box.b1 + 1) * ldx + (i2 - box.b2 + 1) * ldxy;
       const bool zero = flags & EXAMG_CG_ZERO_START;      // the start is the zero field: nothing of `sol` is read
-      r[j] = rhs[lidx(lf, i0, i1, i2)] - (zero ? cg_apply_zero(st) : cg_apply(st, lu, sol, lu, i0, i1, i2));   // Residual = RHS - Laplace * Solution
+      r[j] = rhs[lidx_plain(lf, i0, i1, i2)] - (zero ? cg_apply_zero(st) : cg_apply(st, lu, sol, lu, i0, i1, i2));   // Residual = RHS - Laplace * Solution
       x[j] = zero ? 0.0 : sol[ku[j]];
       s = s + r[j] * r[j];
     }

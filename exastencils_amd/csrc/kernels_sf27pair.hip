@@ -68,7 +68,7 @@ k_sf27_two_stage(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
   // ---- addressing.  Loads are unconditional with element indices clamped into the arrays (8-byte accesses: a clamped load
   // puts some other value where a point outside the allocation would be, which nothing valid depends on) ----
   const long long usz = lu.size - 1, fsz = lf.size - 1, csz = lc.size * 27 - 1;
-  auto uidx = [&](int xx, int yy, int zz) { return min(max(lidx(lu, xx, yy, zz), 0LL), usz); };
+  auto uidx = [&](int xx, int yy, int zz) { return min(max(lidx_plain(lu, xx, yy, zz), 0LL), usz); };
   // rows / planes of the coefficient field clamped into its allocation (scalar); the row's record stream starts at point xw
   const int cy = min(max(gy + lc.ref1, 0), lc.tot1 - 1);
   auto crow = [&](int zz) {
@@ -111,7 +111,7 @@ k_sf27_two_stage(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
       if (lane < 2) UB[pb][orow][hc] = v.oh;
     }
   };
-  auto load_f = [&](int zz) { return rhs[min(max(lidx(lf, x, gy, zz), 0LL), fsz)]; };
+  auto load_f = [&](int zz) { return rhs[min(max(lidx_plain(lf, x, gy, zz), 0LL), fsz)]; };
 
   // ---- start-up: input planes mb-2, mb-1 in LDS, plane mb and the records / rhs of plane mb-1 in flight ----
   put_u(load_u(mb - 2), mb - 2);
@@ -163,10 +163,10 @@ k_sf27_two_stage(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
       for (int k = 18; k < 27; ++k) a2 = a2 + cR[k - 18] * V(q & 1, s27_dx(k), s27_dy(k));
       if (out_xy) {
         if (MODE2 == EXAMG_SMOOTH) {
-          __builtin_nontemporal_store(vR + wwR * (fR - a2), out + lidx(lu, x, gy, m));
+          __builtin_nontemporal_store(vR + wwR * (fR - a2), out + lidx_plain(lu, x, gy, m));
         } else {
-          __builtin_nontemporal_store(vR, out + lidx(lu, x, gy, m));
-          __builtin_nontemporal_store(fR - a2, res + lidx(lr, x, gy, m));
+          __builtin_nontemporal_store(vR, out + lidx_plain(lu, x, gy, m));
+          __builtin_nontemporal_store(fR - a2, res + lidx_plain(lr, x, gy, m));
         }
       }
     }

@@ -65,7 +65,7 @@ __device__ __forceinline__ double small_prolong(const LayoutDev &lc, const doubl
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         if (a < n[0] && b < n[1] && c < n[2]) {
-          const double tv = ((cw[0][a] * cw[1][b]) * cw[2][c]) * uc[lidx(lc, ci[0][a], ci[1][b], ci[2][c])];
+          const double tv = ((cw[0][a] * cw[1][b]) * cw[2][c]) * uc[lidx_plain(lc, ci[0][a], ci[1][b], ci[2][c])];
           acc = first ? tv : acc + tv;
           first = false;
         }
@@ -106,7 +106,7 @@ k_small_two_stage(LayoutDev lu, const double *__restrict__ u_in, double *__restr
         double val = 0.0;
         if (need && xl < LX) {
           const int x = x0 + xl;
-          val = u_in[lidx(lu, x, y, z)];
+          val = u_in[lidx_plain(lu, x, y, z)];
           if (VAR == 1 && x >= box.b0 && x < box.e0 && y >= box.b1 && y < box.e1 && z >= box.b2 && z < box.e2) val = val + small_prolong(lc, uc, x, y, z);
         }
         v[j][h] = val;
@@ -141,7 +141,7 @@ k_small_two_stage(LayoutDev lu, const double *__restrict__ u_in, double *__restr
         const int xf = box.b0 + (((box.b0 + y + z) & 1) != colour ? 1 : 0);
         for (int x = xf + 2 * hl; x < box.e0; x += 64) {
           const int it = (x - x0) + LX * ((y - y0) + RY * (z - z0));
-          const double f = rhs[lidx(lf, x, y, z)];
+          const double f = rhs[lidx_plain(lf, x, y, z)];
           double acc = st.coef[0] * T[it + st.lo[0]];
           for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * T[it + st.lo[k]];
           T[it] = T[it] + w * (f - acc);
@@ -156,7 +156,7 @@ k_small_two_stage(LayoutDev lu, const double *__restrict__ u_in, double *__restr
       if (y < box.b1 || y >= box.e1 || z < box.b2 || z >= box.e2) continue;
       for (int x = box.b0 + lane; x < box.e0; x += 64) {
         const int it = (x - x0) + LX * ((y - y0) + RY * (z - z0));
-        const double f = rhs[lidx(lf, x, y, z)];
+        const double f = rhs[lidx_plain(lf, x, y, z)];
         double acc = st.coef[0] * T[it + st.lo[0]];
         for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * T[it + st.lo[k]];
         T2[it] = T[it] + w * (f - acc);
@@ -168,7 +168,7 @@ k_small_two_stage(LayoutDev lu, const double *__restrict__ u_in, double *__restr
       if (y >= box.e1 || z >= box.e2) continue;
       for (int x = box.b0 + lane; x < box.e0; x += 64) {
         const int it = (x - x0) + LX * ((y - y0) + RY * (z - z0));
-        const double f = rhs[lidx(lf, x, y, z)];
+        const double f = rhs[lidx_plain(lf, x, y, z)];
         double acc = st.coef[0] * T2[it + st.lo[0]];
         for (int k = 1; k < st.nent; ++k) acc = acc + st.coef[k] * T2[it + st.lo[k]];
         T[it] = T2[it] + w * (f - acc);
@@ -180,7 +180,7 @@ k_small_two_stage(LayoutDev lu, const double *__restrict__ u_in, double *__restr
   for (int r = wv; r < ROWS2; r += NW) {
     const int y = oy + r % SM_SY, z = oz + r / SM_SY;
     if (y >= box.e1 || z >= box.e2) continue;
-    for (int x = box.b0 + lane; x < box.e0; x += 64) u_out[lidx(lu, x, y, z)] = T[(x - x0) + LX * ((y - y0) + RY * (z - z0))];
+    for (int x = box.b0 + lane; x < box.e0; x += 64) u_out[lidx_plain(lu, x, y, z)] = T[(x - x0) + LX * ((y - y0) + RY * (z - z0))];
   }
 }
 
@@ -205,10 +205,10 @@ k_small_residual_restrict(LayoutDev lu, const double *__restrict__ u, LayoutDev 
     const int a = j / 9 - 1, b = (j / 3) % 3 - 1, c = j % 3 - 1;
     const double w1[3] = {0.25, 0.5, 0.25};
     const int i0 = 2 * I0 + a, i1 = 2 * I1 + b, i2 = 2 * I2 + c;
-    const long long iu = lidx(lu, i0, i1, i2);
+    const long long iu = lidx_plain(lu, i0, i1, i2);
     double r = st.coef[0] * u[iu + st.uo[0]];
     for (int k = 1; k < st.nent; ++k) r = r + st.coef[k] * u[iu + st.uo[k]];
-    r = rhs[lidx(lf, i0, i1, i2)] - r;
+    r = rhs[lidx_plain(lf, i0, i1, i2)] - r;
     const double wgt = scale * ((w1[a + 1] * w1[b + 1]) * w1[c + 1]);
     tv = wgt * r;
   }
@@ -216,7 +216,7 @@ k_small_residual_restrict(LayoutDev lu, const double *__restrict__ u, LayoutDev 
   double acc = __shfl(tv, base);
 #pragma unroll
   for (int k = 1; k < 27; ++k) acc = acc + __shfl(tv, base + k);
-  if (live && j == 0) fc[lidx(lc, I0, I1, I2)] = acc;
+  if (live && j == 0) fc[lidx_plain(lc, I0, I1, I2)] = acc;
 }
 
 static thread_local int g_small_disable = 0;      // examg_debug_small(1): the plain loops instead (A/B and parity tests)

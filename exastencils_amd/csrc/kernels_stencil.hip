@@ -126,7 +126,7 @@ k_stencilfield_unrolled(LayoutDev lu, const double *__restrict__ u, LayoutDev lf
     const int i0 = box.b0 + (int)(t - row * n0);
     const int i1 = box.b1 + (int)(row % box.n1());
     const int i2 = box.b2 + (int)(row / box.n1());
-    const long long iu = lidx(lu, i0, i1, i2), ic = lidx(lc, i0, i1, i2);
+    const long long iu = lidx_plain(lu, i0, i1, i2), ic = lidx_plain(lc, i0, i1, i2);
     double c[NENT], v[NENT];
 #pragma unroll
     for (int k = 0; k < NENT; ++k) c[k] = cf[ic + k * cplane];
@@ -139,10 +139,10 @@ k_stencilfield_unrolled(LayoutDev lu, const double *__restrict__ u, LayoutDev lf
       // the centre entry comes first (dispatch condition): c[0] is the diagonal, v[0] the point's own value; a run-time
       // index into c[] would push the whole array to scratch memory
       const double ww = (1.0 / c[0]) * w;
-      acc = v[0] + ww * (rhs[lidx(lf, i0, i1, i2)] - acc);
+      acc = v[0] + ww * (rhs[lidx_plain(lf, i0, i1, i2)] - acc);
     }
-    if (MODE == EXAMG_RESIDUAL) acc = rhs[lidx(lf, i0, i1, i2)] - acc;
-    dst[lidx(ld, i0, i1, i2)] = acc;
+    if (MODE == EXAMG_RESIDUAL) acc = rhs[lidx_plain(lf, i0, i1, i2)] - acc;
+    dst[lidx_plain(ld, i0, i1, i2)] = acc;
   }
 }
 
@@ -181,7 +181,7 @@ k_stencilfield27_rec(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, c
     t.i2 = box.b2 + (int)(row / box.n1());
     t.x = box.b0 + tx * 64;
     t.nv = min(64, box.e0 - t.x);
-    t.rec0 = lidx(lc, t.x, t.i1, t.i2) * 27;
+    t.rec0 = lidx_plain(lc, t.x, t.i1, t.i2) * 27;
     return t;
   };
   auto load_raw = [&](d2 (&raw)[14], const SF27Tile &t) {
@@ -195,12 +195,12 @@ k_stencilfield27_rec(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, c
   double *sb = strip[wv];
   auto work = [&](const d2 (&raw)[14], const SF27Tile &t) {
     const int x = t.x + (lane < t.nv ? lane : 0);
-    const long long iu = lidx(lu, x, t.i1, t.i2);
+    const long long iu = lidx_plain(lu, x, t.i1, t.i2);
     double v[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) v[k] = u[iu + uo.o[k]];
     double f = 0.0;
-    if (MODE != EXAMG_APPLY) f = rhs[lidx(lf, x, t.i1, t.i2)];
+    if (MODE != EXAMG_APPLY) f = rhs[lidx_plain(lf, x, t.i1, t.i2)];
 #pragma unroll
     for (int i = 0; i < 14; ++i)
       if (i < 13 || lane < 32) *reinterpret_cast<d2 *>(sb + 2 * (64 * i + lane)) = raw[i];
@@ -215,7 +215,7 @@ k_stencilfield27_rec(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, c
       acc = v[0] + ww * (f - acc);
     }
     if (MODE == EXAMG_RESIDUAL) acc = f - acc;
-    if (lane < t.nv) dst[lidx(ld, x, t.i1, t.i2)] = acc;
+    if (lane < t.nv) dst[lidx_plain(ld, x, t.i1, t.i2)] = acc;
   };
   d2 ra[14], rb[14];
   SF27Tile ta = tile_of(t0), tb = ta;
@@ -659,10 +659,16 @@ k_rbgs_half_split7(LayoutDev lu, double *__restrict__ u, LayoutDev lf, const dou
                    SplitGeom g) {
   const int lane = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  int t = blockIdx.x;
-  const int tx = t % g.ntx;
-  t /= g.ntx;
-  const int ty = t % g.nty, tz = t / g.nty;
+  // workgroups are dealt round-robin to the 8 XCDs: within a z layer every XCD takes a band of y-adjacent row groups (all x windows of
+  // them), so that the y neighbours a wave reads -- the pairs other waves loaded two planes earlier -- meet in ONE L2
+  const int per_layer = g.ntx * g.nty;
+  const int tz = blockIdx.x / per_layer;
+  int r = blockIdx.x - tz * per_layer;
+  if ((g.nty & 7) == 0) {
+    const int band = r & 7, q = r >> 3;          // XCD, position within the XCD's share of the layer
+    r = (band * (g.nty >> 3) + q / g.ntx) * g.ntx + q % g.ntx;
+  }
+  const int tx = r % g.ntx, ty = r / g.ntx;
   const int y = box.b1 + ty * SP_WY + wv;
   if (y >= box.e1) return;                       // wave-uniform
   const int mb = box.b2 + tz * g.zc, me = min(mb + g.zc, box.e2);

@@ -310,7 +310,7 @@ k_prolong_add3_pairs(LayoutDev lc, const double *__restrict__ uc, LayoutDev lfin
 #pragma unroll
       for (int qs = 0; qs < 2; ++qs) {
         if ((rs == 1 && !odd1) || (qs == 1 && !odd2)) { c[0][rs][qs] = 0.0; c[1][rs][qs] = 0.0; continue; }
-        const long long k = lidx(lc, j, rs ? r1 : r0, qs ? q1 : q0);
+        const long long k = lidx_plain(lc, j, rs ? r1 : r0, qs ? q1 : q0);
         c[0][rs][qs] = uc[k];
         c[1][rs][qs] = vb ? uc[k + 1] : 0.0;
       }
@@ -341,7 +341,7 @@ k_prolong_add3_pairs(LayoutDev lc, const double *__restrict__ uc, LayoutDev lfin
           fb = false;
         }
       }
-    double *q = uf + lidx(lfine, xa, i1, i2);
+    double *q = uf + lidx_plain(lfine, xa, i1, i2);
     if (va && vb) {
       pd2 v = *reinterpret_cast<pd2 *>(q);
       v.a = v.a + acc_a;

@@ -97,6 +97,7 @@ def _st_const(nd, shape, kind):
     (3, (33, 17, 9), "star", [0, 1, 0], [34, 17, 10]),  # odd rows, loop over duplicate planes (interior faces)
     (3, (200, 12, 40), "star", None, None),           # several 64-pair windows, z chunks (k_rbgs_half_split7)
     (3, (131, 9, 7), "star", [0, 0, 0], [132, 10, 8]),  # every face an interior face: first column pair at array index 1
+    (3, (70, 65, 9), "star", None, None),             # 16 row groups: the XCD band order of the workgroups
     (3, (24, 12, 10), "27", None, None),              # 27-point constant stencil
     (2, (64, 48), "star", None, None),                # 2-D 5-point
     (3, (24, 14, 8), "field7", None, None),           # 7-entry stencil field (coefficients in the plain layout)
