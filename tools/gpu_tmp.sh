@@ -1,5 +1,5 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r04_gputests.log 2>&1; rc=$?; tail -6 gpurun_out/r04_gputests.log
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r04_gputests.log 2>&1; rc=$?; tail -4 gpurun_out/r04_gputests.log
 if [ $rc -ne 0 ]; then exit $rc; fi
-timeout -k 10 300 python3 tools/ab_small.py 2>/dev/null | grep -E "split|zmarch|vcycle"
+ROUND=r04 bash tools/gpu_profiles.sh
