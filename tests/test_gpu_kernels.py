@@ -592,12 +592,12 @@ def test_stencil_field_27_entries_under_the_entry_fastest_layout_transformation(
     assert_same(g, c, "27-entry stencil field, entry-fastest coefficients")
 
 
-def _sf27_pair_case(ops, shape, b1, e1, b2, e2, kind, entry_fastest=True):
+def _sf27_pair_case(ops, shape, b1, e1, b2, e2, kind, entry_fastest=True, cghost=0):
     """Two Jacobi steps (kind 'pair': step 1 on box 1, step 2 on box 2) or one step + residual ('residual') on a 27-entry stencil field
     with random positive-diagonal coefficients; one call on the GPU, the separate loops through the oracle."""
     from exastencils_amd.field import helmholtz27_offsets
 
-    lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+    lu, lf = FieldLayout.node(3, shape, 1 + cghost), FieldLayout.node(3, shape, cghost)
     u, f, out, tmp, res = (ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size),
                            ops.new_array(lu.size))
     ops.fill_random(u, 12345)
@@ -637,20 +637,23 @@ def _sf27_pair_case(ops, shape, b1, e1, b2, e2, kind, entry_fastest=True):
 
 
 @pytest.mark.parametrize("kind", ["pair", "residual"])
-@pytest.mark.parametrize("shape,b1,e1,b2,e2", [
-    ((66, 66, 66), [1, 1, 1], [66, 66, 66], [1, 1, 1], [66, 66, 66]),          # two x windows, ragged row groups, one chunk
-    ((130, 40, 70), [1, 1, 1], [130, 40, 70], [1, 1, 1], [130, 40, 70]),       # three windows, two z chunks of 64 / 5 planes
-    ((130, 40, 20), [0, 1, 0], [131, 40, 21], [0, 1, 0], [131, 40, 21]),       # interior faces: the halo reaches the ghost layers
-    ((200, 24, 36), [0, 0, 0], [201, 25, 37], [1, 1, 1], [200, 24, 36]),       # separate stage boxes (block with neighbours)
+@pytest.mark.parametrize("shape,b1,e1,b2,e2,cghost", [
+    ((66, 66, 66), [1, 1, 1], [66, 66, 66], [1, 1, 1], [66, 66, 66], 0),       # two x windows, ragged row groups, one chunk (two rows per wave)
+    ((130, 40, 70), [1, 1, 1], [130, 40, 70], [1, 1, 1], [130, 40, 70], 0),    # three windows, two z chunks of 64 / 5 planes (one row per wave)
+    ((130, 40, 20), [0, 1, 0], [131, 40, 21], [0, 1, 0], [131, 40, 21], 0),    # interior faces: the halo reaches the ghost layers
+    ((200, 24, 36), [0, 0, 0], [201, 25, 37], [1, 1, 1], [200, 24, 36], 0),    # separate stage boxes (block with neighbours)
+    ((130, 60, 70), [1, 1, 1], [130, 60, 70], [1, 1, 1], [130, 60, 70], 0),    # two rows per wave: last window moved left, tiles of 14 + 14 + 14 + 14 + 3 rows
+    ((136, 47, 9), [0, 0, 0], [137, 48, 10], [1, 1, 1], [136, 47, 9], 1),      # two rows per wave, separate stage boxes, coefficients with ghost layers
+    ((64, 48, 5), [2, 1, 1], [63, 47, 4], [2, 3, 1], [63, 47, 4], 0),          # two rows per wave, one window, boxes off the array edges
 ])
-def test_two_jacobi_steps_on_a_27_entry_field_in_one_pass(hip, orc, kind, shape, b1, e1, b2, e2):
+def test_two_jacobi_steps_on_a_27_entry_field_in_one_pass(hip, orc, kind, shape, b1, e1, b2, e2, cghost):
     """Temporal blocking on config 4's operator (csrc/kernels_sf27pair.hip): both steps of a point share its 216 B of coefficients.
     Same 27 products in the same order as the one-step loops: bit-identical to running them one after the other (oracle)."""
     if kind == "residual" and (b1, e1) != (b2, e2):
         pytest.skip("one step + residual has a single box")
-    g = _sf27_pair_case(hip, shape, b1, e1, b2, e2, kind)
+    g = _sf27_pair_case(hip, shape, b1, e1, b2, e2, kind, cghost=cghost)
     hip.synchronize()
-    c = _sf27_pair_case(orc, shape, b1, e1, b2, e2, kind, entry_fastest=False)
+    c = _sf27_pair_case(orc, shape, b1, e1, b2, e2, kind, entry_fastest=False, cghost=cghost)
     assert_same([hip.to_host(t) for t in g], [orc.to_host(t) for t in c], "27-entry pair " + kind)
 
 

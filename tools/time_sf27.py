@@ -43,8 +43,11 @@ cases = [("one step, planes", lambda: ops.stencil_op(2, Ls, u, Fs, f, Ls, un, pl
          ("step + residual, one pass", lambda: ops.jacobi_residual(Ls, u, un, Fs, f, Ls, res, rec, 0.8, b, e), 248)]
 if dbg:
     L.examg_debug_sf27_pair.argtypes = [C.c_int, C.c_int]
-    for zc in (16, 32, 37, 64, 128, 256):
-        cases.append(("two steps, one pass, %d planes" % zc, (lambda zc=zc: (L.examg_debug_sf27_pair(1, zc), ops.jacobi2(Ls, u, un, None, Fs, f, rec, 0.8, b, e))), 240))
+    for rows in (1, 2):
+        for zc in ((32, 64, 128) if rows == 1 else (32, 43, 64, 86, 128, 171, 256)):
+            cases.append(("two steps, one pass, %d rows per wave, %d planes" % (rows, zc),
+                          (lambda zc=zc, rows=rows: (L.examg_debug_sf27_pair(10 + rows, zc), ops.jacobi2(Ls, u, un, None, Fs, f, rec, 0.8, b, e))), 240))
+    cases.append(("step + residual, one pass, 1 row per wave", lambda: (L.examg_debug_sf27_pair(11, 0), ops.jacobi_residual(Ls, u, un, Fs, f, Ls, res, rec, 0.8, b, e)), 248))
 for _ in range(5):
     for _, fn, _ in cases:
         fn()
