@@ -576,15 +576,33 @@ def open_transport(dom, ops, dist, args, notes, dist_module=None):
     order = [pinned] if pinned in ("peer", "c", "torch") else (["peer", "c", "torch"] if args.backend == "nccl" else ["peer", "torch"])
     world = dom.world_size
     dev = ops.device if args.backend == "nccl" else "cpu"
+    # a peer that never answers the probe must leave time for the next transport inside --preflight-timeout (the library's default
+    # patience of 120 s is meant for neighbours that write files); the communicators of the run inherit it: ranks of a bench run in step
+    os.environ.setdefault("EXAMG_PEER_TIMEOUT_MS", "40000")
     for tr in order:
         os.environ["EXAMG_TRANSPORT"] = tr
         ok, why = 1.0, ""
         try:
             c = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True, transport=tr, dist_module=dist_module)
             probe = Field("probe", 4, FieldLayout.node(dom.nd, dom.ncells(4), 1, True, True, 0), ops, 1, None)
-            ops.fill_random(probe.data(), 99 + dom.rank)
+            probe.data().fill_(1.0 + dom.rank)
             full = Communicator(dom, ops, transport=tr, dist_module=dist_module)
             full.exchange(probe, None, "all")
+            ops.synchronize()
+            # the VALUES that arrived: every ghost face towards a neighbour holds that neighbour's number (a transport whose
+            # messages complete but whose bytes are stale -- a cached mapping across GPUs -- fails here, not in a wrong residual later)
+            a, lay = probe.host_array(ops), probe.layout
+            for d in range(dom.nd):
+                for side in (-1, 1):
+                    nb = dom.neighbor(d, side)
+                    if nb is None:
+                        continue
+                    g = lay.ref(d) - 1 if side < 0 else lay.ref(d) + dom.ncells(4)[d] + 1
+                    sl = [slice(lay.ref(e) + 1, lay.ref(e) + dom.ncells(4)[e]) if e < dom.nd else slice(None) for e in range(3)]
+                    sl[d] = g
+                    face = a[tuple(reversed(sl))]
+                    if not (face == 1.0 + nb).all():
+                        raise RuntimeError("ghost face %+d of axis %d holds %r .. %r, not rank %d's value" % (side, d, float(face.min()), float(face.max()), nb))
             t = ops.from_host(__import__("numpy").array([1.0 + dom.rank]))
             c.allreduce(t, "sum")
             ops.synchronize()

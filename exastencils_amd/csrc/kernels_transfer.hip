@@ -147,26 +147,42 @@ k_restrict3_wide(LayoutDev lfine, const double *__restrict__ rf, LayoutDev lc, d
 template <int ORDER, int RW>
 __global__ void __launch_bounds__(256)
 k_residual_restrict3(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ f, LayoutDev lc,
-                     double *__restrict__ fc, Coef7 k, double scale, Box box, int ntx, int zc, int nwaves) {
+                     double *__restrict__ fc, Coef7 k, double scale, Box box, int ntx, int zc, int nwaves, int order) {
   constexpr int NR = 2 * RW + 1;     // residual (and rhs) rows of the wave: 2J-1 .. 2J+2RW-1
   constexpr int NU = NR + 2;         // u rows: 2J-2 .. 2J+2RW
   const int lane = threadIdx.x;
   const int n1w = (box.n1() + RW - 1) / RW;
-  long long wg = blockIdx.x;
-  // workgroups are dealt round-robin to the 8 XCDs: within a layer (one x tile, one z chunk) every XCD takes a band of y-adjacent
-  // workgroups, whose shared fine rows then meet in one L2 (512^3: 0.462 -> 0.455 ms)
-  if ((n1w & 3) == 0) {
-    const int wpl = n1w >> 2, per = wpl >> 3;
-    const long long lz = wg / wpl;
-    const int r = (int)(wg - lz * wpl);
-    wg = lz * wpl + (r < (per << 3) ? (r & 7) * per + (r >> 3) : r);
+  int J, tx, kb;
+  if (order == 1) {
+    // workgroups are dealt round-robin to the 8 XCDs: within a z layer every XCD takes a band of consecutive (x tile fastest, then y)
+    // workgroups -- the fine rows that y-adjacent row groups share AND the cache lines that x-adjacent tiles share (a tile's rows start
+    // 1008 B after its neighbour's: 9 lines for 1 KiB) then meet in one L2 while both are being worked on
+    const int ngy = (n1w + 3) >> 2, wpl = ntx * ngy, per = wpl >> 3;
+    const int lz = blockIdx.x / wpl;
+    int r = blockIdx.x - lz * wpl;
+    if (r < (per << 3)) r = (r & 7) * per + (r >> 3);
+    tx = r % ntx;
+    const int jw = (r / ntx) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+    if (jw >= n1w) return;
+    J = box.b1 + jw * RW;
+    kb = box.b2 + lz * zc;
+  } else {
+    long long wg = blockIdx.x;
+    // within a layer (one x tile, one z chunk) every XCD takes a band of y-adjacent workgroups, whose shared fine rows then meet in one
+    // L2 (512^3: 0.462 -> 0.455 ms)
+    if ((n1w & 3) == 0) {
+      const int wpl = n1w >> 2, per = wpl >> 3;
+      const long long lz = wg / wpl;
+      const int r = (int)(wg - lz * wpl);
+      wg = lz * wpl + (r < (per << 3) ? (r & 7) * per + (r >> 3) : r);
+    }
+    long long t = wg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+    if (t >= nwaves) return;
+    J = box.b1 + (int)(t % n1w) * RW;   // consecutive waves of a workgroup: consecutive coarse rows (shared fine rows)
+    t /= n1w;
+    tx = (int)(t % ntx);
+    kb = box.b2 + (int)(t / ntx) * zc;
   }
-  long long t = wg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
-  if (t >= nwaves) return;
-  const int J = box.b1 + (int)(t % n1w) * RW;   // consecutive waves of a workgroup: consecutive coarse rows (shared fine rows)
-  t /= n1w;
-  const int tx = (int)(t % ntx);
-  const int kb = box.b2 + (int)(t / ntx) * zc;
   const int ke = min(kb + zc, box.e2);
   int I = box.b0 + tx * 63 + lane - 1;
   const bool valid = lane >= 1 && I < box.e0;
@@ -361,6 +377,7 @@ static thread_local int g_restrict_wide = 1;
 // chunks of 8 coarse planes at any size: with a fixed count of 24576 waves the chunks of blocks larger than 512^3 grew long and the
 // front wide (tools/sweep_big_others.py: 768^3 1.86 -> 1.75 ms, 1024^3 4.69 -> 4.16 ms; 512^3 0.527 -> 0.523, there 13 planes before)
 static thread_local int g_rr_waves = 1 << 22, g_rr_minzc = 8, g_rr_rows = 0;   // examg_debug_residual_restrict(waves, minzc [+ 1000: two coarse rows per wave, + 2000: one]); 0 = by size
+static thread_local int g_rr_order = 0;          // examg_debug_rr_order: 1 = x tiles fastest inside the XCD bands of a z layer (measured equal: 0.491 / 0.493 ms at 512^3), 0 = bands of row groups per x tile
 static thread_local int g_restrict_rows = 2;     // examg_debug_restrict(-1 / -2): coarse rows per wave of the wide restriction kernel
 static thread_local int g_restrict_waves = -1;   // examg_debug_restrict(n > 1): wave count target of the wide restriction kernel
 static thread_local int g_prolong_zb = -1;    // planes per workgroup of the pair prolongation (examg_debug_prolong)   // examg_debug_restrict(0): one-thread-per-point kernel everywhere
@@ -382,6 +399,11 @@ extern "C" int examg_debug_residual_restrict(int waves, int minzc) {
   examg::g_rr_rows = minzc >= 2000 ? 1 : (minzc >= 1000 ? 2 : 0);
   minzc %= 1000;
   if (minzc > 0) examg::g_rr_minzc = minzc;
+  return 0;
+}
+
+extern "C" int examg_debug_rr_order(int order) {
+  examg::g_rr_order = order ? 1 : 0;
   return 0;
 }
 
@@ -492,9 +514,11 @@ extern "C" int examg_residual_restrict(const examg_layout_t *lu_, const double *
     if (zc > cb.n2()) zc = cb.n2();
     ntz = (cb.n2() + zc - 1) / zc;
     const long long nwaves = cols * ntz;
-    dim3 grid((unsigned)((nwaves + 3) / 4)), block(64, 4, 1);
+    const int order = g_rr_order;
+    const long long nwg = order == 1 ? (long long)ntz * ntx * (((cb.n1() + rw - 1) / rw + 3) / 4) : (nwaves + 3) / 4;
+    dim3 grid((unsigned)nwg), block(64, 4, 1);
     hipStream_t s = (hipStream_t)stream;
-#define EXAMG_RR(O, W) hipLaunchKernelGGL((k_residual_restrict3<O, W>), grid, block, 0, s, lu, u, lf, rhs, lc, fc, k, scale, cb, ntx, zc, (int)nwaves)
+#define EXAMG_RR(O, W) hipLaunchKernelGGL((k_residual_restrict3<O, W>), grid, block, 0, s, lu, u, lf, rhs, lc, fc, k, scale, cb, ntx, zc, (int)nwaves, order)
     if (rw == 2) {
       if (ord == 0) EXAMG_RR(0, 2);
       else EXAMG_RR(1, 2);

@@ -97,9 +97,9 @@ def cases(ops, level, with27=True, align=0):
         # temporal blocking on the records (csrc/kernels_sf27pair.hip): both loops of a pair share the coefficients of a point
         r27 = ops.new_array(lu.size)
         cs.append(("jacobi_27entry_two_steps", lambda: ops.jacobi2(L, u, un, None, Fn, f27, A27t, 0.8, b, e),
-                   "k_sf27_two_stage<2>", (24 + 8 * 27) * pts, 2 * pts))
+                   "k_sf27_two_stage_r2<2>", (24 + 8 * 27) * pts, 2 * pts))
         cs.append(("jacobi_27entry_step_residual", lambda: ops.jacobi_residual(L, u, un, Fn, f27, L, r27, A27t, 0.8, b, e),
-                   "k_sf27_two_stage<1>", (32 + 8 * 27) * pts, 2 * pts))
+                   "k_sf27_two_stage_r2<1>", (32 + 8 * 27) * pts, 2 * pts))
     return cs, dict(u=u)
 
 

@@ -44,7 +44,7 @@ cases = [("one step, planes", lambda: ops.stencil_op(2, Ls, u, Fs, f, Ls, un, pl
 if dbg:
     L.examg_debug_sf27_pair.argtypes = [C.c_int, C.c_int]
     for rows in (1, 2):
-        for zc in ((32, 64, 128) if rows == 1 else (32, 43, 64, 86, 128, 171, 256)):
+        for zc in ((32, 64, 128) if rows == 1 else ((32, 43, 64, 86, 128, 171, 256) if n > 256 else (12, 16, 22, 26, 32, 43))):
             cases.append(("two steps, one pass, %d rows per wave, %d planes" % (rows, zc),
                           (lambda zc=zc, rows=rows: (L.examg_debug_sf27_pair(10 + rows, zc), ops.jacobi2(Ls, u, un, None, Fs, f, rec, 0.8, b, e))), 240))
     cases.append(("step + residual, one pass, 1 row per wave", lambda: (L.examg_debug_sf27_pair(11, 0), ops.jacobi_residual(Ls, u, un, Fs, f, Ls, res, rec, 0.8, b, e)), 248))
