@@ -831,7 +831,9 @@ static int launch_zmarch(const LayoutDev &lu, const double *u, const LayoutDev &
   g.zc = zc;
   g.ntz = (box.n2() + zc - 1) / zc;
   g.colour = colour;
-  g.store = g_zm_store >= 0 ? g_zm_store : 0;
+  // stores: non-temporal where the loop streams, plain where input, output and right-hand side fit the 256 MB Infinity Cache together and
+  // the next loop over the level reads what this one wrote (kernels_twostage.hip has the measurements for the two-stage passes)
+  g.store = g_zm_store >= 0 ? g_zm_store : (box.count() * 24LL > 200000000LL ? 0 : 2);
   dim3 block(64, ZM_WY, 1), grid(g.ntx * g.nty * g.ntz, 1, 1);
   if (max_waves > 0 && (long long)grid.x * ZM_WY > max_waves) return -1;     // nothing launched
   if (colour >= 0) {

@@ -510,6 +510,7 @@ static thread_local int g_ts_minzc = -1;     // minimum planes per z chunk; -1: 
 //   256^3: LDS-5 0.138, LDS-8 0.119-0.124;  128^3: LDS-5 0.028, LDS-8 0.031
 // ~120 VGPRs -> 4 waves per SIMD = 16 per CU: two 8-wave workgroups fill a CU (a 9-wave workgroup runs alone)
 static thread_local int g_ts_lds = -2;
+static thread_local int g_ts_nt = -1;          // stores of the plain passes: -1 by size, 1 non-temporal, 0 plain (examg_debug_two_stage_nt)
 static thread_local int g_ts_wpe = 1;          // plain passes: 4 = capped at 128 VGPRs (examg_debug_two_stage_prol(wpe + 10) sets it)
 static thread_local int g_ts_prol_wpe = 1;     // PROL variants: 1 = uncapped (151 / 176 VGPRs: 512^3 0.742 ms), 4 = capped at 128 VGPRs (spills in the unrolled loop: 1.15 ms)
 
@@ -600,8 +601,18 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   if (RPW != 2 && (prol || zero_in)) { set_error("examg two-stage kernel: the folded forms have two rows per wave"); return 1; }
   // COL: the kernel instantiation by the parity that fixes which point of a pair each unrolled step updates (see the kernel)
   const int pf = COL ? ((box.b0 - 2 - g.xs) + (box.b1 - g.ys - 1) + (box.b2 - g.zs - 1) + first) & 1 : 0;
-#define EXAMG_TS_LAUNCH(ORD, W, V, PFV) \
-  hipLaunchKernelGGL((k_two_stage7_lds<ORD, COL, NW, true, W, V, PFV, ((V) == 0 ? RPW : 2)>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr)
+  // Stores: non-temporal where the pass streams (its output would only push the inputs of the next pass out of the caches), plain where
+  // the arrays of a level -- input, output, right-hand side -- fit the 256 MB Infinity Cache together and the next pass of the level reads
+  // what this one wrote (tools/ab_nt.py, ping-pong passes, non-temporal / plain, ms: 128^3 0.0158 / 0.0142, 192^3 0.0433 / 0.0339,
+  // 256^3 0.0888 / 0.1086, 384^3 0.305 / 0.333, 512^3 0.652 / 0.708).  Plain passes only.
+  const bool nt = g_ts_nt >= 0 ? g_ts_nt != 0 : box.count() * 24LL > 200000000LL;
+#define EXAMG_TS_LAUNCH(ORD, W, V, PFV)                                                                                                               \
+  do {                                                                                                                                                \
+    if ((V) == 0 && (W) == 1 && !nt)                                                                                                                  \
+      hipLaunchKernelGGL((k_two_stage7_lds<ORD, COL, NW, false, 1, 0, PFV, RPW>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr);           \
+    else                                                                                                                                              \
+      hipLaunchKernelGGL((k_two_stage7_lds<ORD, COL, NW, true, W, V, PFV, ((V) == 0 ? RPW : 2)>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g, pr); \
+  } while (0)
 #define EXAMG_TS_LAUNCH_PF(ORD, W, V)              \
   do {                                             \
     if constexpr (COL) {                           \
@@ -689,6 +700,11 @@ using namespace examg;
 #ifdef EXAMG_DEBUG_HOOKS
 extern "C" int examg_debug_two_stage_lds(int nw) {
   g_ts_lds = nw < 0 ? -2 : nw;
+  return 0;
+}
+
+extern "C" int examg_debug_two_stage_nt(int nt) {
+  g_ts_nt = nt < 0 ? -1 : (nt ? 1 : 0);
   return 0;
 }
 
