@@ -438,7 +438,7 @@ static int fill_impl(const char *who, const examg_layout_t *l_, double *x, const
 
 template <class F>
 static int dirichlet_impl(const char *who, const examg_layout_t *l, double *x, const examg_geom_t *g, const F &fn, uint32_t face_mask,
-                          examg_stream_t stream) {
+                          examg_stream_t stream, bool tangential_ghost = true) {
   if (!l || !x || !g) { set_error("examg_apply_dirichlet: null argument"); return 1; }
   FaceBoxes fb;
   fb.n = 0;
@@ -452,8 +452,8 @@ static int dirichlet_impl(const char *who, const examg_layout_t *l, double *x, c
           if (side == 0) { b[t] = 0; e[t] = l->dup_l[t]; }                       // DLB..DLE
           else { b[t] = l->dup_l[t] + l->inner[t]; e[t] = b[t] + l->dup_r[t]; }  // DRB..DRE
         } else {
-          b[t] = -l->ghost_l[t];                                                 // GLB..GRE
-          e[t] = l->dup_l[t] + l->inner[t] + l->dup_r[t] + l->ghost_r[t];
+          b[t] = tangential_ghost ? -l->ghost_l[t] : 0;                          // GLB..GRE (apply bc) or DLB..DRE (`only dup on boundary`)
+          e[t] = l->dup_l[t] + l->inner[t] + l->dup_r[t] + (tangential_ghost ? l->ghost_r[t] : 0);
         }
       }
       Box bx{b[0], b[1], b[2], e[0], e[1], e[2]};
@@ -506,6 +506,12 @@ extern "C" int examg_apply_dirichlet_expr(const examg_layout_t *l, double *x, co
                                           uint32_t face_mask, examg_stream_t stream) {
   if (!expr_ok(e)) return 1;
   return dirichlet_impl("k_apply_dirichlet_expr", l, x, g, ExprEval{*e}, face_mask, stream);
+}
+
+extern "C" int examg_fill_dup_faces_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, const examg_expr_t *e,
+                                         uint32_t face_mask, examg_stream_t stream) {
+  if (!expr_ok(e)) return 1;
+  return dirichlet_impl("k_fill_dup_faces_expr", l, x, g, ExprEval{*e}, face_mask, stream, false);
 }
 
 extern "C" int examg_init_varcoeff7(const examg_layout_t *lc, double *cfield, const examg_geom_t *g, const examg_expr_t *a,

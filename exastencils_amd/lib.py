@@ -72,7 +72,7 @@ SYMBOLS = [
     "examg_version", "examg_last_error", "examg_device_count", "examg_stencil_op", "examg_jacobi",
     "examg_rbgs_colour", "examg_residual", "examg_rbgs_sweep_fused", "examg_rbgs_sweep_fused_boxes", "examg_jacobi2", "examg_jacobi2_boxes", "examg_jacobi_residual", "examg_rbgs_sweep_fused_prolong", "examg_jacobi2_prolong", "examg_rbgs_sweep_fused_zero", "examg_two_stage_eligible", "examg_restrict", "examg_residual_restrict", "examg_prolong_add",
     "examg_set", "examg_axpby", "examg_axpby_dev", "examg_reduce_work_bytes", "examg_dot", "examg_residual_norm2",
-    "examg_fill_expr", "examg_apply_dirichlet_expr", "examg_max_err_expr", "examg_init_varcoeff7", "examg_init_helmholtz27", "examg_pack", "examg_unpack",
+    "examg_fill_expr", "examg_apply_dirichlet_expr", "examg_fill_dup_faces_expr", "examg_max_err_expr", "examg_init_varcoeff7", "examg_init_helmholtz27", "examg_pack", "examg_unpack",
     "examg_cg_coarse", "examg_cg_coarse_variant", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
     "examg_comm_unique_id", "examg_comm_create", "examg_comm_destroy", "examg_comm_rank", "examg_comm_size",
     "examg_exchange_workspace_bytes", "examg_exchange", "examg_allreduce", "examg_allgather",
@@ -143,6 +143,7 @@ def load(path=None):
     ep = C.POINTER(ExprC)
     L.examg_fill_expr.argtypes = [lp, vp, gp, ep, ip, ip, vp]
     L.examg_apply_dirichlet_expr.argtypes = [lp, vp, gp, ep, C.c_uint32, vp]
+    L.examg_fill_dup_faces_expr.argtypes = [lp, vp, gp, ep, C.c_uint32, vp]
     L.examg_max_err_expr.argtypes = [lp, vp, gp, ep, ip, ip, vp, vp, vp]
     L.examg_init_varcoeff7.argtypes = [lp, vp, gp, ep, ip, ip, vp]
     L.examg_init_helmholtz27.argtypes = [lp, vp, gp, ep, C.c_double, ip, ip, vp]

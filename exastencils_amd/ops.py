@@ -189,6 +189,11 @@ class HipOps:
     def fill_fn(self, l, x, geom, fn: int, params: Sequence[float], begin, end):
         self.fill_expr(l, x, geom, fn_expr(fn, params), begin, end)
 
+    def fill_dup_faces(self, l, x, geom, fn: int, params: Sequence[float], face_mask: int):
+        """`loop over F only dup [dir] on boundary { F = fn }` for every physical face of the mask, one launch."""
+        check(self.L.examg_fill_dup_faces_expr(C.byref(l), self.ptr(x), C.byref(geom), C.byref(fn_expr(fn, params)), int(face_mask), self._stream()),
+              "examg_fill_dup_faces_expr")
+
     def apply_dirichlet(self, l, x, geom, fn: int, params: Sequence[float], face_mask: int):
         self.apply_dirichlet_expr(l, x, geom, fn_expr(fn, params), face_mask)
 

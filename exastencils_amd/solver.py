@@ -868,6 +868,7 @@ class SolverFromL3(_Program):
     # Function VCycle@((coarsest + 1) to finest)
     def VCycle(self, l: int, solution_is_zero: bool = False):
         if l == self.cfg.min_level:
+            self._flush_deferred_correction()
             return self.VCycle_0(l)
         if (self.cfg.fused_smooth_residual and self.cfg.smoother == "jacobi" and self.cfg.n_smooth >= 1 and self._single_block() and
                 not solution_is_zero and hasattr(self.ops, "jacobi_residual")):
@@ -888,7 +889,17 @@ class SolverFromL3(_Program):
             self.Correction(l)
             self.Smoothers(l, self.cfg.n_smooth)
             return
-        self.Smoothers(l, self.cfg.n_smooth, zero_input=solution_is_zero)
+        if getattr(self, "_deferred_correction", None) == l and not solution_is_zero:
+            # first cycle on this level after the FMG start came up from below: its Correction in the first sweep, then ResetBC@coarser
+            self._deferred_correction = None
+            Sc = self.Solution[l - 1]
+            self.communicate(Sc, Sc.active, "ghost")
+            self.Smoother(l, correction_from=Sc)
+            self.ResetBC(l - 1)
+            self.Smoothers(l, self.cfg.n_smooth - 1)
+        else:
+            self._flush_deferred_correction()
+            self.Smoothers(l, self.cfg.n_smooth, zero_input=solution_is_zero)
         if self.cfg.fused_residual_restrict and self._single_block():
             # UpResidual@current + Restriction@current: nothing reads Residual@current before UpResidual writes it again
             S, R, F, Fc = self.Solution[l], self.Residual[l], self.RHS[l], self.RHS[l - 1]
@@ -964,18 +975,10 @@ class SolverFromL3(_Program):
             self._boundary_planes(l, self._rb_alt[l])
 
     def _set_func_dir(self, l: int, array):
-        S, lay, dom = self.Solution[l], self.Solution[l].layout, self.domain
-        for d in range(dom.nd):
-            for side in (-1, 1):
-                if dom.neighbor(d, side) is not None:
-                    continue
-                b, e = [0, 0, 0], [1, 1, 1]
-                for t in range(dom.nd):
-                    if t == d:
-                        b[t], e[t] = (lay.idx("DLB", t), lay.idx("DLE", t)) if side < 0 else (lay.idx("DRB", t), lay.idx("DRE", t))
-                    else:
-                        b[t], e[t] = lay.idx("DLB", t), lay.idx("DRE", t)
-                self.ops.fill_fn(S.lc, array, dom.geom(l), self.cfg.bc_fn, (self.cfg.kappa,), b, e)
+        S, dom = self.Solution[l], self.domain
+        mask = dom.face_mask()
+        if mask:      # every physical face in one launch (six loops in the program text)
+            self.ops.fill_dup_faces(S.lc, array, dom.geom(l), self.cfg.bc_fn, (self.cfg.kappa,), mask)
 
     def InitRHS(self, l: int):
         F = self.RHS[l]
@@ -996,10 +999,23 @@ class SolverFromL3(_Program):
         self.SetFuncDir(l)
         self.InitRHS(l)
         self.VCycle(l)
-        self.Correction(l + 1)
-        self.ResetBC(l)
+        if self._folds_prolongation(l + 1) and self.cfg.smoother == "rbgs":
+            # Correction@(l+1) rides along with the first pre-smoothing sweep of VCycle@(l+1) (the statements in between -- ResetBC@l,
+            # SetFuncDir@(l+1), InitRHS@(l+1) -- neither read nor write what the correction loop writes); ResetBC@l, which changes the
+            # boundary values the correction reads on level l, waits for it (VCycle, _deferred_correction)
+            self._deferred_correction = l + 1
+        else:
+            self.Correction(l + 1)
+            self.ResetBC(l)
         if l != self.cfg.max_level - 1:
             self.FMG(l + 1)
+
+    def _flush_deferred_correction(self):
+        l = getattr(self, "_deferred_correction", None)
+        if l is not None:
+            self._deferred_correction = None
+            self.Correction(l)
+            self.ResetBC(l - 1)
 
     # Function Application: init part
     def setup(self):
@@ -1064,6 +1080,7 @@ class SolverFromL3(_Program):
         for f in getattr(self, "_pair_tmp", {}).values():
             self.apply_bc(f)
         self._func_dir = {}
+        self._deferred_correction = None
         self.log, self.res_history, self.err_history, self.cg_iters = [], [], [], []
         self.setup()
 
@@ -1080,6 +1097,8 @@ class SolverFromL3(_Program):
             out = []
             if cfg.fmg and hi > lo:
                 out.append(("fmg", lambda: self.FMG(lo)))
+                if self._folds_prolongation(hi) and cfg.smoother == "rbgs":
+                    out.append(("cycle_first", lambda: self.VCycle(hi)))      # carries the FMG start's last Correction and ResetBC
             out.append(("cycle", lambda: self.VCycle(hi)))
             return out
 
@@ -1112,10 +1131,14 @@ class SolverFromL3(_Program):
             else:
                 self.FMG(cfg.min_level)
         numIt = 0
+        first = cfg.fmg and use_graph and "cycle_first" in self._graphs
+        if first and (res < cfg.tol * resStart or cfg.max_it <= 0):
+            raise RuntimeError("Solve(use_graph=True): no cycle follows the FMG start, whose last correction the first cycle's graph carries")
         while not (res < cfg.tol * resStart or numIt >= cfg.max_it):
             numIt += 1
             if use_graph:
-                self._graphs["cycle"].replay()
+                self._graphs["cycle_first" if first else "cycle"].replay()
+                first = False
             else:
                 self.VCycle(hi)
             res = self._residual_and_norm(hi)
@@ -1126,6 +1149,7 @@ class SolverFromL3(_Program):
                 self.log.append(reduced_prec(err))
             else:
                 self.log.append(reduced_prec(res))
+        self._flush_deferred_correction()      # no cycle ran after the FMG start
         self._report_cg_limit()
         self.log.append(str(numIt))
         self.iterations = numIt

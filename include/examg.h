@@ -303,6 +303,11 @@ int examg_fill_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, c
  * (IR_IV_NeighborIsValid false) and gets its duplicate plane, tangentially GLB..GRE, set to e(node position). */
 int examg_apply_dirichlet_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, const examg_expr_t *e,
                                uint32_t face_mask, examg_stream_t stream);
+/* `loop over F only dup [dir] on boundary { F = <expr> }` for every direction of the mask in one launch (the SetFuncDir loops of
+ * Testing/FMG/3D_Trigonometric.exa4:189-201; baseExt/ir/IR_LoopOverPointsInOneFragment.scala:57-70): the duplicate plane of each
+ * physical face, tangentially DLB..DRE.  Same values as one examg_fill_expr per face (edges are written by two faces: same value). */
+int examg_fill_dup_faces_expr(const examg_layout_t *l, double *x, const examg_geom_t *g, const examg_expr_t *e,
+                              uint32_t face_mask, examg_stream_t stream);
 /* max |x - e(node position)| over the box (`loop over F with reduction(max : err)`); result in device memory */
 int examg_max_err_expr(const examg_layout_t *l, const double *x, const examg_geom_t *g, const examg_expr_t *e,
                        const int32_t *begin, const int32_t *end, double *result, void *work, examg_stream_t stream);

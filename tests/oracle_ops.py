@@ -268,6 +268,22 @@ class OracleOps:
     def fill_fn(self, l, x, geom, fn, params, begin, end):
         self.L.orc_fill_fn(_lp(l), self.ptr(x), _gp(geom), int(fn), _p4(params), _iv(begin), _iv(end))
 
+    def fill_dup_faces(self, l, x, geom, fn, params, face_mask):
+        """One fill per face: duplicate plane, tangentially DLB..DRE (`only dup [dir] on boundary`)."""
+        nd = l.nd
+        for d in range(nd):
+            for side in (0, 1):
+                if not (face_mask >> (2 * d + side)) & 1:
+                    continue
+                b, e = [0, 0, 0], [1, 1, 1]
+                for t in range(nd):
+                    if t == d:
+                        b[t] = 0 if side == 0 else l.dup_l[t] + l.inner[t]
+                        e[t] = b[t] + (l.dup_l[t] if side == 0 else l.dup_r[t])
+                    else:
+                        b[t], e[t] = 0, l.dup_l[t] + l.inner[t] + l.dup_r[t]
+                self.fill_fn(l, x, geom, fn, params, b, e)
+
     def apply_dirichlet(self, l, x, geom, fn, params, face_mask):
         nd = l.nd
         for d in range(nd):

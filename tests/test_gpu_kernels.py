@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle_ops import OracleOps
 
-from exastencils_amd.field import (FN_KAPPA_COEF, FN_KAPPA_EXPSOL, FN_KAPPA_RHS, FN_POLY3D, FN_TRIG2D_SOL,
+from exastencils_amd.field import (FN_KAPPA_COEF, FN_KAPPA_EXPSOL, FN_KAPPA_RHS, FN_POLY3D, FN_TRIG2D_SOL, FN_XSQ,
                                    FN_TRIG3D_SOL, Stencil, laplace_fd, laplace_unit, stencil_field_offsets)
 from exastencils_amd.layout import FieldLayout
 from exastencils_amd.lib import GeomC
@@ -1104,6 +1104,22 @@ def test_fused_kernels_on_a_large_odd_block(hipd):
     finally:
         hip.L.examg_debug_restrict(1)
     assert torch.equal(fc1, fc2)
+
+
+@pytest.mark.parametrize("nd,shape,mask", [(3, (12, 10, 8), 63), (3, (12, 10, 8), 0b100110), (2, (20, 14, 0), 15), (3, (6, 6, 6), 0)])
+def test_fill_of_the_duplicate_planes_of_all_physical_faces_in_one_launch(hip, orc, nd, shape, mask):
+    """examg_fill_dup_faces_expr (`loop over F only dup [dir] on boundary`, the SetFuncDir loops of Testing/FMG/3D_Trigonometric.exa4) equals
+    one fill per face: duplicate plane, tangentially DLB..DRE -- ghost layers and interior untouched."""
+    l = FieldLayout.node(nd, shape, 2)
+    g = geom(nd, max(shape), 0.25)
+
+    def run(ops):
+        x = ops.new_array(l.size)
+        ops.fill_random(x, 3)
+        ops.fill_dup_faces(l.c_struct(), x, g, FN_POLY3D if nd == 3 else FN_XSQ, (), mask)
+        return ops.to_host(x).copy()
+
+    assert np.array_equal(run(hip), run(orc))
 
 
 def test_expression_programs_on_device(hip, orc):
