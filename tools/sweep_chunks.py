@@ -11,7 +11,7 @@ from exastencils_amd.ops import HipOps
 
 ops = HipOps(0, lib.DBG_LIB_PATH)
 L = ops.L
-n = 512
+n = ([int(a) for a in sys.argv[1:] if a.isdigit()] or [512])[0]
 lu, lf = FieldLayout.node(3, (n, n, n), 1), FieldLayout.node(3, (n, n, n), 0, True, False)
 u, un, f = ops.new_array(lu.size), ops.new_array(lu.size), ops.new_array(lf.size)
 ops.fill_random(u, 1); ops.fill_random(f, 2)
@@ -31,11 +31,12 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / reps
 
 
-ntzs = [32, 29, 26, 22, 19, 18, 17, 16, 13]
+ntzs = [32, 29, 26, 22, 19, 18, 17, 16, 13] if n == 512 else [3, 4, 5, 6, 7, 8, 9, 11, 13, 16]
+xy = 120 if n == 512 else 57
 res = {(k, t): [] for k in cases for t in ntzs}
 for rep in range(4):
     for t in ntzs:
-        L.examg_debug_two_stage(0, 120 * t, -1, 8)
+        L.examg_debug_two_stage(0, xy * t, -1, 8)
         for k, fn in cases.items():
             fn(); v = timed(fn)
             if rep:
