@@ -216,12 +216,16 @@ def _two_stage_reference(orc, kind, shape, st, b, e, first=0):
     return [orc.to_host(out), orc.to_host(u)]
 
 
-@pytest.fixture(params=[5, 8, 83], ids=["lds5", "lds8", "lds8x3"])
-def two_stage_variant(request, hipd):
-    """The workgroup shapes of the two-stage kernel (5 or 8 waves with two rows each, 8 waves with three rows each -- plain passes --
-    share a row stack through LDS), forced through the debug build; yields the kernel layer to use."""
+@pytest.fixture(params=[None, 5, 8, 83], ids=["product", "lds5", "lds8", "lds8x3"])
+def two_stage_variant(request, hip, hipd):
+    """The product library with its own choice of workgroup shape, then every shape of the two-stage kernel (5 or 8 waves with two rows
+    each, 8 waves with three rows each -- plain passes -- share a row stack through LDS) forced through the debug build; yields the kernel
+    layer to use."""
     import ctypes as C
 
+    if request.param is None:
+        yield hip
+        return
     hipd.L.examg_debug_two_stage_lds.argtypes = [C.c_int]
     hipd.L.examg_debug_two_stage_lds(request.param)
     yield hipd
