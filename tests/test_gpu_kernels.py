@@ -640,19 +640,47 @@ def _sf27_pair_case(ops, shape, b1, e1, b2, e2, kind, entry_fastest=True, cghost
     return [ko, kr, u]
 
 
-@pytest.mark.parametrize("kind", ["pair", "residual"])
-@pytest.mark.parametrize("shape,b1,e1,b2,e2,cghost", [
-    ((66, 66, 66), [1, 1, 1], [66, 66, 66], [1, 1, 1], [66, 66, 66], 0),       # two x windows, ragged row groups, one chunk (two rows per wave)
-    ((130, 40, 70), [1, 1, 1], [130, 40, 70], [1, 1, 1], [130, 40, 70], 0),    # three windows, two z chunks of 64 / 5 planes (one row per wave)
-    ((130, 40, 20), [0, 1, 0], [131, 40, 21], [0, 1, 0], [131, 40, 21], 0),    # interior faces: the halo reaches the ghost layers
+SF27_PAIR_BOXES = [
+    ((66, 66, 66), [1, 1, 1], [66, 66, 66], [1, 1, 1], [66, 66, 66], 0),       # two x windows, ragged row groups
+    ((130, 40, 70), [1, 1, 1], [130, 40, 70], [1, 1, 1], [130, 40, 70], 0),    # three windows
+    ((130, 40, 20), [0, 1, 0], [131, 40, 21], [0, 1, 0], [131, 40, 21], 0),    # interior faces: the halo reaches the ghost layers (one row per wave only)
     ((200, 24, 36), [0, 0, 0], [201, 25, 37], [1, 1, 1], [200, 24, 36], 0),    # separate stage boxes (block with neighbours)
     ((130, 60, 70), [1, 1, 1], [130, 60, 70], [1, 1, 1], [130, 60, 70], 0),    # two rows per wave: last window moved left, tiles of 14 + 14 + 14 + 14 + 3 rows
     ((136, 47, 9), [0, 0, 0], [137, 48, 10], [1, 1, 1], [136, 47, 9], 1),      # two rows per wave, separate stage boxes, coefficients with ghost layers
-    ((64, 48, 5), [2, 1, 1], [63, 47, 4], [2, 3, 1], [63, 47, 4], 0),          # two rows per wave, one window, boxes off the array edges
-])
-def test_two_jacobi_steps_on_a_27_entry_field_in_one_pass(hip, orc, kind, shape, b1, e1, b2, e2, cghost):
+    ((64, 48, 5), [2, 1, 1], [63, 47, 4], [2, 3, 1], [63, 47, 4], 0),          # one window, boxes off the array edges
+]
+
+
+@pytest.mark.parametrize("kind", ["pair", "residual"])
+@pytest.mark.parametrize("rows,zc", [(1, 0), (1, 7), (2, 0), (2, 6)], ids=["one-row", "one-row-chunks", "two-rows", "two-rows-chunks"])
+@pytest.mark.parametrize("shape,b1,e1,b2,e2,cghost", SF27_PAIR_BOXES)
+def test_two_jacobi_steps_on_a_27_entry_field_in_one_pass(hipd, orc, kind, rows, zc, shape, b1, e1, b2, e2, cghost):
     """Temporal blocking on config 4's operator (csrc/kernels_sf27pair.hip): both steps of a point share its 216 B of coefficients.
-    Same 27 products in the same order as the one-step loops: bit-identical to running them one after the other (oracle)."""
+    Same 27 products in the same order as the one-step loops: bit-identical to running them one after the other (oracle).  Both kernels
+    (one row per wave / two rows per wave with the records by LDS-DMA; the second keeps to the first where a box reaches the first or last
+    array column), forced through the debug build at sizes the product library leaves to two launches, with and without short z chunks."""
+    import ctypes as C
+
+    if kind == "residual" and (b1, e1) != (b2, e2):
+        pytest.skip("one step + residual has a single box")
+    hipd.L.examg_debug_sf27_pair.argtypes = [C.c_int, C.c_int]
+    hipd.L.examg_debug_sf27_pair(10 + rows, zc)
+    try:
+        g = _sf27_pair_case(hipd, shape, b1, e1, b2, e2, kind, cghost=cghost)
+        hipd.synchronize()
+    finally:
+        hipd.L.examg_debug_sf27_pair(1, 0)
+    c = _sf27_pair_case(orc, shape, b1, e1, b2, e2, kind, entry_fastest=False, cghost=cghost)
+    assert_same([hipd.to_host(t) for t in g], [orc.to_host(t) for t in c], "27-entry pair " + kind)
+
+
+@pytest.mark.parametrize("kind", ["pair", "residual"])
+@pytest.mark.parametrize("shape,b1,e1,b2,e2,cghost", [
+    ((130, 100, 90), [1, 1, 1], [130, 100, 90], [1, 1, 1], [130, 100, 90], 0),     # 1.14 * 10^6 points: the product library takes the pass
+    ((136, 100, 84), [0, 0, 0], [137, 101, 85], [1, 1, 1], [136, 100, 84], 1),     # ... with separate stage boxes
+])
+def test_two_jacobi_steps_on_a_27_entry_field_product_library(hip, orc, kind, shape, b1, e1, b2, e2, cghost):
+    """The same pass as the product library launches it (from 2^20 points; its own choice of kernel and chunk length)."""
     if kind == "residual" and (b1, e1) != (b2, e2):
         pytest.skip("one step + residual has a single box")
     g = _sf27_pair_case(hip, shape, b1, e1, b2, e2, kind, cghost=cghost)
