@@ -16,6 +16,7 @@ if [ $rc -ne 0 ]; then tail -5 $R/gpurun_out/prof_${ROUND}_bench.err; exit $rc; 
 cd $R
 for d in smoother bench; do f=$(ls gpurun_out/prof_${ROUND}_$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f gpurun_out/${ROUND}_bench$([ $d = smoother ] && echo _smoother_only)_kernel_stats.csv; done
 bash tools/gpu_vtrace.sh && cp gpurun_out/vtrace.txt gpurun_out/${ROUND}_vcycle_timeline.txt
+( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/fmgtrace -- python3 $R/tools/fmg_trace.py > $R/gpurun_out/fmgtrace.log 2>&1 ) && python3 tools/vcycle_trace_reduce.py gpurun_out/fmgtrace > gpurun_out/${ROUND}_fmg_timeline.txt && tail -1 gpurun_out/${ROUND}_fmg_timeline.txt
 LEVEL=9 ROUND=$ROUND bash tools/gpu_pmc.sh || exit 1
 LEVEL=8 ROUND=$ROUND bash tools/gpu_pmc.sh || exit 1
 timeout -k 10 200 python tools/exchange_faces.py > gpurun_out/${ROUND}_exchange_faces.json 2> /dev/null; cat gpurun_out/${ROUND}_exchange_faces.json
