@@ -85,6 +85,24 @@ def test_fmg_driver_with_one_pass_forms():
     assert plain.res_history == O.res_history
 
 
+def test_fmg_start_without_a_following_cycle_still_applies_its_last_correction():
+    """The FMG start leaves Correction@finest (and ResetBC of the level below) to the first sweep of the cycle that follows; when no
+    cycle follows (the loop condition of Solve is false at once) they run where the program has them: same Solution as the plain driver."""
+    import numpy as np
+
+    kw = dict(nd=3, min_level=2, max_level=5, smoother="rbgs", omega=1.0, stencil="scaled", restrict_scale=1.0, tol=2.0, bc_fn=1, fmg=True)
+    plain = SolverFromL3(ConfigL3(**kw), OracleOps())
+    plain.setup()
+    plain.Solve()
+    fused = SolverFromL3(ConfigL3(**kw, fused_rbgs=True, fused_residual_restrict=True, fused_prolong_min_points=1, fused_zero_start=True), OracleOps())
+    fused.setup()
+    assert fused._folds_prolongation(5)
+    fused.Solve()
+    assert plain.iterations == 0 and fused.iterations == 0 and getattr(fused, "_deferred_correction", None) is None
+    for l in (4, 5):
+        assert np.array_equal(plain.ops.to_host(plain.Solution[l].data()), fused.ops.to_host(fused.Solution[l].data()))
+
+
 def test_one_call_coarse_solve_keeps_the_iteration_limit_message():
     """`print ( "Maximum number of cgs iterations (", n, ") was exceeded" )` after the CG loop: the one-call coarse solve counts the
     event on the device and the driver appends the message when Solve ends -- as often as the statement-by-statement driver prints it."""
