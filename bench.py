@@ -57,6 +57,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true")
     ap.add_argument("--settle-steps", type=int, default=150, help="untimed smoother steps before the warm-up (device clocks reach their steady state)")
+    ap.add_argument("--halo", choices=("deep", "shell"), default="deep",
+                    help="N > 1: two ghost layers and one kernel per pass (deep), or one ghost layer and interior + shell launches (shell)")
     ap.add_argument("--preflight-timeout", type=float, default=180.0, help="N > 1: seconds the first exchange + pass may take")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-temporal-blocking", action="store_true", help="one kernel launch per smoother step")
@@ -278,8 +280,13 @@ def run(args, world, rank, local_rank, dist, injected=False):
     else:
         comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
     nc = dom.ncells(L)
-    Solution = Field("Solution", L, FieldLayout.node(nd, nc, 1, True, True, args.align), ops, 2, None)
-    RHS = Field("RHS", L, FieldLayout.node(nd, nc, 0, False, False, args.align), ops, 1, None)
+    # N > 1: two ghost layers on Solution and one on RHS (the layouts' `ghostLayers`; the reference needs as many for its contracting
+    # loops, baseExt/ir/IR_ContractingLoop.scala:45-196): a two-step pass is then ONE exchange and ONE kernel per block -- the first stage
+    # also covers the neighbour's first plane -- instead of an interior kernel beside a shell of thin launches and two exchanges
+    # (--halo shell: that scheme, one ghost layer; exastencils_amd/smoothers.py)
+    deep = world > 1 and args.halo == "deep"
+    Solution = Field("Solution", L, FieldLayout.node(nd, nc, 2 if deep else 1, True, True, args.align), ops, 2, None)
+    RHS = Field("RHS", L, FieldLayout.node(nd, nc, 1, True, True, args.align) if deep else FieldLayout.node(nd, nc, 0, False, False, args.align), ops, 1, None)
     # synthetic data: one global random field, so that the duplicate planes two blocks share hold the same values on both
     for t, seed in ((Solution.data(0), 12345), (Solution.data(1), 12345), (RHS.data(), 777)):
         ops.fill_random(t, seed + (0 if world == 1 else 1000 * rank))
@@ -301,9 +308,12 @@ def run(args, world, rank, local_rank, dist, injected=False):
         full = Communicator(dom, ops, dist_module=dist_module)
         for s_ in (0, 1):
             full.exchange(Solution, s_, "all")
-        rhs_alias = Field("RHS", L, FieldLayout.node(nd, nc, 0, True, False, args.align), ops, 1, None)
-        rhs_alias.slots[0] = RHS.data()
-        full.exchange(rhs_alias, None, "dup")
+        if deep:
+            full.exchange(RHS, None, "all")
+        else:
+            rhs_alias = Field("RHS", L, FieldLayout.node(nd, nc, 0, True, False, args.align), ops, 1, None)
+            rhs_alias.slots[0] = RHS.data()
+            full.exchange(rhs_alias, None, "dup")
 
     def step():
         # Function Smoother@finest: communicate ghost of Solution<active>; Jacobi loop; advance
@@ -525,7 +535,7 @@ def run(args, world, rank, local_rank, dist, injected=False):
         except Exception as ex:
             more["config1_error"] = repr(ex)[:300]
         try:
-            more.update(vcycle(ops, dom, comm, L, world, args.align, check_dups=not args.no_check_duplicates))
+            more.update(vcycle(ops, dom, comm, L, world, args.align, check_dups=not args.no_check_duplicates, deep_halo=args.halo == "deep"))
         except Exception as ex:  # the headline number must not depend on the extra measurement
             more["vcycle_error"] = repr(ex)[:300]
         if world == 1:
@@ -703,7 +713,7 @@ def config1(ops, world):
     return out
 
 
-def vcycle(ops, dom, comm, L, world, align=0, check_dups=True):
+def vcycle(ops, dom, comm, L, world, align=0, check_dups=True, deep_halo=True):
     """Config 3: one V(3,3) red-black cycle of Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4, 6 levels."""
     import torch
 
@@ -715,7 +725,7 @@ def vcycle(ops, dom, comm, L, world, align=0, check_dups=True):
     # coarsens log2(max blocks per dimension) levels further, back to a few hundred points
     extra = max(dom.num_blocks).bit_length() - 1 if world > 1 else 0
     cfg = ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True, agglomerate_level=agg, fused_prolong_min_points=10_000_000, fused_zero_start=True, fused_residual_norm=True,
-                   agglomerate_extra_levels=extra, align=align)
+                   agglomerate_extra_levels=extra, align=align, deep_halo=deep_halo)
     P = SolverFromL4(cfg, ops, dom, comm)
 
     def rendezvous():

@@ -437,7 +437,8 @@ class Communicator:
                 buf.copy_(wire)
             ops.unpack(f.lc, x, buf, box[0], box[1])
 
-    def c_pass(self, kind: str, S: Field, u_in, u_out, tmp, F: Field, A, w: float, first: int, begin, end, axis_only: bool, overlap: bool):
+    def c_pass(self, kind: str, S: Field, u_in, u_out, tmp, F: Field, A, w: float, first: int, begin, end, axis_only: bool, overlap: bool,
+               tmp_planes_valid: bool = False):
         """One overlapped smoother pass on a block with neighbours as ONE library call (examg_jacobi2_blocks /
         examg_rbgs_sweep_blocks: interior two-stage kernel on the launch stream, exchanges and shell launches on the
         communicator's side stream).  Only with the C transport; True if the call was made."""
@@ -450,6 +451,8 @@ class Communicator:
         ops, L = self.ops, self.ops.L
         wsp, nbytes = self._workspace(S.lc, S.layout)
         flags = _lib.EXCH_CONCURRENT_AXES if (self.concurrent_ghost_axes and axis_only) else 0
+        if tmp_planes_valid:      # the caller wrote tmp's physical-face planes once (position-only Dirichlet values)
+            flags |= _lib.PASS_TMP_PLANES_VALID
         sc = A.c_struct(ops.ptr)
         if kind == "jacobi2":
             rc = L.examg_jacobi2_blocks(self._c, C.byref(self._nb), C.byref(S.lc), ops.ptr(u_in), ops.ptr(u_out), ops.ptr(tmp), C.byref(F.lc),

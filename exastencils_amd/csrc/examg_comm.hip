@@ -318,7 +318,14 @@ namespace {
 typedef examg_comm Overlap;
 Overlap *overlap_of(examg_comm_t *c) {
   if (!c->side) {
-    if (check_hip(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    // the shell work -- exchanges and thin launches -- is a chain of short kernels beside a pass that fills the chip: at the highest
+    // priority its workgroups are placed ahead of the interior pass' (EXAMG_SIDE_PRIORITY=0: default priority, for A/B runs)
+    int least = 0, greatest = 0;
+    const char *pe = getenv("EXAMG_SIDE_PRIORITY");
+    const bool high = !(pe && pe[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
+    if (check_hip(high ? hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking),
+                  "hipStreamCreate"))
+      return nullptr;
     if (check_hip(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming), "hipEventCreate")) return nullptr;
     if (check_hip(hipEventCreateWithFlags(&c->join, hipEventDisableTiming), "hipEventCreate")) return nullptr;
   }
@@ -400,13 +407,12 @@ int pass_blocks(const char *who, examg_comm_t *comm, const examg_neighbors_t *nb
   };
   auto shell = [&](hipStream_t s) -> int {
     if (examg_exchange(comm, lu, const_cast<double *>(u_in), nb, what, workspace, workspace_bytes, s)) return 1;
-    if (copy_physical_planes(lu, nb, u_in, tmp, s)) return 1;
+    if (!(exchange_flags & EXAMG_PASS_TMP_PLANES_VALID) && copy_physical_planes(lu, nb, u_in, tmp, s)) return 1;
     int32_t sb[3], se[3];
     for (int i = 0; i < f.n; ++i) {        // first stage on three planes
       slab(begin, end, f.d[i], f.side[i], 3, sb, se);
-      if (COL) {                           // tmp = u_in on the slab, then the colour's points (reads u_in only)
-        if (examg_axpby(lu, u_in, lu, tmp, 1.0, 0.0, sb, se, s)) return 1;
-        if (examg_stencil_op(EXAMG_SMOOTH, lu, u_in, lf, rhs, lu, tmp, st, w, first, sb, se, s)) return 1;
+      if (COL) {                           // tmp = u_in on the slab with the colour's points updated (reads u_in only): one launch
+        if (stencil_colour_passthrough(lu, u_in, lf, rhs, lu, tmp, st, w, first, sb, se, s)) return 1;
       } else if (examg_stencil_op(EXAMG_SMOOTH, lu, u_in, lf, rhs, lu, tmp, st, w, -1, sb, se, s)) {
         return 1;
       }
@@ -415,8 +421,7 @@ int pass_blocks(const char *who, examg_comm_t *comm, const examg_neighbors_t *nb
     for (int i = 0; i < f.n; ++i) {        // second stage on two planes
       slab(begin, end, f.d[i], f.side[i], 2, sb, se);
       if (COL) {
-        if (examg_axpby(lu, tmp, lu, u_out, 1.0, 0.0, sb, se, s)) return 1;
-        if (examg_stencil_op(EXAMG_SMOOTH, lu, tmp, lf, rhs, lu, u_out, st, w, 1 - first, sb, se, s)) return 1;
+        if (stencil_colour_passthrough(lu, tmp, lf, rhs, lu, u_out, st, w, 1 - first, sb, se, s)) return 1;
       } else if (examg_stencil_op(EXAMG_SMOOTH, lu, tmp, lf, rhs, lu, u_out, st, w, -1, sb, se, s)) {
         return 1;
       }

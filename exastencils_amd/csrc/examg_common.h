@@ -106,6 +106,10 @@ bool small_residual_restrict_ok(const examg_layout_t *lu, const examg_layout_t *
 int launch_small_residual_restrict(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs, const examg_layout_t *lc,
                                    double *fc, const examg_stencil_t *st, double scale, const Box &cb, hipStream_t s);
 
+// coloured loop out of place with the other colour carried over (kernels_stencil.hip), for the shell passes of examg_comm.hip
+int stencil_colour_passthrough(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs, const examg_layout_t *ld,
+                               double *dst, const examg_stencil_t *st, double w, int colour, const int32_t *begin, const int32_t *end, hipStream_t s);
+
 #define EXAMG_CHECK_LAUNCH(name)                                   \
   do {                                                             \
     hipError_t _e = hipGetLastError();                             \

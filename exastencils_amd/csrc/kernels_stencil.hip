@@ -33,7 +33,7 @@ struct StencilDev {
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_stencil_generic(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs, LayoutDev ld,
-                  double *dst, LayoutDev lc, StencilDev st, double w, int colour, Box box, int row_w) {
+                  double *dst, LayoutDev lc, StencilDev st, double w, int colour, Box box, int row_w, int passthru) {
   const long long rows = (long long)box.n1() * box.n2();
   const long long total = rows * row_w;
   const bool small = total < (1LL << 31);      // 32-bit index arithmetic (wave-uniform choice; same indices)
@@ -55,6 +55,10 @@ k_stencil_generic(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, cons
       // points of this row with (i0+i1+i2) % 2 == colour, no idle lanes
       const int first = box.b0 + (((box.b0 + i1 + i2) & 1) != colour ? 1 : 0);
       i0 = first + 2 * c0;
+      if (passthru) {      // out of place: the other point of the pair is carried over (dst = u there), one loop instead of copy + loop
+        const int p = first == box.b0 ? i0 + 1 : i0 - 1;
+        if (p >= box.b0 && p < box.e0) dst[lidx(ld, p, i1, i2)] = u[lidx(lu, p, i1, i2)];
+      }
     } else {
       i0 = box.b0 + c0;
     }
@@ -716,6 +720,7 @@ k_rbgs_half_split7(LayoutDev lu, double *__restrict__ u, LayoutDev lf, const dou
 }
 
 static thread_local int g_force_generic = 0;  // test hook (debug build only): examg_debug_force_generic
+static thread_local int g_passthru = 0;       // stencil_colour_passthrough (below): coloured loop out of place, the other colour carried over
 // workgroup cap of the unrolled stencil-field kernel: none.  One short-lived workgroup per 256 points, dispatched in order, keeps
 // the front that sweeps the 30 streams (27 coefficient planes, u, rhs, dst) narrow: 512^3, 27 entries: 7.8 ms with 16384
 // grid-striding workgroups, 6.85 ms uncapped (round-2 sweep through examg_debug_sf27_blocks); a tiled form with XCD-contiguous order: 7.7 ms.
@@ -893,6 +898,18 @@ extern "C" int examg_debug_force_generic(int on) {
 }
 #endif
 
+namespace examg {
+// `dst = u` on the box followed by the coloured loop from u into dst (the shell passes of examg_rbgs_sweep_blocks), as ONE launch: the
+// generic kernel writes the colour's points and carries the others over.  Same values as the two launches.
+int stencil_colour_passthrough(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs, const examg_layout_t *ld,
+                               double *dst, const examg_stencil_t *st, double w, int colour, const int32_t *begin, const int32_t *end, hipStream_t s) {
+  g_passthru = 1;
+  const int rc = examg_stencil_op(EXAMG_SMOOTH, lu, u, lf, rhs, ld, dst, st, w, colour, begin, end, (examg_stream_t)s);
+  g_passthru = 0;
+  return rc;
+}
+}  // namespace examg
+
 extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_,
                                 const double *rhs, const examg_layout_t *ld_, double *dst, const examg_stencil_t *st,
                                 double w, int colour, const int32_t *begin, const int32_t *end, examg_stream_t stream) {
@@ -918,7 +935,8 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   // index; the coefficient field of a stencil field has its own transformation (ctransform) and a plain clayout
   const bool transformed = lay_split(lu_) || lay_split(ld_) || (lf_ && lay_split(lf_));
   if (st->cfield && lay_split(&st->clayout)) { set_error("examg_stencil_op: the coefficient layout of a stencil field cannot be colour-split"); return 1; }
-  const bool force_generic = g_force_generic || transformed;
+  const int passthru = (g_passthru && colour >= 0 && u != dst) ? 1 : 0;
+  const bool force_generic = g_force_generic || transformed || passthru;
   const int ord = canonical_order7(st);
   if (transformed && !g_force_generic && mode == EXAMG_SMOOTH && colour >= 0 && u == dst && lay_split(lu_) && memcmp(lu_, ld_, sizeof(*lu_)) == 0 &&
       lu_->nd == 3 && ord >= 0 && box.n0() >= 32 && box_inside(lu_, box, 1)) {
@@ -1035,11 +1053,11 @@ extern "C" int examg_stencil_op(int mode, const examg_layout_t *lu_, const doubl
   if (nb > 8192) nb = 8192;
   dim3 grid((unsigned)nb), block(256);
   if (mode == EXAMG_APPLY)
-    hipLaunchKernelGGL((k_stencil_generic<EXAMG_APPLY>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, lc, sd, w, colour, box, row_w);
+    hipLaunchKernelGGL((k_stencil_generic<EXAMG_APPLY>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, lc, sd, w, colour, box, row_w, passthru);
   else if (mode == EXAMG_RESIDUAL)
-    hipLaunchKernelGGL((k_stencil_generic<EXAMG_RESIDUAL>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, lc, sd, w, colour, box, row_w);
+    hipLaunchKernelGGL((k_stencil_generic<EXAMG_RESIDUAL>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, lc, sd, w, colour, box, row_w, passthru);
   else
-    hipLaunchKernelGGL((k_stencil_generic<EXAMG_SMOOTH>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, lc, sd, w, colour, box, row_w);
+    hipLaunchKernelGGL((k_stencil_generic<EXAMG_SMOOTH>), grid, block, 0, s, lu, u, lf, rhs, ld, dst, lc, sd, w, colour, box, row_w, passthru);
   EXAMG_CHECK_LAUNCH("k_stencil_generic");
   return 0;
 }

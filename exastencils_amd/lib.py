@@ -85,6 +85,7 @@ SYMBOLS = [
 COMM_ID_BYTES = 128
 PEER_HANDLE_BYTES = 128
 EXCH_DUP, EXCH_GHOST, EXCH_ALL, EXCH_CONCURRENT_AXES = 1, 2, 3, 4
+PASS_TMP_PLANES_VALID = 8
 CG_ALPHA_FROM_NORM, CG_NO_BC, CG_ZERO_START = 1, 2, 4
 
 

@@ -50,7 +50,10 @@ class HipOps:
     def side_stream(self):
         """A second HIP stream for halo traffic that overlaps the interior kernels."""
         if getattr(self, "_side", None) is None:
-            self._side = self.torch.cuda.Stream(self.device)
+            # high priority: short shell kernels beside a pass that fills the chip (csrc/examg_comm.hip: overlap_of)
+            import os
+
+            self._side = self.torch.cuda.Stream(self.device, priority=0 if os.environ.get("EXAMG_SIDE_PRIORITY") == "0" else -1)
         return self._side
 
     def to_host(self, t):

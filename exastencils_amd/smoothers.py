@@ -24,6 +24,33 @@ from __future__ import annotations
 SMOOTH = 2
 
 
+def deep_halo_boxes(ops, domain, S, F, A, b, e, faces):
+    """Temporal blocking across block neighbours by DEEPER HALOS instead of a recomputed shell -- the reference's own way
+    (baseExt/ir/IR_ContractingLoop.scala:45-196 on a layout with `ghostLayers` >= 2): with two exchanged ghost layers of the input (and
+    one of the right-hand side) the first stage runs on the loop's box grown by one point across every interior face -- the neighbour's
+    first plane is computed here too, from the same bits with the same kernel -- and the second stage on the loop's own box: ONE exchange
+    and ONE kernel per pass, no scratch field, nothing beside the kernel that competes with it.  Returns the first-stage box, or None
+    when the layouts have no room for it (then the shell scheme below runs)."""
+    lay, flay = S.layout, F.layout
+    if not faces or any(lay.ghost[d] < 2 or flay.ghost[d] < 1 for d, _ in faces) or not (lay.communicates_ghost and flay.communicates_ghost):
+        return None
+    b1, e1 = list(b), list(e)
+    for d, side in faces:
+        if side < 0:
+            b1[d] = b[d] - 1
+        else:
+            e1[d] = e[d] + 1
+    if hasattr(ops, "two_stage_eligible") and not ops.two_stage_eligible(S.lc, F.lc, A, b1, e1, list(b), list(e)):
+        return None
+    return b1, e1
+
+
+def _edges_matter(faces) -> bool:
+    """More than one axis with neighbours: the first stage on a ghost plane reads edge ghosts, which only the axis-by-axis exchange fills."""
+    return len({d for d, _ in faces}) > 1
+
+
+
 def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool = True, correction_from=None):
     """Two applications of `Smoother@current` (Testing/Smoothers/Jac.exa4:125-131) on field S (2 slots):
     reads slot <active>, leaves the result in the slot two `advance`s would make active (the same one),
@@ -92,6 +119,12 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool =
         S.advance()
         return
     assert correction_from is None, "the folded correction needs a block without neighbours"
+    deep = deep_halo_boxes(ops, domain, S, F, A, b, e, faces)
+    if deep is not None:
+        comm.exchange(S, src, "ghost", axis_only and not _edges_matter(faces))
+        ops.jacobi2_boxes(S.lc, S.data(src), S.data(dst), tmp_field.data(), F.lc, F.data(), A, w, deep[0], deep[1], list(b), list(e))
+        S.advance()
+        return
     # product path on GPUs: the whole choreography below as ONE library call (csrc/examg_comm.hip: pass_blocks) -- the Python
     # form that follows is the same sequence statement by statement; it serves the CPU kernel layer (gloo tests) and is what
     # the library call is tested against (tests/test_gpu_transport.py)
@@ -122,7 +155,7 @@ def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool =
     S.advance()
 
 
-def rbgs_sweep(ops, comm, domain, S, F, A, w: float, alt, tmp_field, first: int = 0, overlap: bool = True):
+def rbgs_sweep(ops, comm, domain, S, F, A, w: float, alt, tmp_field, first: int = 0, overlap: bool = True, tmp_planes_valid: bool = False):
     """One red-black sweep of `repeat { color with { (i0+i1+i2) % 2, communicate S; loop over S { S += w (F - A S) };
     apply bc to S } }` (Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:204-213) on a block WITH neighbours, out of place
     from S's array into `alt`; returns the array that is free afterwards (S's former one) -- the two change roles.
@@ -160,7 +193,14 @@ def rbgs_sweep(ops, comm, domain, S, F, A, w: float, alt, tmp_field, first: int 
             sb[d] = max(e[d] - k, b[d])
         return sb, se
 
-    if hasattr(comm, "c_pass") and comm.c_pass("rbgs", S, src, alt, tmp_field.data(), F, A, w, first, b, e, axis_only, overlap):
+    deep = deep_halo_boxes(ops, domain, S, F, A, b, e, faces)
+    if deep is not None:
+        comm.exchange(S, None, "ghost", axis_only and not _edges_matter(faces))
+        scratch = None if hasattr(ops, "two_stage_eligible") else tmp_field.data()      # the CPU kernel layer runs the two loops through a copy
+        ops.rbgs_sweep_fused_boxes(S.lc, src, alt, scratch, F.lc, F.data(), A, w, first, deep[0], deep[1], list(b), list(e))
+        S.slots[S.active] = alt
+        return src
+    if hasattr(comm, "c_pass") and comm.c_pass("rbgs", S, src, alt, tmp_field.data(), F, A, w, first, b, e, axis_only, overlap, tmp_planes_valid):
         S.slots[S.active] = alt        # one library call did interior + shell (see jacobi_pair)
         return src
     b1, e1 = shrunk(1)
@@ -177,7 +217,7 @@ def rbgs_sweep(ops, comm, domain, S, F, A, w: float, alt, tmp_field, first: int 
     def shell():
         lay, tmp = S.layout, tmp_field.data()
         comm.exchange(S, None, "ghost", axis_only)
-        for d in range(nd):                      # tmp's physical-face planes: S's (read tangentially by the second colour)
+        for d in range(nd if not tmp_planes_valid else 0):     # tmp's physical-face planes: S's (read tangentially by the second colour)
             for side in (-1, 1):
                 if domain.neighbor(d, side) is not None:
                     continue

@@ -96,7 +96,8 @@ class _Program:
         return self.comm.reduce_value(t, "sum")
 
     def _single_block(self) -> bool:
-        return self.domain.world_size == 1
+        """No neighbour across any face (a periodic dimension makes a lone block its own neighbour: the paths with exchanges)."""
+        return self.domain.world_size == 1 and not any(self.domain.periodic)
 
     def _report_cg_limit(self):
         """One-call coarse solves count on the device how often the CG loop ran out of iterations (info[3]); the message the generated
@@ -149,6 +150,7 @@ class ConfigL4:
     agglomerate_level: Optional[int] = None   # blocks > 1: levels <= this are solved redundantly on every rank (see _agg_cycle)
     agglomerate_extra_levels: int = 0         # the gathered hierarchy coarsens this many levels below min_level
     graph_agglomerated: bool = True           # GPU: the cycle on the gathered levels (no communication) replays from a hipGraph
+    deep_halo: bool = False                   # blocks > 1: Solution with TWO ghost layers and RHS with one (`ghostLayers` of the layouts): the one-pass sweeps then need one exchange and no shell (smoothers.deep_halo_boxes)
 
 
 class SolverFromL4(_Program):
@@ -167,19 +169,23 @@ class SolverFromL4(_Program):
             nc = dom.ncells(l)
             with_comm = FieldLayout.node(nd, nc, 1, True, True, cfg.align)     # Layout NodeWithComm (...exa4:13-16)
             no_ghost = FieldLayout.node(nd, nc, 0, True, False, cfg.align)     # Layout NodeNoGhost  (...exa4:18-21)
-            self.Solution[l] = Field("Solution", l, with_comm, ops, 1, cfg.bc_fn if l == hi else FN_ZERO)   # :24-25
-            self.RHS[l] = Field("RHS", l, no_ghost, ops, 1, None)                                           # :27
+            # (the levels that run distributed sweeps: above the coarsest and above the agglomerated ones, whose gather buffers assume one ghost layer)
+            deep = cfg.deep_halo and not self._single_block() and l != lo and (cfg.agglomerate_level is None or l > cfg.agglomerate_level)
+            sol_lay = FieldLayout.node(nd, nc, 2, True, True, cfg.align) if deep else with_comm
+            rhs_lay = with_comm if deep else no_ghost
+            self.Solution[l] = Field("Solution", l, sol_lay, ops, 1, cfg.bc_fn if l == hi else FN_ZERO)   # :24-25
+            self.RHS[l] = Field("RHS", l, rhs_lay, ops, 1, None)                                           # :27
             self.Residual[l] = Field("Residual", l, no_ghost if l == lo else with_comm, ops, 1, FN_ZERO)    # :29-30
             self.Laplace[l] = laplace_fd(nd, dom.h(l), "mp", "pow")                                         # :39-47
             if cfg.fused_rbgs and l != lo:
-                self._sol_alt[l] = ops.new_array(with_comm.size)
+                self._sol_alt[l] = ops.new_array(sol_lay.size)
         nc = dom.ncells(lo)
         self.cgTmp0 = Field("cgTmp0", lo, FieldLayout.node(nd, nc, 1, True, True, cfg.align), ops, 1, FN_ZERO)   # :32
         self.cgTmp1 = Field("cgTmp1", lo, FieldLayout.node(nd, nc, 0, True, False, cfg.align), ops, 1, None)     # :33
         self._cg_info = ops.new_array(4)
         self._agg = None
         k = cfg.agglomerate_level
-        if k is not None and dom.world_size > 1 and lo <= k < hi:
+        if k is not None and (dom.world_size > 1 or any(dom.periodic)) and lo <= k < hi:
             # The coarse levels of a decomposed hierarchy are latency-bound (a 64^3 block per GPU and six exchanges per
             # sweep): from level k down every rank gathers the whole level (one all-gather of the restricted right-hand
             # side, a few MB over xGMI) and runs the remaining cycle on it as ONE block -- fused sweeps, persistent CG
@@ -265,6 +271,13 @@ class SolverFromL4(_Program):
         t = self.ops.residual_norm2(S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), A, b, e, R.lc, R.data())
         return math.sqrt(self.comm.reduce_value(t, "sum"))
 
+    def _rhs_ghosts(self, l: int):
+        """deep_halo: the right-hand side of level l changed -- its ghost layer, which the first stage of the one-pass sweeps reads on the
+        neighbour's first plane, follows (one exchange per level and cycle)."""
+        F = self.RHS[l]
+        if self.cfg.deep_halo and not self._single_block() and F.layout.communicates_ghost and max(F.layout.ghost) > 0:
+            self.communicate(F, None, "ghost")
+
     def _update_residual(self, l: int):
         S, R = self.Solution[l], self.Residual[l]
         b, e = self.bounds(R)
@@ -291,6 +304,7 @@ class SolverFromL4(_Program):
             f = self.RHS[hi]
             b, e = self.bounds(f)
             self.ops.fill_fn(f.lc, f.data(), self.domain.geom(hi), cfg.rhs_fn, (), b, e)
+        self._rhs_ghosts(hi)
         for l in self.levels:           # finest: the program's `apply bc`; coarser: homogeneous values the cycle relies on (mgCycle: static_bc)
             self.apply_bc(self.Solution[l])
         self._init_alt_shells()
@@ -415,8 +429,9 @@ class SolverFromL4(_Program):
             tmp = self._sweep_tmp.get(l)
             if tmp is None:
                 tmp = self._sweep_tmp[l] = Field("SolutionSweepTmp", l, S.layout, self.ops, 1, S.bc_fn, S.bc_params)
+                self.apply_bc(tmp)      # once: the values are functions of the position, and no loop writes those planes
             for _ in range(self.cfg.n_smooth):
-                self._sol_alt[l] = rbgs_sweep(self.ops, self.comm, self.domain, S, F, A, w, self._sol_alt[l], tmp, 0)
+                self._sol_alt[l] = rbgs_sweep(self.ops, self.comm, self.domain, S, F, A, w, self._sol_alt[l], tmp, 0, tmp_planes_valid=True)
             return
         for _ in range(self.cfg.n_smooth):
             for colour in (0, 1):
@@ -460,6 +475,7 @@ class SolverFromL4(_Program):
             else:
                 self.communicate(R)
                 ops.restrict(R.lc, R.data(), Fc.lc, Fc.data(), 1.0, b, e)
+        self._rhs_ghosts(l - 1)
         Sc, S = self.Solution[l - 1], self.Solution[l]
         b, e = self.bounds(Sc)
         # single block with the one-pass sweeps: every loop of the cycle writes inner points only and the Dirichlet values are

@@ -405,7 +405,10 @@ typedef struct examg_neighbors {
  *       | EXAMG_EXCH_CONCURRENT_AXES: ghost layers of all axes as ONE send/recv group -- face ghosts only, for loops that read
  *       nothing else (5/7-point stencils).  Which parts a field communicates is the layout declaration's business
  *       (`ghostLayers = [..] with communication`): the caller passes `what` accordingly. */
-enum { EXAMG_EXCH_DUP = 1, EXAMG_EXCH_GHOST = 2, EXAMG_EXCH_ALL = 3, EXAMG_EXCH_CONCURRENT_AXES = 4 };
+enum { EXAMG_EXCH_DUP = 1, EXAMG_EXCH_GHOST = 2, EXAMG_EXCH_ALL = 3, EXAMG_EXCH_CONCURRENT_AXES = 4,
+       /* examg_jacobi2_blocks / examg_rbgs_sweep_blocks only: tmp's duplicate planes on the physical faces already hold u_in's values
+        * (position-only Dirichlet values, written once by the caller): the pass does not refresh them */
+       EXAMG_PASS_TMP_PLANES_VALID = 8 };
 /* caller-owned device scratch for the packed slabs (the generated program's buffer_Send / buffer_Recv arrays) */
 size_t examg_exchange_workspace_bytes(const examg_layout_t *l);
 int examg_exchange(examg_comm_t *comm, const examg_layout_t *l, double *x, const examg_neighbors_t *nb, int what,
