@@ -122,6 +122,12 @@ class HipOps:
         sc = st.c_struct(self.ptr)
         return bool(self.L.examg_two_stage_eligible(C.byref(lu), C.byref(lf), C.byref(sc), ivec(begin1), ivec(end1), ivec(begin2), ivec(end2)))
 
+    def residual_restrict_one_pass(self, lu, lf, st: Stencil, lc, fbegin, fend, cbegin, cend) -> bool:
+        """Will residual_restrict run its one-pass kernel for these boxes (True) or residual + restriction through the residual array?"""
+        sc = st.c_struct(self.ptr)
+        return bool(self.L.examg_residual_restrict_one_pass(C.byref(lu), C.byref(lf), C.byref(sc), C.byref(lc), ivec(fbegin), ivec(fend), ivec(cbegin),
+                                                            ivec(cend)))
+
     # -- inter-grid -------------------------------------------------------------------------------
     def restrict(self, lfine, rf, lc, fc, scale: float, begin, end):
         check(self.L.examg_restrict(C.byref(lfine), self.ptr(rf), C.byref(lc), self.ptr(fc), float(scale), ivec(begin),

@@ -271,6 +271,30 @@ class SolverFromL4(_Program):
         t = self.ops.residual_norm2(S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), A, b, e, R.lc, R.data())
         return math.sqrt(self.comm.reduce_value(t, "sum"))
 
+    def _deep_residual_restrict(self, l: int) -> bool:
+        """`communicate Solution; Residual = RHS - A * Solution; communicate Residual; RHS@coarser = Restriction * Residual` on a block with
+        neighbours whose layouts carry two ghost layers of Solution and one of RHS: the residual on the neighbour's first plane -- what
+        `communicate Residual` would bring -- is evaluated here from the same bits, so the one-pass kernel runs on the WHOLE coarse box
+        (its fine footprint reaches one point across every interior face) after one exchange; no shell, no residual array."""
+        S, F, R, Fc, A = self.Solution[l], self.RHS[l], self.Residual[l], self.RHS[l - 1], self.Laplace[l]
+        dom = self.domain
+        faces = [(d, side) for d in range(dom.nd) for side in (-1, 1) if dom.neighbor(d, side) is not None]
+        if (not self.cfg.deep_halo or not faces or any(S.layout.ghost[d] < 2 or F.layout.ghost[d] < 1 for d, _ in faces) or
+                not hasattr(self.ops, "residual_restrict_one_pass")):
+            return False
+        fb, fe = [list(x) for x in self.bounds(R)]
+        for d, side in faces:
+            if side < 0:
+                fb[d] -= 1
+            else:
+                fe[d] += 1
+        b, e = self.bounds(Fc)
+        if not self.ops.residual_restrict_one_pass(S.lc, F.lc, A, Fc.lc, fb, fe, b, e):
+            return False
+        self.communicate(S)          # axis by axis: the restriction's footprint reads edge and corner ghosts
+        self.ops.residual_restrict(S.lc, S.data(), F.lc, F.data(), R.lc, R.data(), A, Fc.lc, Fc.data(), 1.0, fb, fe, b, e)
+        return True
+
     def _rhs_ghosts(self, l: int):
         """deep_halo: the right-hand side of level l changed -- its ghost layer, which the first stage of the one-pass sweeps reads on the
         neighbour's first plane, follows (one exchange per level and cycle)."""
@@ -456,6 +480,8 @@ class SolverFromL4(_Program):
             b, e = self.bounds(Fc)
             ops.residual_restrict(S.lc, S.data(), self.RHS[l].lc, self.RHS[l].data(), R.lc, R.data(), self.Laplace[l], Fc.lc,
                                   Fc.data(), 1.0, fb, fe, b, e)
+        elif self.cfg.fused_residual_restrict and self._deep_residual_restrict(l):
+            pass      # deep halos: one exchange of Solution (two ghost layers) and the one-pass kernel on the whole coarse box
         elif (self.cfg.fused_residual_restrict and self.cfg.overlap_transfers and not self._single_block() and
               self._faces_only(self.Laplace[l]) and hasattr(self.comm, "c_residual_restrict") and
               self.comm.c_residual_restrict(self.Solution[l], self.RHS[l], R, self.Laplace[l], Fc, 1.0, *self.bounds(R), *self.bounds(Fc),

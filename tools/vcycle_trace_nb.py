@@ -16,7 +16,7 @@ ops = HipOps(0)
 dom = RectDomain(3, (1, 1, 1), 0, periodic=tuple(a in axes for a in "xyz"))
 comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True, transport="peer")
 P = SolverFromL4(ConfigL4(nd=3, min_level=L - 5, max_level=L, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True, agglomerate_level=L - 3,
-                          fused_prolong_min_points=10_000_000, fused_zero_start=True, fused_residual_norm=True), ops, dom, comm)
+                          fused_prolong_min_points=10_000_000, fused_zero_start=True, fused_residual_norm=True, deep_halo=True), ops, dom, comm)
 P.setup()
 P.capture_cycle()
 for _ in range(3):
