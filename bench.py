@@ -498,6 +498,7 @@ def run(args, world, rank, local_rank, dist, injected=False):
             out["duplicate_planes_bit_identical"] = dup_check       # compared after the settle, warm-up and timed steps
         if world > 1:
             out["transport"] = getattr(comm, "transport", None)
+            out["halo"] = "deep (two ghost layers: one exchange + one kernel per pass)" if deep else "shell (one ghost layer: interior kernel beside shell launches, two exchanges per pass)"
             if transport_notes:
                 out["transport_notes"] = transport_notes      # transports that were tried first and did not pass the probe, and why
         if sustained is not None:

@@ -1,7 +1,10 @@
 set -o pipefail
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout -k 10 900 python -m pytest tests/test_gpu_peer.py tests/test_gpu_multi.py -m gpu -x -q -k "multi_process_on_one_gpu or bench" > gpurun_out/t.log 2>&1; rc=$?; tail -25 gpurun_out/t.log | cut -c1-300
-[ $rc -ne 0 ] && exit $rc
-timeout -k 10 400 python tools/vcycle_neighbours.py 9 lone_block neighbours_z neighbours_y_z neighbours_x_y_z > gpurun_out/vcycle_neighbours.json 2> gpurun_out/vcycle_neighbours.err || { tail -5 gpurun_out/vcycle_neighbours.err; exit 1; }
-cat gpurun_out/vcycle_neighbours.json
+for halo in deep shell; do
+timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --backend gloo --halo $halo > gpurun_out/bench_n2_$halo.json 2> gpurun_out/bench_n2.err; rc=$?
+[ $rc -ne 0 ] && { tail -5 gpurun_out/bench_n2.err; exit $rc; }
+python -c "
+import json; d=json.loads([l for l in open('gpurun_out/bench_n2_$halo.json') if l.startswith('{')][-1])
+print('$halo', {k: d.get(k) for k in ('value','ms_per_step','sustained_ms_per_step','vcycle_ms','totalTimeSolve_ms','solve_iterations','duplicate_planes_bit_identical','vcycle_duplicate_planes_bit_identical','transport')})"
+done
