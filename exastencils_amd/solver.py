@@ -506,7 +506,8 @@ class SolverFromL4(_Program):
         b, e = self.bounds(Sc)
         # single block with the one-pass sweeps: every loop of the cycle writes inner points only and the Dirichlet values are
         # functions of the position, written once by setup() -- `apply bc` would re-write the same bits (as in _smooth)
-        static_bc = self.cfg.fused_rbgs and self._single_block()
+        # (blocks with neighbours alike: exchanges bring the neighbour's copies of the same position-only values)
+        static_bc = self.cfg.fused_rbgs
         # ... and a coarser level that starts with a one-pass sweep reads its zero Solution as a constant (its boundary values are 0)
         zero_start = self._starts_from_zero(l - 1) or (l - 1 == self.cfg.min_level and self._coarsest_starts_from_zero())
         if not zero_start:

@@ -1,10 +1,7 @@
 set -o pipefail
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-for halo in deep shell; do
-timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --backend gloo --halo $halo > gpurun_out/bench_n2_$halo.json 2> gpurun_out/bench_n2.err; rc=$?
-[ $rc -ne 0 ] && { tail -5 gpurun_out/bench_n2.err; exit $rc; }
-python -c "
-import json; d=json.loads([l for l in open('gpurun_out/bench_n2_$halo.json') if l.startswith('{')][-1])
-print('$halo', {k: d.get(k) for k in ('value','ms_per_step','sustained_ms_per_step','vcycle_ms','totalTimeSolve_ms','solve_iterations','duplicate_planes_bit_identical','vcycle_duplicate_planes_bit_identical','transport')})"
-done
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r04_gputests.log 2>&1; rc=$?; tail -4 gpurun_out/r04_gputests.log
+[ $rc -ne 0 ] && exit $rc
+timeout -k 10 400 python tools/vcycle_neighbours.py 9 > gpurun_out/vcycle_neighbours.json 2> gpurun_out/vcycle_neighbours.err || { tail -5 gpurun_out/vcycle_neighbours.err; exit 1; }
+cat gpurun_out/vcycle_neighbours.json
