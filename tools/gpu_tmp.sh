@@ -1,7 +1,6 @@
 set -o pipefail
 mkdir -p gpurun_out
-export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r04_gputests.log 2>&1; rc=$?; tail -4 gpurun_out/r04_gputests.log
-[ $rc -ne 0 ] && exit $rc
-timeout -k 10 400 python tools/vcycle_neighbours.py 9 > gpurun_out/vcycle_neighbours.json 2> gpurun_out/vcycle_neighbours.err || { tail -5 gpurun_out/vcycle_neighbours.err; exit 1; }
-cat gpurun_out/vcycle_neighbours.json
+timeout -k 10 600 python bench.py > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err || { tail -5 gpurun_out/r04_bench.err; exit 1; }
+python -c "
+import json; d=json.load(open('gpurun_out/r04_bench.json'))
+print({k: d[k] for k in ('value','ms_per_step','vcycle_ms','totalTimeSolve_ms','jacobi_single_step_frac','jacobi_256cube_single_step_frac','helmholtz27_vcycle_ms','fmg_solve_ms','shim_vcycle_ms_deferred') if k in d}); print(d['roofline'])"
