@@ -280,6 +280,16 @@ def run(args, world, rank, local_rank, dist, injected=False):
     else:
         comm = Communicator(dom, ops, concurrent_ghost_axes=True, consistent_duplicates=True)
     nc = dom.ncells(L)
+    if world > 1 and getattr(comm, "transport", None) == "peer":
+        # size the peer-write regions ONCE for everything this run exchanges -- the widest face of the finest level (two ghost layers) and
+        # the gathered coarse level of the V-cycle leg -- so that no region is re-allocated (a collective: synchronise, barrier, unmap,
+        # barrier, map) in the middle of the measurements
+        from exastencils_amd.layout import FieldLayout as _FL
+
+        gather = 8
+        for d in range(nd):
+            gather *= dom.ncells(max(L - 3, 0))[d] + 3
+        comm._peer_ensure(comm._max_face_bytes(_FL.node(nd, nc, 2, True, True, args.align), nd), gather)
     # N > 1: two ghost layers on Solution and one on RHS (the layouts' `ghostLayers`; the reference needs as many for its contracting
     # loops, baseExt/ir/IR_ContractingLoop.scala:45-196): a two-step pass is then ONE exchange and ONE kernel per block -- the first stage
     # also covers the neighbour's first plane -- instead of an interior kernel beside a shell of thin launches and two exchanges

@@ -1,6 +1,7 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 600 python bench.py > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err || { tail -5 gpurun_out/r04_bench.err; exit 1; }
-python -c "
-import json; d=json.load(open('gpurun_out/r04_bench.json'))
-print({k: d[k] for k in ('value','ms_per_step','vcycle_ms','totalTimeSolve_ms','jacobi_single_step_frac','jacobi_256cube_single_step_frac','helmholtz27_vcycle_ms','fmg_solve_ms','shim_vcycle_ms_deferred') if k in d}); print(d['roofline'])"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/lab/regrow_probe.py > gpurun_out/regrow.txt 2>&1; rc=$?
+grep "ok:\|Error\|error" gpurun_out/regrow.txt | head -30
+echo rc=$rc
+EXAMG_HOSTED_RANKS=1 timeout -k 10 500 python -m pytest tests/test_gpu_peer.py -x -q -m gpu -k eight_ranks > gpurun_out/hosted_8ranks.log 2>&1; echo "8 ranks hosted rc=$?"; tail -3 gpurun_out/hosted_8ranks.log
