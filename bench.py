@@ -7,14 +7,15 @@ step      = one application of the smoother function of the generated program
             reference layout, 511^3 updated points).
 metric    = LU/s (lattice updates per second, the authors' formula Testing/PolyExpl/Jac3Dcc.exa4:58),
             whole job: ranks x points x steps / max-over-ranks time.
-            K steps run as K/2 two-step passes (exastencils_amd/smoothers.py: temporal blocking, the reference's
-            contracting-loop idea; bit-identical to K single steps, also across block neighbours) unless
-            --no-temporal-blocking.
+            K steps run as passes of three steps on a block without neighbours (examg_jacobi3: 20 steps = 6 x 3 + 2) and of two
+            steps across block neighbours (exastencils_amd/smoothers.py: temporal blocking, the reference's contracting-loop
+            idea, baseExt/ir/IR_ContractingLoop.scala; bit-identical to K single steps) unless --no-temporal-blocking;
+            --temporal-depth 2 keeps the single block on two-step passes.
 roofline  = HBM.  `achieved` = compulsory bytes of ONE launch of the dominant kernel / its average duration (HIP events on
             the launch stream).  Compulsory bytes follow the reference's own rule
             (Compiler/src/exastencils/performance/ir/IR_EvaluatePerformanceEstimates.scala:206-215): 8 B x points x distinct
-            (field, slot, read/write) streams of the launch = 24 B per point for a Jacobi pass -- also for the two-step
-            kernel, which reads u and rhs once and writes once for TWO updates per point.  `frac` = achieved / 8 TB/s is
+            (field, slot, read/write) streams of the launch = 24 B per point for a Jacobi pass -- also for the two- and three-step
+            kernels, which read u and rhs once and write once for TWO / THREE updates per point.  `frac` = achieved / 8 TB/s is
             therefore a fraction of the roofline for every kernel; the per-update figure (24 B per lattice update, which
             exceeds the peak when two updates share a pass) is reported separately as `lu_equivalent_*`.
             `traffic` = fabric-side bytes per launch from rocprofv3 PMC passes (profiles/r02_pmc_kernels.json), given only
@@ -62,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--preflight-timeout", type=float, default=180.0, help="N > 1: seconds the first exchange + pass may take")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-temporal-blocking", action="store_true", help="one kernel launch per smoother step")
+    ap.add_argument("--temporal-depth", type=int, default=3, choices=(1, 2, 3),
+                    help="smoother steps per pass over HBM (3: single block only -- blocks with neighbours have two ghost layers and run pairs)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--extras-timeout", type=float, default=240.0, help="seconds the extra measurements may take")
     ap.add_argument("--no-check-duplicates", action="store_true",
@@ -305,7 +308,11 @@ def run(args, world, rank, local_rank, dist, injected=False):
     b, e = dom.loop_bounds(Solution.layout)
     updates = (e[0] - b[0]) * (e[1] - b[1]) * (e[2] - b[2])
 
-    from exastencils_amd.smoothers import jacobi_pair
+    from exastencils_amd.smoothers import jacobi_pair, jacobi_triple
+
+    # steps per pass over HBM: 3 on a block without neighbours (k_three_stage7_lds), 2 with neighbours (two ghost layers; three steps
+    # without an exchange would need three), 1 with --no-temporal-blocking
+    depth = 1 if args.no_temporal_blocking else min(args.temporal_depth, 3 if world == 1 else 2)
 
     Tmp = Field("SolutionTmp", L, Solution.layout, ops, 1, None)
 
@@ -335,10 +342,14 @@ def run(args, world, rank, local_rank, dist, injected=False):
     def steps(k):
         """k smoother applications; consecutive pairs run as one pass over HBM (temporal blocking,
         exastencils_amd/smoothers.py) unless --no-temporal-blocking: same results bit for bit."""
-        if args.no_temporal_blocking:
+        if depth == 1:
             for _ in range(k):
                 step()
             return
+        if depth == 3:      # a block without neighbours: three steps per pass (examg_jacobi3), the rest as a pair or a step
+            while k >= 3 and (k - 3) != 1:
+                jacobi_triple(ops, comm, dom, Solution, RHS, A, w, Tmp)
+                k -= 3
         for _ in range(k // 2):
             jacobi_pair(ops, comm, dom, Solution, RHS, A, w, Tmp)
         if k % 2:
@@ -408,6 +419,16 @@ def run(args, world, rank, local_rank, dist, injected=False):
     ev1.record(stream)
     torch.cuda.synchronize()
     pair_ms = ev0.elapsed_time(ev1) / nk
+    triple_ms = None
+    if world == 1:
+        ev0.record(stream)
+        for _ in range(nk):
+            ops.jacobi3(Solution.lc, Solution.data(Solution.active), Solution.data(Solution.next), Tmp.data(), RHS.lc, RHS.data(),
+                        A, w, b, e)
+            Solution.advance()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        triple_ms = ev0.elapsed_time(ev1) / nk
     # sustained leg: the same step for >= --sustained-seconds, reported beside the K-step value (the driver's SMI samples then
     # see the device under load, and the settle-phase argument is a measurement: a K-step value near this one was taken at the
     # steady-state clocks)
@@ -440,8 +461,11 @@ def run(args, world, rank, local_rank, dist, injected=False):
     compulsory = BYTES_PER_LU * updates          # one pass: read u, read rhs, write u' -- for either kernel
     single_gbs = compulsory / (single_ms * 1e-3) / 1e9
     pair_gbs = compulsory / (pair_ms * 1e-3) / 1e9
-    if args.no_temporal_blocking:
+    if depth == 1:
         case, kernel_name, kernel_ms, achieved, lus = "jacobi_1step", "k_stencil7_zmarch (one Jacobi step per launch)", single_ms, single_gbs, updates
+    elif depth == 3 and triple_ms is not None:
+        case, kernel_name, kernel_ms, achieved, lus = ("jacobi_3step", "k_three_stage7_lds (three Jacobi steps per launch)", triple_ms,
+                                                       compulsory / (triple_ms * 1e-3) / 1e9, 3 * updates)
     else:
         case, kernel_name, kernel_ms, achieved, lus = "jacobi_2step", "k_two_stage7_lds (two Jacobi steps per launch)", pair_ms, pair_gbs, 2 * updates
 
@@ -450,8 +474,12 @@ def run(args, world, rank, local_rank, dist, injected=False):
         "jacobi_single_step_frac": single_gbs / HBM_PEAK_GBS,
         "jacobi_two_step_kernel_ms": pair_ms,
         "jacobi_two_step_frac": pair_gbs / HBM_PEAK_GBS,
-        "temporal_blocking": not args.no_temporal_blocking,
+        "temporal_blocking": depth > 1,
+        "temporal_depth": depth,
     }
+    if triple_ms is not None:
+        extra["jacobi_three_step_kernel_ms"] = triple_ms
+        extra["jacobi_three_step_frac"] = compulsory / (triple_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out = None
     if rank == 0:
         pmc = pmc_traffic(case, L, args.align) if nc[0] == nc[1] == nc[2] == (1 << L) else None
@@ -475,7 +503,7 @@ def run(args, world, rank, local_rank, dist, injected=False):
                             % (nc[0], nc[1], nc[2],
                                "reference field layout" if not args.align else "reference layout model with rows padded to multiples of %d doubles" % args.align,
                                Solution.layout.tot(0),
-                               "" if args.no_temporal_blocking else "; consecutive step pairs fused (temporal blocking, bit-identical)"),
+                               "" if depth == 1 else "; %s consecutive steps per pass over HBM (temporal blocking, bit-identical)" % ("three" if depth == 3 else "two")),
                 "blocks": list(dom.num_blocks),
                 "updates_per_step_per_gpu": updates,
                 "levels": L,
@@ -699,7 +727,8 @@ def config1(ops, world):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     out = {}
     for name, fn, steps in (("single_step", lambda x, y: ops.stencil_op(2, Lu, x, Lf, f, Lu, y, A, w, -1, b, e), 1),
-                            ("two_step", lambda x, y: ops.jacobi2(Lu, x, y, None, Lf, f, A, w, b, e), 2)):
+                            ("two_step", lambda x, y: ops.jacobi2(Lu, x, y, None, Lf, f, A, w, b, e), 2),
+                            ("three_step", lambda x, y: ops.jacobi3(Lu, x, y, None, Lf, f, A, w, b, e), 3)):
         # ~60 ms of the same launches first: a 256^3 launch takes ~75 us, and 50 of them from an idle device would sit entirely inside the
         # power-management transient the headline's settle phase exists for (see main: the first ~30 ms after idle run ~20 % slow)
         for _ in range(800):
@@ -717,7 +746,7 @@ def config1(ops, world):
         out["jacobi_256cube_%s_kernel_ms" % name] = ms
         out["jacobi_256cube_%s_lups" % name] = steps * (n - 1) ** 3 / (ms * 1e-3)
         out["jacobi_256cube_%s_frac" % name] = 24.0 * (n - 1) ** 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        pmc = pmc_traffic("jacobi_1step" if steps == 1 else "jacobi_2step", 8, 0)      # profiles/<round>_pmc_kernels_L8.json
+        pmc = pmc_traffic("jacobi_%dstep" % steps, 8, 0)      # profiles/<round>_pmc_kernels_L8.json
         if pmc and not pmc.get("stale"):
             out["jacobi_256cube_%s_traffic" % name] = pmc["traffic"]
             out["jacobi_256cube_%s_traffic_over_compulsory" % name] = pmc["traffic"] / (24.0 * (n - 1) ** 3)

@@ -693,6 +693,317 @@ static bool stage_boxes_ok(const examg_layout_t *lf_, const Box &box1, const Box
   return !lo && !hi;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// THREE dependent Jacobi steps in one pass (temporal blocking of depth 3; `repeat 5 times with contraction` of
+// Testing/PolyExpl/Jac3Dcc.exa4:27 runs as 3 + 2; baseExt/ir/IR_ContractingLoop.scala:45-196): 24 B per point for three updates.
+// The structure of k_two_stage7_lds with one more stage behind it: a workgroup of NW waves owns a 128-point x window and
+// NS = 3 NW stage-1 rows, every wave three consecutive rows; in step q a wave evaluates
+//   stage 1 on plane q   (V(q)   from the input planes q-1, q, q+1),
+//   stage 2 on plane q-1 (W(q-1) from V(q-2), V(q-1), V(q)),
+//   stage 3 on plane q-2 (output from W(q-3), W(q-2), W(q-1)),
+// all three pipelines in registers (rings of four slots, the plane loop unrolled four times by hand).  Halo: three points on
+// every side -- 120 of 128 columns, NS - 4 of NS + 2 rows, zc of zc + 6 planes are outputs.  Only a wave's FIRST and LAST row are
+// anybody's y neighbours: those two rows of every field pass through LDS (96 KB for eight waves), the outer input rows of the first
+// and the last wave stay in the registers of the wave that loads them.  One barrier per plane.
+// Points outside the box pass through stages 1 and 2 with their value (boundary and ghost values), stage 3 stores inside the box only.
+// Every value is the expression of the one-step kernel in its order: bit-identical to three Jacobi loops one after the other.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TS3_OUT = 120;   // outputs per 128-point window: lanes 2 .. 61
+
+template <int ORDER, int NW, bool NT, int RPW = 3>
+__global__ void __launch_bounds__(64 * NW, 1)
+k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs,
+                   double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g) {
+  constexpr int NS = RPW * NW;      // stage-1 rows s = 0 .. NS-1, global row rw0 - 2 + s
+  constexpr int NO = NS - 4;        // output rows: s = 2 .. NS-3
+  // edge rows of the waves, two plane buffers each: [field][buffer][lo / hi][wave][lane]
+  __shared__ d2 SM[3 * 2 * 2 * NW * 64];
+#define EB(f, p, h, wq) SM[((((f) * 2 + (p)) * 2 + (h)) * NW + (wq)) * 64 + lane]
+  const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  int t = blockIdx.x;
+  if (g.remap == 2) {  // XCD-contiguous within every z layer of tiles (see k_two_stage7_lds)
+    const int xy = g.ntx * g.nty;
+    const int lz = t / xy, r = t - lz * xy;
+    const int per = xy >> 3;
+    t = lz * xy + (r < (per << 3) ? (r & 7) * per + (r >> 3) : r);
+  }
+  const int tx = t % g.ntx;
+  t /= g.ntx;
+  const int ty = t % g.nty;
+  const int tz = t / g.nty;
+  const int xw = box.b0 - 4 + TS3_OUT * tx;     // first point of the window
+  const int xa = xw + 2 * lane;
+  const int rw0 = box.b1 + ty * NO;             // first output row of the workgroup
+  const int mb = box.b2 + tz * g.zc;            // first output plane
+  const int me = min(mb + g.zc, box.e2);
+  const bool inx_a = xa >= box.b0 && xa < box.e0, inx_b = xa + 1 >= box.b0 && xa + 1 < box.e0;
+  const bool out_lane = lane >= 2 && lane <= 61;
+  const bool st_a = out_lane && inx_a, st_b = out_lane && inx_b;
+  const int s0 = RPW * wv;
+  int grow[RPW];
+  bool row_in[RPW], row_out[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    grow[r] = rw0 - 2 + s0 + r;
+    row_in[r] = grow[r] >= box.b1 && grow[r] < box.e1;
+    row_out[r] = s0 + r >= 2 && s0 + r <= NS - 3 && row_in[r];
+  }
+  const bool has_outer = wv == 0 || wv == NW - 1;      // input rows rw0 - 3 (below the first wave) and rw0 - 2 + NS (above the last)
+  const int outer_row = wv == 0 ? rw0 - 3 : rw0 - 2 + NS;
+  const int wlo = wv >= 1 ? wv - 1 : 0, whi = wv + 1 <= NW - 1 ? wv + 1 : NW - 1;
+
+  // addressing as in k_two_stage7_lds: scalar base per row, one clamped byte offset per lane, running scalar plane offsets
+  struct Site {
+    const char *row;
+    unsigned voff;
+  };
+  auto site = [&](const double *base, const LayoutDev &l, int R) {
+    const int rc = min(max(R + l.ref1, 0), l.tot1 - 1), i0 = xw + l.ref0;
+    Site st;
+    st.row = reinterpret_cast<const char *>(base + ((long long)i0 + (long long)((unsigned)l.s1 * (unsigned)rc)));
+    st.voff = (unsigned)(min(max(2 * lane, -i0 - (rc == 0 ? 0 : 1)), l.tot0 - 1 - i0 - (rc == l.tot1 - 1 ? 1 : 0)) * 8);
+    return st;
+  };
+  struct PlaneCursor {
+    int p;
+    long long bytes, step;
+    int last;
+  };
+  auto cursor = [&](const LayoutDev &l, int P) {
+    PlaneCursor c;
+    c.p = P + l.ref2;
+    c.last = l.tot2 - 1;
+    c.step = uniform64(l.s2 * 8);
+    c.bytes = uniform64(l.s2 * 8 * min(max(c.p, 0), c.last));
+    return c;
+  };
+  auto advance = [&](PlaneCursor &c) {
+    ++c.p;
+    c.bytes += (c.p >= 1 && c.p <= c.last) ? c.step : 0LL;
+  };
+  auto load_at = [&](const Site &st, long long pb) { return load2(reinterpret_cast<const double *>(st.row + pb + st.voff)); };
+  Site urow[RPW], frow[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    urow[r] = site(u, lu, grow[r]);
+    frow[r] = site(rhs, lf, grow[r]);
+  }
+  const Site uouter = site(u, lu, outer_row);
+  const int q0 = mb - 2;                                           // first step
+  PlaneCursor cu = cursor(lu, q0 - 1), cf = cursor(lf, q0);        // the next plane to load
+  const unsigned vo = (unsigned)lane * 16u;
+  char *obase[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+    obase[r] = reinterpret_cast<char *>(out + ((long long)(xw + lu.ref0) + (long long)((unsigned)lu.s1 * (unsigned)max(grow[r] + lu.ref1, 0))));
+  long long obytes = uniform64(lu.s2 * 8 * (long long)(q0 - 2 + lu.ref2));   // plane q-2 of the first step (not used before the first output plane)
+  const long long ostep = uniform64(lu.s2 * 8);
+
+  // rings: in step q = q0 + 4 n + PH plane p of every field lives in slot (p - q + PH + 1) & 3
+  d2 U[4][RPW], V[4][RPW], W[4][RPW], F[4][RPW], O[4];
+  O[0] = O[1] = O[2] = O[3] = d2{0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {      // input planes q0-1 .. q0+2
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) U[j][r] = load_at(urow[r], cu.bytes);
+    if (has_outer && j >= 1) O[j] = load_at(uouter, cu.bytes);
+    advance(cu);
+  }
+#pragma unroll
+  for (int j = 1; j < 3; ++j) {      // rhs planes q0, q0+1
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) F[j][r] = load_at(frow[r], cf.bytes);
+    advance(cf);
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    F[0][r] = F[1][r];
+    F[3][r] = F[1][r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      V[j][r] = U[0][r];
+      W[j][r] = U[0][r];
+    }
+  }
+  // publish the edge rows of input plane q0
+  EB(0, 0, 0, wv) = U[1][0];
+  EB(0, 0, 1, wv) = U[1][RPW - 1];
+  __syncthreads();
+
+  using I0_ = std::integral_constant<int, 0>;
+  using I1_ = std::integral_constant<int, 1>;
+  using I2_ = std::integral_constant<int, 2>;
+  using I3_ = std::integral_constant<int, 3>;
+  // one Jacobi update of a pair: centre c, y neighbours ym / yp, z neighbours zm / zp, right-hand side f
+  auto jac = [&](d2 c, d2 ym, d2 yp, d2 zm, d2 zp, d2 f) {
+    const double xl = lane_below0(c.y), xr = lane_above0(c.x);
+    const double acc_a = conv7<ORDER>(k, c.x, xl, c.y, ym.x, yp.x, zm.x, zp.x);
+    const double acc_b = conv7<ORDER>(k, c.y, c.x, xr, ym.y, yp.y, zm.y, zp.y);
+    d2 n;
+    n.x = c.x + w * (f.x - acc_a);
+    n.y = c.y + w * (f.y - acc_b);
+    return n;
+  };
+  auto step = [&](const int q, auto PHc) {
+    constexpr int PH = decltype(PHc)::value;
+    d2 (&Um)[RPW] = U[PH & 3], (&Uc)[RPW] = U[(PH + 1) & 3], (&Up)[RPW] = U[(PH + 2) & 3];
+    d2 (&Vmm)[RPW] = V[(PH + 3) & 3], (&Vm)[RPW] = V[PH & 3], (&Vn)[RPW] = V[(PH + 1) & 3];          // planes q-2, q-1, q (written here)
+    d2 (&Wmm)[RPW] = W[(PH + 2) & 3], (&Wm)[RPW] = W[(PH + 3) & 3], (&Wn)[RPW] = W[PH & 3];          // planes q-3, q-2, q-1 (written here)
+    d2 (&Fq)[RPW] = F[(PH + 1) & 3], (&Fm)[RPW] = F[PH & 3], (&Fmm)[RPW] = F[(PH + 3) & 3];          // rhs on planes q, q-1, q-2
+    constexpr int ub = PH & 1, vb = (PH + 1) & 1;
+    // y-neighbour rows from the waves below and above (input plane q, stage-1 plane q-1, stage-2 plane q-2); the first wave's lower and
+    // the last wave's upper input row are their own outer rows; of the stage fields those rows do not exist (some row is read instead:
+    // they are neighbours of rows that are nobody's input)
+    d2 ulo = EB(0, ub, 1, wlo), uhi = EB(0, ub, 0, whi);
+    const d2 vlo = EB(1, vb, 1, wlo), vhi = EB(1, vb, 0, whi);
+    const d2 zlo = EB(2, vb, 1, wlo), zhi = EB(2, vb, 0, whi);
+    if (wv == 0) ulo = O[(PH + 1) & 3];
+    if (wv == NW - 1) uhi = O[(PH + 1) & 3];
+    // ---- stage 1 on plane q ----
+    {
+      const bool pin = q >= box.b2 && q < box.e2;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const d2 c = Uc[r];
+        const d2 n = jac(c, r == 0 ? ulo : Uc[r == 0 ? 0 : r - 1], r == RPW - 1 ? uhi : Uc[r == RPW - 1 ? r : r + 1], Um[r], Up[r], Fq[r]);
+        const bool on = pin && row_in[r];
+        Vn[r].x = (inx_a && on) ? n.x : c.x;
+        Vn[r].y = (inx_b && on) ? n.y : c.y;
+      }
+    }
+    // ---- stage 2 on plane q-1 ----
+    if (q >= mb) {     // wave-uniform: before that nothing reads what it would produce
+      const bool pin = q - 1 >= box.b2 && q - 1 < box.e2;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const d2 c = Vm[r];
+        const d2 n = jac(c, r == 0 ? vlo : Vm[r == 0 ? 0 : r - 1], r == RPW - 1 ? vhi : Vm[r == RPW - 1 ? r : r + 1], Vmm[r], Vn[r], Fm[r]);
+        const bool on = pin && row_in[r];
+        Wn[r].x = (inx_a && on) ? n.x : c.x;
+        Wn[r].y = (inx_b && on) ? n.y : c.y;
+      }
+    }
+    // ---- stage 3 on plane q-2: output rows inside the box ----
+    if (q - 2 >= mb) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        if (row_out[r]) {   // wave-uniform
+          const d2 c = Wm[r];
+          const d2 o = jac(c, r == 0 ? zlo : Wm[r == 0 ? 0 : r - 1], r == RPW - 1 ? zhi : Wm[r == RPW - 1 ? r : r + 1], Wmm[r], Wn[r], Fmm[r]);
+          double *qp = reinterpret_cast<double *>(obase[r] + obytes + vo);
+          if (st_a && st_b) {
+            if (NT) store2_nt(qp, o);
+            else store2(qp, o);
+          } else if (st_a) {
+            qp[0] = o.x;
+          } else if (st_b) {
+            qp[1] = o.y;
+          }
+        }
+      }
+    }
+    // ---- publish the edge rows of input plane q+1, stage-1 plane q, stage-2 plane q-1 for the next step ----
+    if (q <= me) {
+      EB(0, vb, 0, wv) = Up[0];
+      EB(0, vb, 1, wv) = Up[RPW - 1];
+      EB(1, ub, 0, wv) = Vn[0];
+      EB(1, ub, 1, wv) = Vn[RPW - 1];
+      EB(2, ub, 0, wv) = Wn[0];
+      EB(2, ub, 1, wv) = Wn[RPW - 1];
+    }
+    // loads without a condition: input plane q+3 into the slot of plane q-1, rhs plane q+2 into the slot of plane q-2
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      Um[r] = load_at(urow[r], cu.bytes);
+      Fmm[r] = load_at(frow[r], cf.bytes);
+    }
+    if (has_outer) O[PH & 3] = load_at(uouter, cu.bytes);
+    advance(cu);
+    advance(cf);
+    obytes += ostep;
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const int qe = me + 1;      // last step: stage 3 on plane me - 1
+  for (int q = q0; q <= qe; q += 4) {
+    step(q, I0_{});
+    if (q + 1 > qe) break;
+    step(q + 1, I1_{});
+    if (q + 2 > qe) break;
+    step(q + 2, I2_{});
+    if (q + 3 > qe) break;
+    step(q + 3, I3_{});
+  }
+#undef EB
+}
+
+static thread_local int g_ts3_zc = -1;         // planes per z chunk of the three-step pass; -1: by size (examg_debug_three_stage)
+static thread_local int g_ts3_disable = 0;
+static thread_local int g_ts3_shape = 83;      // 83: eight waves of three rows; 122: twelve waves of two rows (the same 24-row tile, three waves per SIMD)
+
+// the three-step pass: 3-D 7-point constant stencils on rows of at least 64 points and at least 2^20 points (below, a pair and a step)
+static bool three_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
+  if (g_ts3_disable || !two_stage_ok(lu, lf, st, box) || box.n1() < 20 || box.count() < (1LL << 20)) return false;
+  const LayoutDev u = make_layout(lu), f = make_layout(lf);
+  return u.s2 < (1LL << 32) && f.s2 < (1LL << 32);
+}
+
+template <int NW, int RPW>
+static int launch_three_stage_shape(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs, double *out,
+                                    const examg_stencil_t *st, double w, const Box &box, hipStream_t s) {
+  constexpr int NO = RPW * NW - 4;
+  const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
+  TSGeom g;
+  g.xs = g.ys = g.zs = 0;
+  g.ntx = (box.n0() + TS3_OUT - 1) / TS3_OUT;
+  g.nty = (box.n1() + NO - 1) / NO;
+  const int xy = g.ntx * g.nty, n2 = box.n2();
+  // planes per chunk: six halo planes each; large boxes take short chunks (many workgroups, one moving front), smaller ones the count
+  // that fills the 256 CUs most evenly (the rule of launch_two_stage_lds with this kernel's halo)
+  int zc = 16;
+  if (box.count() < 50000000LL) {
+    long long best = -1;
+    for (int t = 1; t <= (n2 + 7) / 8; ++t) {
+      const int c = (n2 + t - 1) / t, tt = (n2 + c - 1) / c;
+      const long long cost = (((long long)xy * tt + 255) / 256) * (c + 8);
+      if (best < 0 || cost < best) { best = cost; zc = c; }
+    }
+  }
+  if (g_ts3_zc > 0) zc = g_ts3_zc;
+  if (zc > n2) zc = n2;
+  g.zc = zc;
+  g.ntz = (n2 + zc - 1) / zc;
+  g.nblocks = xy * g.ntz;
+  g.remap = g_ts_remap >= 0 ? g_ts_remap : 2;
+  g.first = 0;
+  g.box1 = box;
+  g.ax0 = -lu.ref0; g.ax1 = lu.tot0 - lu.ref0;
+  g.ay0 = -lu.ref1; g.ay1 = lu.tot1 - lu.ref1;
+  g.az0 = -lu.ref2; g.az1 = lu.tot2 - lu.ref2;
+  Coef7 k;
+  for (int i = 0; i < 7; ++i) k.c[i] = st->coef[i];
+  const int ord = canonical_order7(st);
+  const bool nt = g_ts_nt >= 0 ? g_ts_nt != 0 : box.count() * 24LL > 200000000LL;    // the store policy of the two-step passes
+  dim3 block(64, NW, 1), grid(g.nblocks, 1, 1);
+#define EXAMG_TS3(ORD, NTV) hipLaunchKernelGGL((k_three_stage7_lds<ORD, NW, NTV, RPW>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g)
+  if (ord == 0) {
+    if (nt) EXAMG_TS3(0, true);
+    else EXAMG_TS3(0, false);
+  } else {
+    if (nt) EXAMG_TS3(1, true);
+    else EXAMG_TS3(1, false);
+  }
+#undef EXAMG_TS3
+  EXAMG_CHECK_LAUNCH("k_three_stage7_lds");
+  return 0;
+}
+
+static int launch_three_stage(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs, double *out,
+                              const examg_stencil_t *st, double w, const Box &box, hipStream_t s) {
+  if (g_ts3_shape == 122) return launch_three_stage_shape<12, 2>(lu, u, lf, rhs, out, st, w, box, s);
+  return launch_three_stage_shape<8, 3>(lu, u, lf, rhs, out, st, w, box, s);
+}
+
 }  // namespace examg
 
 using namespace examg;
@@ -711,6 +1022,16 @@ extern "C" int examg_debug_two_stage_nt(int nt) {
 extern "C" int examg_debug_two_stage_prol(int wpe) {
   if (wpe >= 10) g_ts_wpe = wpe - 10 == 4 ? 4 : 1;     // 11 / 14: the plain passes
   else g_ts_prol_wpe = wpe == 1 ? 1 : 4;
+  return 0;
+}
+
+extern "C" int examg_debug_three_stage(int disable, int zc) {
+  if (disable >= 10) {     // 83 / 122: workgroup shape
+    g_ts3_shape = disable;
+    return 0;
+  }
+  g_ts3_disable = disable;
+  g_ts3_zc = zc > 0 ? zc : -1;
   return 0;
 }
 
@@ -976,4 +1297,39 @@ extern "C" int examg_jacobi2(const examg_layout_t *lu, const double *u_in, doubl
   rc = examg_jacobi(lu, u_in, tmp, lf, rhs, st, w, begin, end, stream);
   if (rc) return rc;
   return examg_jacobi(lu, tmp, u_out, lf, rhs, st, w, begin, end, stream);
+}
+
+// Three Jacobi steps, u_in -> u_out on the box (u_out's planes outside the box are not written: the caller keeps boundary and ghost
+// values there, as for examg_jacobi2); one pass where k_three_stage7_lds applies, otherwise a step into `tmp` and a pair from there (or
+// three steps), for which `tmp` must be a distinct array.
+extern "C" int examg_jacobi3(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp, const examg_layout_t *lf,
+                             const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end,
+                             examg_stream_t stream) {
+  if (!lu || !u_in || !u_out || !lf || !rhs || !st || !begin || !end) { set_error("examg_jacobi3: null argument"); return 1; }
+  if (u_in == u_out) { set_error("examg_jacobi3: out of place only"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (three_stage_ok(lu, lf, st, box)) return launch_three_stage(lu, u_in, lf, rhs, u_out, st, w, box, (hipStream_t)stream);
+  if (!tmp || tmp == u_in || tmp == u_out) { set_error("examg_jacobi3: fallback needs a distinct tmp array"); return 1; }
+  const int reach = stencil_reach(st);
+  int32_t b2[3], e2[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool on = d < lu->nd;
+    b2[d] = begin[d] - (on ? reach : 0);
+    e2[d] = end[d] + (on ? reach : 0);
+  }
+  // the first step into tmp (with the box's shell: Dirichlet / halo values for the steps behind it)
+  int rc = examg_axpby(lu, u_in, lu, tmp, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_jacobi(lu, u_in, tmp, lf, rhs, st, w, begin, end, stream);
+  if (rc) return rc;
+  if (examg_two_stage_eligible(lu, lf, st, begin, end, begin, end))      // the pair in one pass (it does not touch its tmp then)
+    return examg_jacobi2(lu, tmp, u_out, nullptr, lf, rhs, st, w, begin, end, stream);
+  rc = examg_axpby(lu, u_in, lu, u_out, 1.0, 0.0, b2, e2, stream);
+  if (rc) return rc;
+  rc = examg_jacobi(lu, tmp, u_out, lf, rhs, st, w, begin, end, stream);       // second step: tmp -> u_out
+  if (rc) return rc;
+  rc = examg_jacobi(lu, u_out, tmp, lf, rhs, st, w, begin, end, stream);       // third step: u_out -> tmp
+  if (rc) return rc;
+  return examg_axpby(lu, tmp, lu, u_out, 1.0, 0.0, begin, end, stream);
 }

@@ -151,13 +151,16 @@ class Peepholes:
                 return False
         elif self._bc_epoch.get((U.name, U.level), 0) != 0:
             return False
-        from .smoothers import jacobi_pair
+        from .smoothers import jacobi_pair, jacobi_triple
 
         key = (U.name, U.level)
         tmp = self._pair_tmp.get(key)
         if tmp is None:
             tmp = self._pair_tmp[key] = Field(U.name + "Tmp", U.level, U.layout, self.ops, 1, None)
         k = n
+        while k >= 3 and k != 4 and jacobi_triple(self.ops, self.comm, self.domain, U, F, A, w, tmp):    # three steps per pass on a lone block
+            self.launches += 1
+            k -= 3
         while k >= 2:
             self.launches += 1
             jacobi_pair(self.ops, self.comm, self.domain, U, F, A, w, tmp)
@@ -187,6 +190,17 @@ class Peepholes:
                 lb, le = self.domain.loop_bounds(U.layout)
                 b1, e1 = self._contract_bounds(U.layout, lb, le, expand, pos, neg)
                 b2, e2 = self._contract_bounds(U.layout, lb, le, expand - 1, pos, neg)
+                if n - it >= 3 and n - it != 4 and hasattr(self.ops, "jacobi3"):
+                    # three steps in one pass where they run on the same box (a block without neighbours: nothing is widened) --
+                    # Testing/PolyExpl/Jac3Dcc.exa4:27's five steps are then a pass of three and a pass of two
+                    b3, e3 = self._contract_bounds(U.layout, lb, le, expand - 2, pos, neg)
+                    if list(b1) == list(b2) == list(b3) and list(e1) == list(e2) == list(e3):
+                        self.launches += 1
+                        self.ops.jacobi3(U.lc, U.data(U.active), U.data(U.next), tmp.data(), F.lc, F.data(), A, w, b1, e1)
+                        U.advance()
+                        expand -= 3
+                        it += 3
+                        continue
                 self.launches += 1
                 self.ops.jacobi2_boxes(U.lc, U.data(U.active), U.data(U.next), tmp.data(), F.lc, F.data(), A, w, b1, e1, b2, e2)
                 U.advance()

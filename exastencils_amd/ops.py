@@ -88,6 +88,13 @@ class HipOps:
                                    C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin), ivec(end), self._stream()),
               "examg_jacobi2")
 
+    def jacobi3(self, lu, u_in, u_out, tmp, lf, rhs, st: Stencil, w: float, begin, end):
+        """Three Jacobi steps in one pass where the kernel applies (examg_jacobi3)."""
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_jacobi3(C.byref(lu), self.ptr(u_in), self.ptr(u_out), self.ptr(tmp) if tmp is not None else None,
+                                   C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin), ivec(end), self._stream()),
+              "examg_jacobi3")
+
     def jacobi_residual(self, lu, u_in, u_out, lf, rhs, lr, res, st: Stencil, w: float, begin, end):
         """One Jacobi step and the residual of its result in one pass (examg_jacobi_residual)."""
         sc = st.c_struct(self.ptr)

@@ -51,6 +51,22 @@ def _edges_matter(faces) -> bool:
 
 
 
+def jacobi_triple(ops, comm, domain, S, F, A, w: float, tmp_field) -> bool:
+    """Three applications of `Smoother@current` on field S (2 slots) in ONE pass (examg_jacobi3: temporal blocking of depth 3), on a block
+    without neighbours: reads slot <active>, writes the other slot, one advance -- the slot three advances make active.  Returns False
+    (nothing done) on a block with neighbours: three steps without an exchange would need three ghost layers; the caller runs a pair and
+    a step there."""
+    nd = domain.nd
+    if any(domain.neighbor(d, side) is not None for d in range(nd) for side in (-1, 1)) or not hasattr(ops, "jacobi3"):
+        return False
+    b, e = domain.loop_bounds(S.layout)
+    axis_only = all(sum(1 for c in o if c != 0) <= 1 for o in A.offsets)
+    comm.exchange(S, S.active, "ghost", axis_only)      # empty on a single block
+    ops.jacobi3(S.lc, S.data(S.active), S.data(S.next), tmp_field.data(), F.lc, F.data(), A, w, b, e)
+    S.advance()
+    return True
+
+
 def jacobi_pair(ops, comm, domain, S, F, A, w: float, tmp_field, overlap: bool = True, correction_from=None):
     """Two applications of `Smoother@current` (Testing/Smoothers/Jac.exa4:125-131) on field S (2 slots):
     reads slot <active>, leaves the result in the slot two `advance`s would make active (the same one),

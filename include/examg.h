@@ -155,6 +155,15 @@ int examg_jacobi2(const examg_layout_t *lu, const double *u_in, double *u_out, d
                   const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end,
                   examg_stream_t stream);
 
+/* Three Jacobi steps in ONE pass (temporal blocking of depth 3: `repeat 5 times with contraction [1,1,1]` of
+ * Testing/PolyExpl/Jac3Dcc.exa4:27 runs as 3 + 2; baseExt/ir/IR_ContractingLoop.scala:45-196): u_out[box] = J(J(J(u_in))), bit-identical
+ * to three examg_jacobi calls.  Same conditions as examg_jacobi2 (no halo exchange needed in between); the one-pass form exists for the
+ * 3-D 7-point constant stencil on rows of at least 64 points; otherwise a step into `tmp` and a pair from there (`tmp` must then be a
+ * distinct array; NULL is allowed where the one-pass form applies). */
+int examg_jacobi3(const examg_layout_t *lu, const double *u_in, double *u_out, double *tmp, const examg_layout_t *lf,
+                  const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end,
+                  examg_stream_t stream);
+
 /* One Jacobi step on [begin,end) and the residual of its result in ONE pass: u_out = J(u_in), res = rhs - A u_out on the box (the
  * last pre-smoothing `Smoother@current` + `Residual@current = RHS - Laplace * Solution`, Testing/SISC/3D_VarCoeff.exa4:141-153,
  * Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:215-219).  27-entry stencil fields in the record layout (EXAMG_CLAYOUT_ENTRY_FASTEST,

@@ -247,6 +247,65 @@ def test_two_stage_kernel_bit_exact(orc, two_stage_variant, kind, order, n, firs
     assert_same([hip.to_host(t) for t in g], c, "two-stage " + kind)
 
 
+@pytest.mark.parametrize("order", ["mp", "pm"])
+@pytest.mark.parametrize("shape,b,e", [((130, 130, 130), None, None), ((165, 150, 140), None, None), ((256, 256, 64), None, None),
+                                       ((200, 72, 90), None, None), ((136, 120, 120), [0, 1, 0], [137, 120, 121]),
+                                       ((150, 130, 110), [3, 2, 5], [148, 127, 108]), ((96, 96, 96), None, None)])
+def test_three_stage_kernel_bit_exact(hip, orc, shape, b, e, order):
+    """examg_jacobi3: three Jacobi steps in one pass (k_three_stage7_lds: 120-point x windows, 20-row groups, z chunks with three halo
+    planes) == three loops one after the other, bit for bit; ragged windows, row groups and chunks; a box over the duplicate planes of a
+    block with neighbours (its input halo in the ghost layer) and a box inside the inner points; 96^3 is below the kernel's size bound
+    and takes a step + a pair."""
+    st = laplace_fd(3, tuple(1.0 / n for n in shape), order)
+    if b is None:
+        b, e = [1, 1, 1], list(shape)
+
+    def f(ops):
+        lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+        u, fr, out, tmp = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size)
+        ops.fill_random(u, 12345)
+        ops.fill_random(fr, 4711)
+        ops.fill_random(out, 5)          # whatever was in the output array outside the box must survive
+        ops.jacobi3(lu.c_struct(), u, out, tmp, lf.c_struct(), fr, st, 0.8 / st.diag, b, e)
+        return [out, u]
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, "jacobi3")
+
+
+def test_three_stage_kernel_chunk_lengths(hipd, orc):
+    """The three-step pass with forced z chunks of 5, 8, 33 and 200 planes (debug build): partial last chunks, one chunk for the whole box;
+    both workgroup shapes (eight waves of three rows, twelve waves of two)."""
+    import ctypes as C
+
+    shape = (140, 100, 131)
+    st = laplace_fd(3, tuple(1.0 / n for n in shape), "mp")
+    hipd.L.examg_debug_three_stage.argtypes = [C.c_int] * 2
+    b, e = [1, 1, 1], list(shape)
+
+    def f(ops):
+        lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+        u, fr, out, tmp = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size)
+        ops.fill_random(u, 77)
+        ops.fill_random(fr, 78)
+        ops.fill_random(out, 79)
+        ops.jacobi3(lu.c_struct(), u, out, tmp, lf.c_struct(), fr, st, 0.8 / st.diag, b, e)
+        return [out]
+
+    want = [orc.to_host(t) for t in f(orc)]
+    try:
+        for wg in (83, 122):
+            hipd.L.examg_debug_three_stage(wg, 0)
+            for zc in (5, 8, 33, 200):
+                hipd.L.examg_debug_three_stage(0, zc)
+                got = f(hipd)
+                hipd.synchronize()
+                assert_same([hipd.to_host(t) for t in got], want, "jacobi3, workgroup shape %d, chunks of %d planes" % (wg, zc))
+    finally:
+        hipd.L.examg_debug_three_stage(83, 0)
+        hipd.L.examg_debug_three_stage(0, -1)
+
+
 SMALL_BOXES = [
     ((64, 64, 64), None, None),                         # level 6 of config 3: 63-point rows, 16 x 16 tiles of 4 x 4 rows
     ((32, 32, 32), None, None),                         # level 5
@@ -780,11 +839,14 @@ def test_restrict_and_prolong_bit_exact(hip, orc, nd, n, scale):
 
 @pytest.mark.parametrize("order", ["mp", "pm"])
 @pytest.mark.parametrize("shape,scale,align", [((64, 64, 64), 1.0, 0), ((130, 130, 130), 1.0, 0), ((200, 200, 200), 4.0, 0),
-                                               ((256, 72, 44), 1.0, 16), ((140, 396, 36), 1.0, 0)])
+                                               ((256, 72, 44), 1.0, 16), ((140, 396, 36), 1.0, 0), ((134, 70, 40), 1.0, 0),
+                                               ((152, 50, 36), 1.0, 0), ((182, 44, 36), 1.0, 0), ((262, 40, 36), 1.0, 0)])
 def test_residual_restrict_fused_bit_exact(hip, orc, shape, scale, align, order):
     """`Residual = RHS - A * Solution` + restriction in one pass (fine residual never stored) against the oracle's two loops;
     64^3: short coarse rows, the two-kernel path through the residual array; anisotropic blocks, a padded layout, the
-    restriction scaled by 4 (the generated-from-L3 programs)."""
+    restriction scaled by 4 (the generated-from-L3 programs).  Coarse rows of 64 / 127 / 69 / 66 / 75 / 90 / 130 points: the columns
+    that the 63-point tiles leave over run in narrow windows of 2 / 2 / 8 / 4 / 16 / 32 / 8 lanes (several row groups side by side
+    in a wave, the last wave partly empty); 99 points: 36 left over, a whole tile."""
     st = laplace_fd(3, tuple(1.0 / s for s in shape), order)
 
     def f(ops):
@@ -802,6 +864,42 @@ def test_residual_restrict_fused_bit_exact(hip, orc, shape, scale, align, order)
 
     g, c = both(hip, orc, f)
     assert_same(g, c, "residual_restrict")
+
+
+@pytest.mark.parametrize("rows", [1, 2])
+@pytest.mark.parametrize("shape", [(134, 70, 40), (256, 62, 44), (152, 38, 36), (182, 44, 20)])
+def test_residual_restrict_narrow_windows_forced_variants(hipd, orc, shape, rows):
+    """k_residual_restrict3 on the debug build: one and TWO coarse rows per wave (the product takes two from 8e6 coarse points on; an odd
+    count of coarse rows leaves the last row group with one) x narrow windows / whole tile for the left-over columns / x tiles fastest --
+    each against the oracle's two loops."""
+    import ctypes as C
+
+    st = laplace_fd(3, tuple(1.0 / s for s in shape), "mp")
+    L = hipd.L
+    L.examg_debug_residual_restrict.argtypes = [C.c_int] * 2
+    L.examg_debug_rr_order.argtypes = [C.c_int]
+
+    def f(ops):
+        cs = tuple(s // 2 for s in shape)
+        lu, lf, lc = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0, True, False), FieldLayout.node(3, cs, 0, True, False)
+        u, fr, r, fc = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lc.size)
+        ops.fill_random(u, 41)
+        ops.fill_random(fr, 42)
+        ops.fill_random(fc, 43)
+        ops.residual_restrict(lu.c_struct(), u, lf.c_struct(), fr, lu.c_struct(), r, st, lc.c_struct(), fc, 1.0, [1, 1, 1], list(shape), [1, 1, 1], list(cs))
+        return [fc]
+
+    want = [orc.to_host(t) for t in f(orc)]
+    try:
+        L.examg_debug_residual_restrict(0, (1000 if rows == 2 else 2000) + 8)
+        for order in (0, 2, 1):
+            L.examg_debug_rr_order(order)
+            got = f(hipd)
+            hipd.synchronize()
+            assert_same([hipd.to_host(t) for t in got], want, "residual_restrict, %d rows per wave, order %d" % (rows, order))
+    finally:
+        L.examg_debug_rr_order(0)
+        L.examg_debug_residual_restrict(0, 8)
 
 
 @pytest.mark.parametrize("shape,order", [((130, 130, 130), "mp"), ((200, 72, 44), "pm"), ((256, 256, 64), "mp"), ((40, 40, 40), "mp")])
