@@ -939,7 +939,6 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
 
 static thread_local int g_ts3_zc = -1;         // planes per z chunk of the three-step pass; -1: by size (examg_debug_three_stage)
 static thread_local int g_ts3_disable = 0;
-static thread_local int g_ts3_shape = 83;      // 83: eight waves of three rows; 122: twelve waves of two rows (the same 24-row tile, three waves per SIMD)
 
 // the three-step pass: 3-D 7-point constant stencils on rows of at least 64 points and at least 2^20 points (below, a pair and a step)
 static bool three_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
@@ -958,13 +957,16 @@ static int launch_three_stage_shape(const examg_layout_t *lu_, const double *u, 
   g.ntx = (box.n0() + TS3_OUT - 1) / TS3_OUT;
   g.nty = (box.n1() + NO - 1) / NO;
   const int xy = g.ntx * g.nty, n2 = box.n2();
-  // planes per chunk: six halo planes each; large boxes take short chunks (many workgroups, one moving front), smaller ones the count
-  // that fills the 256 CUs most evenly (the rule of launch_two_stage_lds with this kernel's halo)
-  int zc = 16;
-  if (box.count() < 50000000LL) {
+  // planes per chunk: six halo planes and two start-up steps each, one workgroup per CU -- the chunk count that minimises
+  // rounds of 256 workgroups x (planes per chunk + 8), chunks of 16 .. 64 planes where the box has them.  tools/time_three_stage.py --dbg,
+  // MI355X, ms per pass at 512^3, 16 / 24 / 40 / 48 / 56 / 64 / 128 planes: 0.887 / 0.834 / 0.825 / 0.834 / 0.815 / 0.899 / 1.023 (another box:
+  // 0.861 / 0.810 / - / 0.801 / - / 0.867 / -); 256^3, 16 / 20 / 44 / 64: 0.154 / 0.129 / 0.130 / 0.173
+  int zc = n2;
+  {
     long long best = -1;
     for (int t = 1; t <= (n2 + 7) / 8; ++t) {
       const int c = (n2 + t - 1) / t, tt = (n2 + c - 1) / c;
+      if ((c > 64 && t < (n2 + 7) / 8) || (c < 16 && t > 1)) continue;
       const long long cost = (((long long)xy * tt + 255) / 256) * (c + 8);
       if (best < 0 || cost < best) { best = cost; zc = c; }
     }
@@ -1000,7 +1002,8 @@ static int launch_three_stage_shape(const examg_layout_t *lu_, const double *u, 
 
 static int launch_three_stage(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs, double *out,
                               const examg_stencil_t *st, double w, const Box &box, hipStream_t s) {
-  if (g_ts3_shape == 122) return launch_three_stage_shape<12, 2>(lu, u, lf, rhs, out, st, w, box, s);
+  // eight waves of three rows (256 VGPRs, two waves per SIMD).  Twelve waves of two rows -- the same 24-row tile at three waves per SIMD --
+  // spill 44 registers at 168 and run at half the speed (512^3: 1.68 against 0.83 ms; written, measured, removed)
   return launch_three_stage_shape<8, 3>(lu, u, lf, rhs, out, st, w, box, s);
 }
 
@@ -1026,10 +1029,6 @@ extern "C" int examg_debug_two_stage_prol(int wpe) {
 }
 
 extern "C" int examg_debug_three_stage(int disable, int zc) {
-  if (disable >= 10) {     // 83 / 122: workgroup shape
-    g_ts3_shape = disable;
-    return 0;
-  }
   g_ts3_disable = disable;
   g_ts3_zc = zc > 0 ? zc : -1;
   return 0;

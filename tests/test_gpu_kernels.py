@@ -274,8 +274,7 @@ def test_three_stage_kernel_bit_exact(hip, orc, shape, b, e, order):
 
 
 def test_three_stage_kernel_chunk_lengths(hipd, orc):
-    """The three-step pass with forced z chunks of 5, 8, 33 and 200 planes (debug build): partial last chunks, one chunk for the whole box;
-    both workgroup shapes (eight waves of three rows, twelve waves of two)."""
+    """The three-step pass with forced z chunks of 5, 8, 33 and 200 planes (debug build): partial last chunks, one chunk for the whole box."""
     import ctypes as C
 
     shape = (140, 100, 131)
@@ -294,15 +293,12 @@ def test_three_stage_kernel_chunk_lengths(hipd, orc):
 
     want = [orc.to_host(t) for t in f(orc)]
     try:
-        for wg in (83, 122):
-            hipd.L.examg_debug_three_stage(wg, 0)
-            for zc in (5, 8, 33, 200):
-                hipd.L.examg_debug_three_stage(0, zc)
-                got = f(hipd)
-                hipd.synchronize()
-                assert_same([hipd.to_host(t) for t in got], want, "jacobi3, workgroup shape %d, chunks of %d planes" % (wg, zc))
+        for zc in (5, 8, 33, 200):
+            hipd.L.examg_debug_three_stage(0, zc)
+            got = f(hipd)
+            hipd.synchronize()
+            assert_same([hipd.to_host(t) for t in got], want, "jacobi3, chunks of %d planes" % zc)
     finally:
-        hipd.L.examg_debug_three_stage(83, 0)
         hipd.L.examg_debug_three_stage(0, -1)
 
 

@@ -19,12 +19,9 @@ sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [512, 256]
 
 
 def setk(k):
-    """None: nothing to set; -1: the defaults; (shape, planes per chunk)."""
-    if k is None:
-        return
-    shape, zc = (83, -1) if k == -1 else k
-    L.examg_debug_three_stage(shape, 0)
-    L.examg_debug_three_stage(0, zc)
+    """None: nothing to set; -1: the launcher's rule; otherwise planes per chunk."""
+    if k is not None:
+        L.examg_debug_three_stage(0, k)
 
 
 def timed(fn, reps=30):
@@ -57,9 +54,8 @@ for n in sizes:
              ("two steps", pp(lambda x, y: ops.jacobi2(Ls, x, y, None, Fs, f, A, w, b, e)), 2, None),
              ("three steps", pp(lambda x, y: ops.jacobi3(Ls, x, y, None, Fs, f, A, w, b, e)), 3, -1 if dbg else None)]
     if dbg:
-        for shape in (83, 122):
-            for zc in (16, 20, 24, 28, 36, 40, 44, 48, 52, 56, 64, 86, 128):
-                cases.append(("three steps, shape %d, %d planes per chunk" % (shape, zc), cases[2][1], 3, (shape, zc)))
+        for zc in (16, 20, 24, 28, 36, 40, 44, 48, 52, 56, 64, 86, 128):
+            cases.append(("three steps, %d planes per chunk" % zc, cases[2][1], 3, zc))
     for _ in range(30):
         for _, fn, _, zc in cases:
             setk(zc)
