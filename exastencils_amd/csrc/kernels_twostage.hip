@@ -716,9 +716,18 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
                    double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g) {
   constexpr int NS = RPW * NW;      // stage-1 rows s = 0 .. NS-1, global row rw0 - 2 + s
   constexpr int NO = NS - 4;        // output rows: s = 2 .. NS-3
-  // edge rows of the waves, two plane buffers each: [field][buffer][lo / hi][wave][lane]
+  // edge rows of the waves, two plane buffers each: [wave][field][buffer][lo / hi][lane] -- a wave's twelve rows lie within 12 KB, so one
+  // address register per wave addressed (own, below, above) and immediate offsets reach all of them
   __shared__ d2 SM[3 * 2 * 2 * NW * 64];
-#define EB(f, p, h, wq) SM[((((f) * 2 + (p)) * 2 + (h)) * NW + (wq)) * 64 + lane]
+#define EB(f, p, h, wq) EBW(wave_rows(wq), f, p, h)
+#define EBW(rows, f, p, h) (rows)[((((f) * 2 + (p)) * 2 + (h)) * 64)]
+  // a wave's block of rows as scalar offset + this lane's 16 bytes, formed where it is used: kept loop-invariant in registers, the three
+  // addresses (own block, the waves below and above) cost the registers that the plane loop does not have
+  auto wave_rows = [&](int wq) {
+    unsigned off = (unsigned)wq * (3 * 2 * 2 * 64 * 16);
+    asm volatile("" : "+s"(off));
+    return reinterpret_cast<d2 *>(reinterpret_cast<char *>(SM) + off + threadIdx.x * 16u);
+  };
   const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
   int t = blockIdx.x;
   if (g.remap == 2) {  // XCD-contiguous within every z layer of tiles (see k_two_stage7_lds)
@@ -828,6 +837,9 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
   // publish the edge rows of input plane q0
   EB(0, 0, 0, wv) = U[1][0];
   EB(0, 0, 1, wv) = U[1][RPW - 1];
+  // every load of the prologue has arrived before the plane loop starts: at the loop header the compiler otherwise joins "the prologue's
+  // loads may still be out" with the steady state and waits for ALL loads in flight at the top of every fourth step
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
   __syncthreads();
 
   using I0_ = std::integral_constant<int, 0>;
@@ -854,62 +866,78 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
     // y-neighbour rows from the waves below and above (input plane q, stage-1 plane q-1, stage-2 plane q-2); the first wave's lower and
     // the last wave's upper input row are their own outer rows; of the stage fields those rows do not exist (some row is read instead:
     // they are neighbours of rows that are nobody's input)
-    d2 ulo = EB(0, ub, 1, wlo), uhi = EB(0, ub, 0, whi);
-    const d2 vlo = EB(1, vb, 1, wlo), vhi = EB(1, vb, 0, whi);
-    const d2 zlo = EB(2, vb, 1, wlo), zhi = EB(2, vb, 0, whi);
+    const d2 *const below = wave_rows(wlo), *const above = wave_rows(whi);
+    d2 ulo = EBW(below, 0, ub, 1), uhi = EBW(above, 0, ub, 0);
+    const d2 vlo = EBW(below, 1, vb, 1), vhi = EBW(above, 1, vb, 0);
+    const d2 zlo = EBW(below, 2, vb, 1), zhi = EBW(above, 2, vb, 0);
     if (wv == 0) ulo = O[(PH + 1) & 3];
     if (wv == NW - 1) uhi = O[(PH + 1) & 3];
-    // ---- stage 1 on plane q ----
-    {
-      const bool pin = q >= box.b2 && q < box.e2;
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        const d2 c = Uc[r];
-        const d2 n = jac(c, r == 0 ? ulo : Uc[r == 0 ? 0 : r - 1], r == RPW - 1 ? uhi : Uc[r == RPW - 1 ? r : r + 1], Um[r], Up[r], Fq[r]);
-        const bool on = pin && row_in[r];
-        Vn[r].x = (inx_a && on) ? n.x : c.x;
-        Vn[r].y = (inx_b && on) ? n.y : c.y;
-      }
-    }
-    // ---- stage 2 on plane q-1 ----
-    if (q >= mb) {     // wave-uniform: before that nothing reads what it would produce
-      const bool pin = q - 1 >= box.b2 && q - 1 < box.e2;
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
+    // The stages row by row, the MIDDLE row of every stage first: it needs no other wave's rows, so its arithmetic runs while the LDS
+    // reads above are still on their way; the first and the last row, which do, follow.
+    const bool pin1 = q >= box.b2 && q < box.e2, pin2 = q - 1 >= box.b2 && q - 1 < box.e2;
+    const bool run2 = q >= mb;          // wave-uniform: before that nothing reads what stage 2 would produce
+    const bool run3 = q - 2 >= mb;      // the first output plane
+    auto stage1 = [&](auto Rc) {        // plane q
+      constexpr int r = decltype(Rc)::value;
+      const d2 c = Uc[r];
+      const d2 n = jac(c, r == 0 ? ulo : Uc[r == 0 ? 0 : r - 1], r == RPW - 1 ? uhi : Uc[r == RPW - 1 ? r : r + 1], Um[r], Up[r], Fq[r]);
+      const bool on = pin1 && row_in[r];
+      Vn[r].x = (inx_a && on) ? n.x : c.x;
+      Vn[r].y = (inx_b && on) ? n.y : c.y;
+    };
+    auto stage2 = [&](auto Rc) {        // plane q-1
+      constexpr int r = decltype(Rc)::value;
+      if (run2) {
         const d2 c = Vm[r];
         const d2 n = jac(c, r == 0 ? vlo : Vm[r == 0 ? 0 : r - 1], r == RPW - 1 ? vhi : Vm[r == RPW - 1 ? r : r + 1], Vmm[r], Vn[r], Fm[r]);
-        const bool on = pin && row_in[r];
+        const bool on = pin2 && row_in[r];
         Wn[r].x = (inx_a && on) ? n.x : c.x;
         Wn[r].y = (inx_b && on) ? n.y : c.y;
       }
-    }
-    // ---- stage 3 on plane q-2: output rows inside the box ----
-    if (q - 2 >= mb) {
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        if (row_out[r]) {   // wave-uniform
-          const d2 c = Wm[r];
-          const d2 o = jac(c, r == 0 ? zlo : Wm[r == 0 ? 0 : r - 1], r == RPW - 1 ? zhi : Wm[r == RPW - 1 ? r : r + 1], Wmm[r], Wn[r], Fmm[r]);
-          double *qp = reinterpret_cast<double *>(obase[r] + obytes + vo);
-          if (st_a && st_b) {
-            if (NT) store2_nt(qp, o);
-            else store2(qp, o);
-          } else if (st_a) {
-            qp[0] = o.x;
-          } else if (st_b) {
-            qp[1] = o.y;
-          }
+    };
+    auto stage3 = [&](auto Rc) {        // plane q-2: output rows inside the box
+      constexpr int r = decltype(Rc)::value;
+      if (run3 && row_out[r]) {         // wave-uniform
+        const d2 c = Wm[r];
+        const d2 o = jac(c, r == 0 ? zlo : Wm[r == 0 ? 0 : r - 1], r == RPW - 1 ? zhi : Wm[r == RPW - 1 ? r : r + 1], Wmm[r], Wn[r], Fmm[r]);
+        double *qp = reinterpret_cast<double *>(obase[r] + obytes + vo);
+        if (st_a && st_b) {
+          if (NT) store2_nt(qp, o);
+          else store2(qp, o);
+        } else if (st_a) {
+          qp[0] = o.x;
+        } else if (st_b) {
+          qp[1] = o.y;
         }
       }
+    };
+    if constexpr (RPW == 3) {
+      stage1(I1_{});
+      stage2(I1_{});
+      stage3(I1_{});
+      stage1(I0_{});
+      stage1(I2_{});
+      stage2(I0_{});
+      stage2(I2_{});
+      stage3(I0_{});
+      stage3(I2_{});
+    } else {
+      stage1(I0_{});
+      stage1(I1_{});
+      stage2(I0_{});
+      stage2(I1_{});
+      stage3(I0_{});
+      stage3(I1_{});
     }
     // ---- publish the edge rows of input plane q+1, stage-1 plane q, stage-2 plane q-1 for the next step ----
     if (q <= me) {
-      EB(0, vb, 0, wv) = Up[0];
-      EB(0, vb, 1, wv) = Up[RPW - 1];
-      EB(1, ub, 0, wv) = Vn[0];
-      EB(1, ub, 1, wv) = Vn[RPW - 1];
-      EB(2, ub, 0, wv) = Wn[0];
-      EB(2, ub, 1, wv) = Wn[RPW - 1];
+      d2 *const own = wave_rows(wv);
+      EBW(own, 0, vb, 0) = Up[0];
+      EBW(own, 0, vb, 1) = Up[RPW - 1];
+      EBW(own, 1, ub, 0) = Vn[0];
+      EBW(own, 1, ub, 1) = Vn[RPW - 1];
+      EBW(own, 2, ub, 0) = Wn[0];
+      EBW(own, 2, ub, 1) = Wn[RPW - 1];
     }
     // loads without a condition: input plane q+3 into the slot of plane q-1, rhs plane q+2 into the slot of plane q-2
 #pragma unroll
@@ -922,7 +950,9 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
     advance(cf);
     obytes += ostep;
     __syncthreads();
+#ifndef TS3_NO_SCHED_BARRIER
     __builtin_amdgcn_sched_barrier(0);
+#endif
   };
   const int qe = me + 1;      // last step: stage 3 on plane me - 1
   for (int q = q0; q <= qe; q += 4) {
@@ -935,6 +965,7 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
     step(q + 3, I3_{});
   }
 #undef EB
+#undef EBW
 }
 
 static thread_local int g_ts3_zc = -1;         // planes per z chunk of the three-step pass; -1: by size (examg_debug_three_stage)
