@@ -388,7 +388,7 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     // ---- stage 2 on plane m = q-1, own rows that are output rows ----
     auto stage2 = [&](auto Rc) {
       constexpr int r = decltype(Rc)::value;
-      if (m >= mlo && row_out[r]) {   // wave-uniform
+      if (m >= mlo && m < me && row_out[r]) {   // wave-uniform
         const d2 c = Vc[r];
         const d2 ym = r == 0 ? vlo : Vc[r == 0 ? 0 : r - 1];
         const d2 yp = r == RPW - 1 ? vhi : Vc[r == RPW - 1 ? r : r + 1];
@@ -468,14 +468,29 @@ k_two_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const
     __builtin_amdgcn_sched_barrier(0);    // nothing of the next step is scheduled into this one (register pressure: 4 waves per SIMD)
   };
   auto march = [&](auto PFWc) {
-    for (int q = mb - 1; q <= me; q += 4) {
-      step(q, I0_{}, PFWc);
-      if (q + 1 > me) break;
-      step(q + 1, I1_{}, PFWc);
-      if (q + 2 > me) break;
-      step(q + 2, I2_{}, PFWc);
-      if (q + 3 > me) break;
-      step(q + 3, I3_{}, PFWc);
+    // whole groups of four steps: up to three steps past the last one (q = me) run along -- their loads are clamped into the arrays, they
+    // publish nothing and stage 2 stores nothing past plane me - 1.  With `break`s between the steps the exits shared a block with the
+    // loop's back edge, and the compiler, joining the load states of all four steps at the loop header, waited for EVERY load in flight
+    // at the top of each group: the prefetch distance of two steps was lost in every fourth step.
+    // (tools/ab_libs.py, both builds in one process, 512^3: Jacobi pair 0.6238 -> 0.6226 ms, red-black sweep 0.6275 -> 0.6241, 256^3 pair
+    // 0.0929 -> 0.0912; the form with the correction folded in lost -- 0.700 -> 0.717 -- and keeps its exits.)
+    if constexpr (PROL) {
+      for (int q = mb - 1; q <= me; q += 4) {
+        step(q, I0_{}, PFWc);
+        if (q + 1 > me) break;
+        step(q + 1, I1_{}, PFWc);
+        if (q + 2 > me) break;
+        step(q + 2, I2_{}, PFWc);
+        if (q + 3 > me) break;
+        step(q + 3, I3_{}, PFWc);
+      }
+    } else {
+      for (int q = mb - 1; q <= me; q += 4) {
+        step(q, I0_{}, PFWc);
+        step(q + 1, I1_{}, PFWc);
+        step(q + 2, I2_{}, PFWc);
+        step(q + 3, I3_{}, PFWc);
+      }
     }
   };
   if constexpr (COL && (RPW & 1)) {
@@ -571,9 +586,14 @@ static int launch_two_stage_lds(const examg_layout_t *lu_, const double *u, cons
   // at least 16 planes per chunk (4 halo planes each); 8 on small boxes that would leave most of the chip idle otherwise
   // (tools/sweep_two_stage3.py, 5-wave workgroups, 16 / 8 / 4 planes: 128^3 0.0243 / 0.0186 / 0.0300 ms, 96^3 0.0235 / 0.0149 / 0.0129)
   int minzc = g_ts_minzc;
-  if (minzc < 0) minzc = ((long long)xy * ((n2 + 15) / 16) < 512 || (mid && g_ts_blocks <= 0)) ? 8 : 16;
+  // (14 and 10 since the plane loop runs groups of four steps, zc + 2 per chunk: 16 and 8 before.  tools/ab_chunks4.py, 512^3, 14 / 16 / 18 / 22
+  // planes: Jacobi pair 0.622 / 0.644 / 0.625 / 0.644 ms, red-black sweep 0.624 / 0.647 / 0.638 / 0.647)
+  if (minzc < 0) minzc = ((long long)xy * ((n2 + 15) / 16) < 512 || (mid && g_ts_blocks <= 0)) ? (prol ? 8 : 10) : (prol ? 16 : 14);
   if (zc < minzc) zc = minzc;
-  if (prol || COL) zc += zc & 1;   // even chunks: every workgroup starts on the same plane parity (PROL: canonical parities; COL: one PF)
+  // the plane loop runs whole groups of four steps (a chunk of zc planes takes zc + 2): chunk lengths of 4 k + 2 planes waste none --
+  // 18 instead of 16 at 512^3.  Even in any case: every workgroup starts on the same plane parity (PROL: canonical parities; COL: one PF)
+  if (g_ts_minzc < 0 && g_ts_blocks <= 0 && !prol) zc += (6 - (zc & 3)) & 3;
+  if (prol || COL) zc += zc & 1;
   // the kernel forms the offset of a row within a plane as a 32-bit product
   if (lu.s2 >= (1LL << 32) || lf.s2 >= (1LL << 32)) { set_error("examg two-stage kernel: a plane must hold less than 2^32 elements"); return 1; }
   if (zc > n2) zc = n2 + ((prol || COL) ? (n2 & 1) : 0);
@@ -876,7 +896,7 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
     // reads above are still on their way; the first and the last row, which do, follow.
     const bool pin1 = q >= box.b2 && q < box.e2, pin2 = q - 1 >= box.b2 && q - 1 < box.e2;
     const bool run2 = q >= mb;          // wave-uniform: before that nothing reads what stage 2 would produce
-    const bool run3 = q - 2 >= mb;      // the first output plane
+    const bool run3 = q - 2 >= mb && q - 2 < me;      // output planes of the chunk
     auto stage1 = [&](auto Rc) {        // plane q
       constexpr int r = decltype(Rc)::value;
       const d2 c = Uc[r];
@@ -955,13 +975,13 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
 #endif
   };
   const int qe = me + 1;      // last step: stage 3 on plane me - 1
+  // whole groups of four steps: up to three steps past the last one run along (their loads are clamped into the arrays, stage 3 stores
+  // nothing past plane me - 1).  With `break`s inside the group the exits share a block with the loop's back edge: the compiler then joins
+  // the load states of all four steps at the loop header and waits for EVERY load in flight at the top of each group.
   for (int q = q0; q <= qe; q += 4) {
     step(q, I0_{});
-    if (q + 1 > qe) break;
     step(q + 1, I1_{});
-    if (q + 2 > qe) break;
     step(q + 2, I2_{});
-    if (q + 3 > qe) break;
     step(q + 3, I3_{});
   }
 #undef EB
@@ -998,9 +1018,10 @@ static int launch_three_stage_shape(const examg_layout_t *lu_, const double *u, 
     for (int t = 1; t <= (n2 + 7) / 8; ++t) {
       const int c = (n2 + t - 1) / t, tt = (n2 + c - 1) / c;
       if ((c > 64 && t < (n2 + 7) / 8) || (c < 16 && t > 1)) continue;
-      const long long cost = (((long long)xy * tt + 255) / 256) * (c + 8);
+      const long long cost = (((long long)xy * tt + 255) / 256) * (((c + 4 + 3) & ~3) + 4);      // whole groups of four steps
       if (best < 0 || cost < best) { best = cost; zc = c; }
     }
+    if (zc + 3 < n2) zc = (zc + 3) & ~3;       // zc + 4 steps: a multiple of four wastes none
   }
   if (g_ts3_zc > 0) zc = g_ts3_zc;
   if (zc > n2) zc = n2;
@@ -1067,7 +1088,7 @@ extern "C" int examg_debug_three_stage(int disable, int zc) {
 
 extern "C" int examg_debug_two_stage(int disable, int blocks, int remap, int wy) {
   g_ts_disable = disable;
-  if (blocks > 0) g_ts_blocks = blocks;
+  if (blocks != 0) g_ts_blocks = blocks > 0 ? blocks : -1;     // 0: unchanged; negative: back to the rule
   if (remap >= 0) g_ts_remap = remap;
   g_ts_minzc = wy > 0 ? wy : -1;    // 4th argument: minimum planes per z chunk (<= 0: default rule)
   return 0;
