@@ -730,7 +730,11 @@ static bool stage_boxes_ok(const examg_layout_t *lf_, const Box &box1, const Box
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TS3_OUT = 120;   // outputs per 128-point window: lanes 2 .. 61
 
-template <int ORDER, int NW, bool NT, int RPW = 3>
+// COL: three colour loops of a red-black smoother instead -- stage 1 updates the points of colour g.first, stage 2 the other colour, stage 3
+// colour g.first again (three sweeps = six colour loops = two such passes, the second one starting with the other colour).  Which point of a
+// pair a stage updates is the same for all three stages of a step (plane and colour both move by one from stage to stage) and wave-uniform
+// per row: one convolution per pair and stage, the other point passes through.
+template <int ORDER, int NW, bool NT, int RPW = 3, bool COL = false>
 __global__ void __launch_bounds__(64 * NW, 1)
 k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, const double *__restrict__ rhs,
                    double *__restrict__ out, Coef7 k, double w, Box box, TSGeom g) {
@@ -876,6 +880,25 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
     n.y = c.y + w * (f.y - acc_b);
     return n;
   };
+  auto jac_x = [&](d2 c, d2 ym, d2 yp, d2 zm, d2 zp, d2 f) {      // the first point of the pair only
+    const double xl = lane_below0(c.y);
+    const double acc = conv7<ORDER>(k, c.x, xl, c.y, ym.x, yp.x, zm.x, zp.x);
+    return c.x + w * (f.x - acc);
+  };
+  auto jac_y = [&](d2 c, d2 ym, d2 yp, d2 zm, d2 zp, d2 f) {      // the second point only
+    const double xr = lane_above0(c.x);
+    const double acc = conv7<ORDER>(k, c.y, c.x, xr, ym.y, yp.y, zm.y, zp.y);
+    return c.y + w * (f.y - acc);
+  };
+  // COL: the update of a pair in the step of plane q, row r -- the first point if its colour (x + y + z) & 1 is the colour of the stage
+  auto upd = [&](bool first_point, d2 c, d2 ym, d2 yp, d2 zm, d2 zp, d2 f) {
+    if constexpr (!COL) return jac(c, ym, yp, zm, zp, f);
+    d2 n = c;
+    if (first_point) n.x = jac_x(c, ym, yp, zm, zp, f);      // wave-uniform
+    else n.y = jac_y(c, ym, yp, zm, zp, f);
+    return n;
+  };
+  const int cpar = xw + g.first;
   auto step = [&](const int q, auto PHc) {
     constexpr int PH = decltype(PHc)::value;
     d2 (&Um)[RPW] = U[PH & 3], (&Uc)[RPW] = U[(PH + 1) & 3], (&Up)[RPW] = U[(PH + 2) & 3];
@@ -897,10 +920,13 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
     const bool pin1 = q >= box.b2 && q < box.e2, pin2 = q - 1 >= box.b2 && q - 1 < box.e2;
     const bool run2 = q >= mb;          // wave-uniform: before that nothing reads what stage 2 would produce
     const bool run3 = q - 2 >= mb && q - 2 < me;      // output planes of the chunk
+    bool fp[RPW];       // COL: does this step update the first point of the pairs of row r (stage 1 on plane q with colour g.first, stage 2 on
+#pragma unroll          // plane q-1 with the other colour, stage 3 on plane q-2 with g.first again: the same parity)
+    for (int r = 0; r < RPW; ++r) fp[r] = ((cpar + grow[r] + q) & 1) == 0;
     auto stage1 = [&](auto Rc) {        // plane q
       constexpr int r = decltype(Rc)::value;
       const d2 c = Uc[r];
-      const d2 n = jac(c, r == 0 ? ulo : Uc[r == 0 ? 0 : r - 1], r == RPW - 1 ? uhi : Uc[r == RPW - 1 ? r : r + 1], Um[r], Up[r], Fq[r]);
+      const d2 n = upd(fp[r], c, r == 0 ? ulo : Uc[r == 0 ? 0 : r - 1], r == RPW - 1 ? uhi : Uc[r == RPW - 1 ? r : r + 1], Um[r], Up[r], Fq[r]);
       const bool on = pin1 && row_in[r];
       Vn[r].x = (inx_a && on) ? n.x : c.x;
       Vn[r].y = (inx_b && on) ? n.y : c.y;
@@ -909,7 +935,7 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
       constexpr int r = decltype(Rc)::value;
       if (run2) {
         const d2 c = Vm[r];
-        const d2 n = jac(c, r == 0 ? vlo : Vm[r == 0 ? 0 : r - 1], r == RPW - 1 ? vhi : Vm[r == RPW - 1 ? r : r + 1], Vmm[r], Vn[r], Fm[r]);
+        const d2 n = upd(fp[r], c, r == 0 ? vlo : Vm[r == 0 ? 0 : r - 1], r == RPW - 1 ? vhi : Vm[r == RPW - 1 ? r : r + 1], Vmm[r], Vn[r], Fm[r]);
         const bool on = pin2 && row_in[r];
         Wn[r].x = (inx_a && on) ? n.x : c.x;
         Wn[r].y = (inx_b && on) ? n.y : c.y;
@@ -919,7 +945,7 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
       constexpr int r = decltype(Rc)::value;
       if (run3 && row_out[r]) {         // wave-uniform
         const d2 c = Wm[r];
-        const d2 o = jac(c, r == 0 ? zlo : Wm[r == 0 ? 0 : r - 1], r == RPW - 1 ? zhi : Wm[r == RPW - 1 ? r : r + 1], Wmm[r], Wn[r], Fmm[r]);
+        const d2 o = upd(fp[r], c, r == 0 ? zlo : Wm[r == 0 ? 0 : r - 1], r == RPW - 1 ? zhi : Wm[r == RPW - 1 ? r : r + 1], Wmm[r], Wn[r], Fmm[r]);
         double *qp = reinterpret_cast<double *>(obase[r] + obytes + vo);
         if (st_a && st_b) {
           if (NT) store2_nt(qp, o);
@@ -998,9 +1024,9 @@ static bool three_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, c
   return u.s2 < (1LL << 32) && f.s2 < (1LL << 32);
 }
 
-template <int NW, int RPW>
+template <int NW, int RPW, bool COL>
 static int launch_three_stage_shape(const examg_layout_t *lu_, const double *u, const examg_layout_t *lf_, const double *rhs, double *out,
-                                    const examg_stencil_t *st, double w, const Box &box, hipStream_t s) {
+                                    const examg_stencil_t *st, double w, const Box &box, hipStream_t s, int first) {
   constexpr int NO = RPW * NW - 4;
   const LayoutDev lu = make_layout(lu_), lf = make_layout(lf_);
   TSGeom g;
@@ -1029,7 +1055,7 @@ static int launch_three_stage_shape(const examg_layout_t *lu_, const double *u, 
   g.ntz = (n2 + zc - 1) / zc;
   g.nblocks = xy * g.ntz;
   g.remap = g_ts_remap >= 0 ? g_ts_remap : 2;
-  g.first = 0;
+  g.first = first;
   g.box1 = box;
   g.ax0 = -lu.ref0; g.ax1 = lu.tot0 - lu.ref0;
   g.ay0 = -lu.ref1; g.ay1 = lu.tot1 - lu.ref1;
@@ -1039,7 +1065,7 @@ static int launch_three_stage_shape(const examg_layout_t *lu_, const double *u, 
   const int ord = canonical_order7(st);
   const bool nt = g_ts_nt >= 0 ? g_ts_nt != 0 : box.count() * 24LL > 200000000LL;    // the store policy of the two-step passes
   dim3 block(64, NW, 1), grid(g.nblocks, 1, 1);
-#define EXAMG_TS3(ORD, NTV) hipLaunchKernelGGL((k_three_stage7_lds<ORD, NW, NTV, RPW>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g)
+#define EXAMG_TS3(ORD, NTV) hipLaunchKernelGGL((k_three_stage7_lds<ORD, NW, NTV, RPW, COL>), grid, block, 0, s, lu, u, lf, rhs, out, k, w, box, g)
   if (ord == 0) {
     if (nt) EXAMG_TS3(0, true);
     else EXAMG_TS3(0, false);
@@ -1056,7 +1082,12 @@ static int launch_three_stage(const examg_layout_t *lu, const double *u, const e
                               const examg_stencil_t *st, double w, const Box &box, hipStream_t s) {
   // eight waves of three rows (256 VGPRs, two waves per SIMD).  Twelve waves of two rows -- the same 24-row tile at three waves per SIMD --
   // spill 44 registers at 168 and run at half the speed (512^3: 1.68 against 0.83 ms; written, measured, removed)
-  return launch_three_stage_shape<8, 3>(lu, u, lf, rhs, out, st, w, box, s);
+  return launch_three_stage_shape<8, 3, false>(lu, u, lf, rhs, out, st, w, box, s, 0);
+}
+
+static int launch_three_colours(const examg_layout_t *lu, const double *u, const examg_layout_t *lf, const double *rhs, double *out,
+                                const examg_stencil_t *st, double w, int first, const Box &box, hipStream_t s) {
+  return launch_three_stage_shape<8, 3, true>(lu, u, lf, rhs, out, st, w, box, s, first);
 }
 
 }  // namespace examg
@@ -1383,4 +1414,36 @@ extern "C" int examg_jacobi3(const examg_layout_t *lu, const double *u_in, doubl
   rc = examg_jacobi(lu, u_out, tmp, lf, rhs, st, w, begin, end, stream);       // third step: u_out -> tmp
   if (rc) return rc;
   return examg_axpby(lu, tmp, lu, u_out, 1.0, 0.0, begin, end, stream);
+}
+
+// 1 if examg_jacobi3 / examg_rbgs_colours3 will run their one-pass kernel for this box, 0 if they will run their loops one after the other
+extern "C" int examg_three_stage_eligible(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const int32_t *begin,
+                                          const int32_t *end) {
+  if (!lu || !lf || !st || !begin || !end) return 0;
+  return three_stage_ok(lu, lf, st, make_box(begin, end)) ? 1 : 0;
+}
+
+// Three colour loops of a red-black smoother in ONE pass, out of place: colour `first` on [begin,end), then the other colour, then `first`
+// again (`repeat 3 times { color with { (i0 + i1 + i2) % 2 ... } }`, Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:204-213, is six colour
+// loops: two such passes, the second with first = 1 - first).  u_out receives the result on the box; bit-identical to three
+// examg_rbgs_colour calls in place.  Where the one-pass kernel does not apply: a copy of the box with its shell and the three loops on it.
+extern "C" int examg_rbgs_colours3(const examg_layout_t *lu, const double *u_in, double *u_out, const examg_layout_t *lf, const double *rhs,
+                                   const examg_stencil_t *st, double w, int first, const int32_t *begin, const int32_t *end,
+                                   examg_stream_t stream) {
+  if (!lu || !u_in || !u_out || !lf || !rhs || !st || !begin || !end) { set_error("examg_rbgs_colours3: null argument"); return 1; }
+  if (u_in == u_out) { set_error("examg_rbgs_colours3: out of place only"); return 1; }
+  if (first != 0 && first != 1) { set_error("examg_rbgs_colours3: first colour must be 0 or 1"); return 1; }
+  const Box box = make_box(begin, end);
+  if (box.count() == 0) return 0;
+  if (three_stage_ok(lu, lf, st, box)) return launch_three_colours(lu, u_in, lf, rhs, u_out, st, w, first, box, (hipStream_t)stream);
+  const int reach = stencil_reach(st);
+  int32_t b2[3], e2[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool on = d < lu->nd;
+    b2[d] = begin[d] - (on ? reach : 0);
+    e2[d] = end[d] + (on ? reach : 0);
+  }
+  int rc = examg_axpby(lu, u_in, lu, u_out, 1.0, 0.0, b2, e2, stream);
+  for (int k = 0; k < 3 && !rc; ++k) rc = examg_rbgs_colour(lu, u_out, lf, rhs, st, w, (k & 1) ? 1 - first : first, begin, end, stream);
+  return rc;
 }

@@ -70,7 +70,7 @@ DBG_LIB_PATH = os.path.join(_HERE, "libexamg_dbg.so")   # -DEXAMG_DEBUG_HOOKS bu
 # every symbol include/examg.h declares
 SYMBOLS = [
     "examg_version", "examg_last_error", "examg_device_count", "examg_stencil_op", "examg_jacobi",
-    "examg_rbgs_colour", "examg_residual", "examg_rbgs_sweep_fused", "examg_rbgs_sweep_fused_boxes", "examg_jacobi2", "examg_jacobi3", "examg_jacobi2_boxes", "examg_jacobi_residual", "examg_rbgs_sweep_fused_prolong", "examg_jacobi2_prolong", "examg_rbgs_sweep_fused_zero", "examg_two_stage_eligible", "examg_restrict", "examg_residual_restrict", "examg_prolong_add",
+    "examg_rbgs_colour", "examg_residual", "examg_rbgs_sweep_fused", "examg_rbgs_sweep_fused_boxes", "examg_jacobi2", "examg_jacobi3", "examg_rbgs_colours3", "examg_three_stage_eligible", "examg_jacobi2_boxes", "examg_jacobi_residual", "examg_rbgs_sweep_fused_prolong", "examg_jacobi2_prolong", "examg_rbgs_sweep_fused_zero", "examg_two_stage_eligible", "examg_restrict", "examg_residual_restrict", "examg_prolong_add",
     "examg_set", "examg_axpby", "examg_axpby_dev", "examg_reduce_work_bytes", "examg_dot", "examg_residual_norm2",
     "examg_fill_expr", "examg_apply_dirichlet_expr", "examg_fill_dup_faces_expr", "examg_max_err_expr", "examg_init_varcoeff7", "examg_init_helmholtz27", "examg_pack", "examg_unpack",
     "examg_cg_coarse", "examg_cg_coarse_variant", "examg_fill_random", "examg_copy_to_external", "examg_copy_from_external",
@@ -126,6 +126,8 @@ def load(path=None):
     L.examg_rbgs_sweep_fused.argtypes = [lp, vp, vp, lp, vp, sp, C.c_double, C.c_int, ip, ip, vp]
     L.examg_jacobi2.argtypes = [lp, vp, vp, vp, lp, vp, sp, C.c_double, ip, ip, vp]
     L.examg_jacobi3.argtypes = [lp, vp, vp, vp, lp, vp, sp, C.c_double, ip, ip, vp]
+    L.examg_rbgs_colours3.argtypes = [lp, vp, vp, lp, vp, sp, C.c_double, C.c_int, ip, ip, vp]
+    L.examg_three_stage_eligible.argtypes = [lp, lp, sp, ip, ip]
     L.examg_jacobi_residual.argtypes = [lp, vp, vp, lp, vp, lp, vp, sp, C.c_double, ip, ip, vp]
     L.examg_jacobi2_boxes.argtypes = [lp, vp, vp, vp, lp, vp, sp, C.c_double, ip, ip, ip, ip, vp]
     L.examg_rbgs_sweep_fused_boxes.argtypes = [lp, vp, vp, vp, lp, vp, sp, C.c_double, C.c_int, ip, ip, ip, ip, vp]

@@ -95,6 +95,16 @@ class HipOps:
                                    C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), ivec(begin), ivec(end), self._stream()),
               "examg_jacobi3")
 
+    def rbgs_colours3(self, lu, u_in, u_out, lf, rhs, st: Stencil, w: float, first: int, begin, end):
+        """Three colour loops (first, other, first) in one pass where the kernel applies (examg_rbgs_colours3)."""
+        sc = st.c_struct(self.ptr)
+        check(self.L.examg_rbgs_colours3(C.byref(lu), self.ptr(u_in), self.ptr(u_out), C.byref(lf), self.ptr(rhs), C.byref(sc), float(w), int(first),
+                                         ivec(begin), ivec(end), self._stream()), "examg_rbgs_colours3")
+
+    def three_stage_eligible(self, lu, lf, st: Stencil, begin, end) -> bool:
+        sc = st.c_struct(self.ptr)
+        return bool(self.L.examg_three_stage_eligible(C.byref(lu), C.byref(lf), C.byref(sc), ivec(begin), ivec(end)))
+
     def jacobi_residual(self, lu, u_in, u_out, lf, rhs, lr, res, st: Stencil, w: float, begin, end):
         """One Jacobi step and the residual of its result in one pass (examg_jacobi_residual)."""
         sc = st.c_struct(self.ptr)

@@ -134,6 +134,9 @@ class ConfigL4:
     align: int = 0
     fused_coarse: bool = True     # single block: mgCycle@coarsest as one persistent kernel
     fused_rbgs: bool = False      # one-pass red-black sweep (out of place, pointer swap)
+    # single block + fused_rbgs: three plain sweeps in a row -- six colour loops -- run as TWO passes of three colour loops each
+    # (examg_rbgs_colours3) where the kernel layer has the one-pass form for the level (examg_three_stage_eligible)
+    fused_rbgs3: bool = True
     fused_residual_restrict: bool = False   # single block: `Residual = ...` + restriction as one pass, fine residual not stored
     # single block + fused_rbgs: the correction loop is folded into the first post-smoothing sweep on levels with at least this
     # many points (0 = never).  MI355X: 512^3 1.16 -> 0.87 ms; below ~5*10^7 points the fields sit in the Infinity Cache, the
@@ -164,6 +167,7 @@ class SolverFromL4(_Program):
         self.Residual: Dict[int, Field] = {}
         self.Laplace: Dict[int, Stencil] = {}
         self._sol_alt: Dict[int, object] = {}
+        self._three_ok: Dict[int, bool] = {}
         self._sweep_tmp: Dict[int, Field] = {}
         for l in self.levels:
             nc = dom.ncells(l)
@@ -416,6 +420,17 @@ class SolverFromL4(_Program):
         # loops on a copy, which costs more than the separate calls
         return self._one_pass_sweep(l)
 
+    def _three_colour_passes(self, l: int) -> bool:
+        """Does the kernel layer run three colour loops of level l in one pass (examg_rbgs_colours3 with its one-pass kernel)?"""
+        if not (self.cfg.fused_rbgs3 and hasattr(self.ops, "three_stage_eligible")):
+            return False
+        hit = self._three_ok.get(l)
+        if hit is None:
+            S, F = self.Solution[l], self.RHS[l]
+            b, e = self.bounds(S)
+            hit = self._three_ok[l] = bool(self.ops.three_stage_eligible(S.lc, F.lc, self.Laplace[l], list(b), list(e)))
+        return hit
+
     def _smooth(self, l: int, correction_from: Optional[Field] = None, zero_input: bool = False):
         S, F, A = self.Solution[l], self.RHS[l], self.Laplace[l]
         w = self.cfg.omega / A.diag           # `0.8 / diag(Laplace)`, folded to a literal by the generator
@@ -432,8 +447,19 @@ class SolverFromL4(_Program):
                     for colour in (0, 1):
                         self.ops.stencil_op(SMOOTH, S.lc, S.data(), F.lc, F.data(), S.lc, S.data(), A, w, colour, b, e)
                 return
-            for it in range(self.cfg.n_smooth):
+            it = 0
+            while it < self.cfg.n_smooth:
                 alt = self._sol_alt[l]
+                plain = not (it == 0 and (correction_from is not None or zero_input))
+                if plain and self.cfg.n_smooth - it >= 3 and self._three_colour_passes(l):
+                    # three sweeps = six colour loops 0 1 0 1 0 1 = two passes of three (the second starts with colour 1): 2 x 24 B per point
+                    # instead of 3 x 24, the same arithmetic in the same order
+                    for first in (0, 1):
+                        alt = self._sol_alt[l]
+                        self.ops.rbgs_colours3(S.lc, S.data(), alt, F.lc, F.data(), A, w, first, b, e)
+                        self._sol_alt[l], S.slots[0] = S.slots[0], alt
+                    it += 3
+                    continue
                 if it == 0 and correction_from is not None:
                     # the correction loop, whose box is the sweep's box, rides along (examg_rbgs_sweep_fused_prolong)
                     Sc = correction_from
@@ -443,6 +469,7 @@ class SolverFromL4(_Program):
                 else:
                     self.ops.rbgs_sweep_fused(S.lc, S.data(), alt, F.lc, F.data(), A, w, 0, b, e)
                 self._sol_alt[l], S.slots[0] = S.slots[0], alt
+                it += 1
             return
         assert correction_from is None and not zero_input
         if self.cfg.fused_rbgs:
@@ -617,26 +644,54 @@ class SolverFromL4(_Program):
                 raise RuntimeError("graph capture of a cycle with block neighbours needs agglomerated coarse levels (agglomerate_level)")
         torch = self.ops.torch
         hi = self.cfg.max_level
-        n_swaps = self.cfg.n_smooth * 2 if self.cfg.fused_rbgs else 0
-        if n_swaps % 2:
-            raise RuntimeError("graph capture with the fused sweep needs an even number of pointer swaps per cycle")
         s = torch.cuda.Stream(self.ops.device)
         s.wait_stream(torch.cuda.current_stream(self.ops.device))
         with torch.cuda.stream(s):
             self.mgCycle(hi)      # warm-up outside capture (lazy allocations)
         torch.cuda.current_stream(self.ops.device).wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        # thread_local: other threads of the process (RCCL's proxy threads at N > 1) may issue HIP calls during the capture
-        with _CAPTURE_LOCK, torch.cuda.graph(g, capture_error_mode="thread_local"):
-            self.mgCycle(hi)
-        self._graphs["cycle"] = g
+        # A cycle with an ODD number of out-of-place passes on a level (three sweeps as two passes of three colour loops + the three
+        # post-smoothing sweeps: five) leaves that level's solution in the other array: the cycle is then recorded twice -- from either
+        # assignment of the arrays -- and the replays alternate, moving the host's pointers as the recorded cycle would have
+        graphs, roles = [], [self._array_roles()]
+        for _ in range(2):
+            g = torch.cuda.CUDAGraph()
+            # thread_local: other threads of the process (RCCL's proxy threads at N > 1) may issue HIP calls during the capture
+            with _CAPTURE_LOCK, torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.mgCycle(hi)
+            graphs.append(g)
+            roles.append(self._array_roles())
+            if roles[-1] == roles[0]:
+                break
+        if roles[-1] != roles[0]:
+            raise RuntimeError("graph capture: the arrays of a level do not return to their roles after two cycles")
+        self._graphs["cycle"] = graphs
+        self._cycle_roles = roles
         self._graph_generation = getattr(self.comm, "generation", 0)
-        return g
+        return graphs[0]
+
+    def _array_roles(self):
+        """Which array is the solution and which the spare one, per level (the fused sweeps swap them)."""
+        return [(l, self.Solution[l].slots[0].data_ptr(), self._sol_alt[l].data_ptr() if self._sol_alt.get(l) is not None else 0)
+                for l in sorted(self.Solution)]
 
     def replay_cycle(self):
         if getattr(self.comm, "generation", 0) != getattr(self, "_graph_generation", 0):
             raise RuntimeError("the peer-write regions were re-allocated after this cycle was captured (a larger field was exchanged since): capture again")
-        self._graphs["cycle"].replay()
+        graphs = self._graphs["cycle"]
+        if len(graphs) == 1:
+            graphs[0].replay()
+            return
+        # two recordings, one per assignment of the arrays (capture_cycle): take the one that starts from the present assignment (cycles
+        # run outside the graph in between move it too), then move the host's pointers as the recorded cycle would have
+        now = self._array_roles()
+        phase = 0 if now == self._cycle_roles[0] else 1
+        if now != self._cycle_roles[phase]:
+            raise RuntimeError("replay_cycle: the arrays are in neither of the two recorded assignments: capture again")
+        graphs[phase].replay()
+        for (l, s0, _a0), (_l, s1, _a1) in zip(self._cycle_roles[phase], self._cycle_roles[phase + 1]):
+            if s0 != s1:
+                S = self.Solution[l]
+                self._sol_alt[l], S.slots[0] = S.slots[0], self._sol_alt[l]
 
 
 # =================================================================================================

@@ -164,6 +164,17 @@ int examg_jacobi3(const examg_layout_t *lu, const double *u_in, double *u_out, d
                   const double *rhs, const examg_stencil_t *st, double w, const int32_t *begin, const int32_t *end,
                   examg_stream_t stream);
 
+/* Three colour loops of a red-black smoother in ONE pass, out of place: colour `first`, the other colour, `first` again -- three sweeps
+ * (`repeat 3 times { color with { ... } }`, Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:204-213) are two such passes, the second with
+ * first = 1 - first.  u_out[box] = the three loops applied to u_in; bit-identical to three examg_rbgs_colour calls in place.  One-pass
+ * form: 3-D 7-point constant stencil, rows of at least 64 points (examg_three_stage_eligible); otherwise a copy and the three loops. */
+int examg_rbgs_colours3(const examg_layout_t *lu, const double *u_in, double *u_out, const examg_layout_t *lf, const double *rhs,
+                        const examg_stencil_t *st, double w, int first, const int32_t *begin, const int32_t *end, examg_stream_t stream);
+
+/* 1 if examg_jacobi3 / examg_rbgs_colours3 run their one-pass kernel for this box, 0 if they run their loops one after the other. */
+int examg_three_stage_eligible(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const int32_t *begin,
+                               const int32_t *end);
+
 /* One Jacobi step on [begin,end) and the residual of its result in ONE pass: u_out = J(u_in), res = rhs - A u_out on the box (the
  * last pre-smoothing `Smoother@current` + `Residual@current = RHS - Laplace * Solution`, Testing/SISC/3D_VarCoeff.exa4:141-153,
  * Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:215-219).  27-entry stencil fields in the record layout (EXAMG_CLAYOUT_ENTRY_FASTEST,

@@ -102,6 +102,12 @@ class OracleOps:
         self.stencil_op(2, lu, b, lf, rhs, lu, a, st, w, -1, begin, end)
         self.axpby(lu, a, lu, u_out, 1.0, 0.0, begin, end)
 
+    def rbgs_colours3(self, lu, u_in, u_out, lf, rhs, st, w, first, begin, end):
+        work = u_in.clone()
+        for c in (first, 1 - first, first):
+            self.stencil_op(2, lu, work, lf, rhs, lu, work, st, w, c, begin, end)
+        self.axpby(lu, work, lu, u_out, 1.0, 0.0, begin, end)
+
     def jacobi_residual(self, lu, u_in, u_out, lf, rhs, lr, res, st, w, begin, end):
         self.stencil_op(2, lu, u_in, lf, rhs, lu, u_out, st, w, -1, begin, end)
         self.stencil_op(1, lu, u_out, lf, rhs, lr, res, st, 0.0, -1, begin, end)

@@ -273,6 +273,85 @@ def test_three_stage_kernel_bit_exact(hip, orc, shape, b, e, order):
     assert_same(g, c, "jacobi3")
 
 
+@pytest.mark.parametrize("order", ["mp", "pm"])
+@pytest.mark.parametrize("first", [0, 1])
+@pytest.mark.parametrize("shape,b,e", [((130, 130, 130), None, None), ((165, 150, 141), None, None), ((256, 256, 64), None, None),
+                                       ((136, 120, 120), [0, 1, 0], [137, 120, 121]), ((150, 130, 110), [3, 2, 5], [148, 127, 108]),
+                                       ((96, 96, 96), None, None)])
+def test_three_colour_loops_in_one_pass(hip, orc, shape, b, e, first, order):
+    """examg_rbgs_colours3: colour `first`, the other colour, `first` again in one pass (k_three_stage7_lds<COL>) == three coloured loops
+    in place, bit for bit; both first colours (all tile / plane parities), odd and even box origins, ragged tiles and chunks; 96^3 takes
+    the copy + three loops."""
+    st = laplace_fd(3, tuple(1.0 / n for n in shape), order)
+    if b is None:
+        b, e = [1, 1, 1], list(shape)
+
+    def f(ops):
+        lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+        u, fr, out = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size)
+        ops.fill_random(u, 12345)
+        ops.fill_random(fr, 4711)
+        ops.fill_random(out, 5)
+        ops.rbgs_colours3(lu.c_struct(), u, out, lf.c_struct(), fr, st, 0.8 / st.diag, first, b, e)
+        return [out, u]
+
+    def ref(ops):     # outside the box the output keeps what it held (the one-pass kernel stores inside the box only)
+        lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+        u, fr, out = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size)
+        ops.fill_random(u, 12345)
+        ops.fill_random(fr, 4711)
+        ops.fill_random(out, 5)
+        ops.rbgs_colours3(lu.c_struct(), u, out, lf.c_struct(), fr, st, 0.8 / st.diag, first, b, e)
+        return [out, u]
+
+    got = f(hip)
+    hip.synchronize()
+    want = [orc.to_host(t) for t in ref(orc)]
+    got = [hip.to_host(t) for t in got]
+    if hip.three_stage_eligible(FieldLayout.node(3, shape, 1).c_struct(), FieldLayout.node(3, shape, 0).c_struct(), st, b, e):
+        assert_same(got, want, "rbgs_colours3")
+    else:
+        # the fallback copies the box with its shell into the output first: compare on the box
+        lu = FieldLayout.node(3, shape, 1)
+        g3, w3 = got[0].reshape(lu.tot(2), lu.tot(1), lu.tot(0)), want[0].reshape(lu.tot(2), lu.tot(1), lu.tot(0))
+        r = [lu.ref(d) for d in range(3)]
+        sl = tuple(slice(b[d] + r[d], e[d] + r[d]) for d in (2, 1, 0))
+        assert np.array_equal(g3[sl], w3[sl])
+        assert np.array_equal(got[1], want[1])
+
+
+def test_two_three_colour_passes_equal_three_sweeps(hip, orc):
+    """Two passes of three colour loops (first colour 0, then 1) == three fused red-black sweeps == six coloured loops of the oracle."""
+    shape = (160, 140, 130)
+    st = laplace_fd(3, tuple(1.0 / n for n in shape), "mp")
+    b, e = [1, 1, 1], list(shape)
+    lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+    w = 0.8 / st.diag
+
+    def start(ops):
+        u, fr, a, c = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size)
+        ops.fill_random(u, 1)
+        ops.fill_random(fr, 2)
+        a.copy_(u)
+        c.copy_(u)
+        return u, fr, a, c
+
+    u, fr, a, c = start(hip)
+    hip.rbgs_colours3(lu.c_struct(), u, a, lf.c_struct(), fr, st, w, 0, b, e)
+    hip.rbgs_colours3(lu.c_struct(), a, c, lf.c_struct(), fr, st, w, 1, b, e)
+    two = hip.to_host(c)
+    u, fr, a, c = start(hip)
+    hip.rbgs_sweep_fused(lu.c_struct(), u, a, lf.c_struct(), fr, st, w, 0, b, e)
+    hip.rbgs_sweep_fused(lu.c_struct(), a, c, lf.c_struct(), fr, st, w, 0, b, e)
+    hip.rbgs_sweep_fused(lu.c_struct(), c, a, lf.c_struct(), fr, st, w, 0, b, e)
+    three = hip.to_host(a)
+    u, fr, a, c = start(orc)
+    for _ in range(3):
+        for col in (0, 1):
+            orc.stencil_op(SMOOTH, lu.c_struct(), u, lf.c_struct(), fr, lu.c_struct(), u, st, w, col, b, e)
+    assert np.array_equal(two, three) and np.array_equal(two, orc.to_host(u))
+
+
 def test_three_stage_kernel_chunk_lengths(hipd, orc):
     """The three-step pass with forced z chunks of 5, 8, 33 and 200 planes (debug build): partial last chunks, one chunk for the whole box."""
     import ctypes as C
