@@ -46,8 +46,9 @@ def cases(ops, level, with27=True, align=0):
         ("residual", lambda: ops.stencil_op(1, L, u, F, f, L, r, A, 0.0, -1, b, e), "k_stencil7_rowmarch<1" if 400 <= n - 1 <= 512 else "k_stencil7_zmarch<1", 24 * pts, pts),
         ("rbgs_half_sweep", lambda: ops.stencil_op(2, L, u, F, f, L, u, A, w, 0, b, e), "k_stencil7_zmarch<2", 24 * pts, pts // 2),
         ("jacobi_2step", lambda: ops.jacobi2(L, u, un, None, F, f, A, w, b, e), "k_two_stage7_lds<0, false, 8, true, 1, 0", 24 * pts, 2 * pts),
-        ("jacobi_3step", lambda: ops.jacobi3(L, u, un, None, F, f, A, w, b, e), "k_three_stage7_lds<0, 8", 24 * pts, 3 * pts),
+        ("jacobi_3step", lambda: ops.jacobi3(L, u, un, None, F, f, A, w, b, e), "k_three_stage7_lds<0, 8, true, 3, false", 24 * pts, 3 * pts),
         ("rbgs_fused_sweep", lambda: ops.rbgs_sweep_fused(L, u, un, F, f, A, w, 0, b, e), "k_two_stage7_lds<0, true, 8, true, 1, 0", 24 * pts, pts),
+        ("rbgs_3colours", lambda: ops.rbgs_colours3(L, u, un, F, f, A, w, 0, b, e), "k_three_stage7_lds<0, 8, true, 3, true", 24 * pts, 3 * (pts // 2)),
         ("rbgs_fused_sweep_prolong", lambda: ops.rbgs_sweep_fused_prolong(L, u, un, F, f, A, w, 0, b, e, Lc, uc), "k_two_stage7_lds<0, true, 8, true, 1, 1",
          24 * pts + 8 * cpts, pts),
         ("rbgs_fused_sweep_zero", lambda: ops.rbgs_sweep_fused_zero(L, un, F, f, A, w, 0, b, e), "k_two_stage7_lds<0, true, 8, true, 1, 2", 16 * pts, pts),

@@ -21,7 +21,7 @@ HBM_PEAK = 8000.0e9
 # the sources a case's kernel is compiled from: their digest travels with the counters, and bench.py reports `traffic` only for a
 # kernel whose sources are still the profiled ones (kernel_source_digest)
 COMMON_SOURCES = ["examg_common.h"]
-CASE_SOURCES = {"jacobi_2step": ["kernels_twostage.hip"], "jacobi_3step": ["kernels_twostage.hip"], "rbgs_fused_sweep": ["kernels_twostage.hip"], "rbgs_fused_sweep_prolong": ["kernels_twostage.hip"],
+CASE_SOURCES = {"jacobi_2step": ["kernels_twostage.hip"], "jacobi_3step": ["kernels_twostage.hip"], "rbgs_3colours": ["kernels_twostage.hip"], "rbgs_fused_sweep": ["kernels_twostage.hip"], "rbgs_fused_sweep_prolong": ["kernels_twostage.hip"],
                 "rbgs_fused_sweep_zero": ["kernels_twostage.hip"], "residual_restrict": ["kernels_transfer.hip"], "restrict": ["kernels_transfer.hip"],
                 "prolong_add": ["kernels_transfer.hip"], "dot_norm": ["kernels_blas.hip"], "jacobi_27entry_two_steps": ["kernels_sf27pair.hip"],
                 "jacobi_27entry_step_residual": ["kernels_sf27pair.hip"]}
