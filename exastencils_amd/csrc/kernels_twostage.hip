@@ -1016,10 +1016,13 @@ k_three_stage7_lds(LayoutDev lu, const double *__restrict__ u, LayoutDev lf, con
 
 static thread_local int g_ts3_zc = -1;         // planes per z chunk of the three-step pass; -1: by size (examg_debug_three_stage)
 static thread_local int g_ts3_disable = 0;
+static thread_local long long g_ts3_minpts = 8000000LL;      // examg_debug_three_stage(2, ..): 2^20, so that the parity tests reach the kernel on small boxes
 
-// the three-step pass: 3-D 7-point constant stencils on rows of at least 64 points and at least 2^20 points (below, a pair and a step)
+// the three-stage pass: 3-D 7-point constant stencils on rows of at least 64 points and at least 8 * 10^6 points -- below, a pass per pair of
+// stages is faster (traced V-cycle, 128^3: two passes of three colour loops 43 + 41 us against three sweeps of 15-20 us; 256^3: 2 x 0.110 ms
+// against 3 x 0.094)
 static bool three_stage_ok(const examg_layout_t *lu, const examg_layout_t *lf, const examg_stencil_t *st, const Box &box) {
-  if (g_ts3_disable || !two_stage_ok(lu, lf, st, box) || box.n1() < 20 || box.count() < (1LL << 20)) return false;
+  if (g_ts3_disable || !two_stage_ok(lu, lf, st, box) || box.n1() < 20 || box.count() < g_ts3_minpts) return false;
   const LayoutDev u = make_layout(lu), f = make_layout(lf);
   return u.s2 < (1LL << 32) && f.s2 < (1LL << 32);
 }
@@ -1112,7 +1115,8 @@ extern "C" int examg_debug_two_stage_prol(int wpe) {
 }
 
 extern "C" int examg_debug_three_stage(int disable, int zc) {
-  g_ts3_disable = disable;
+  g_ts3_disable = disable == 1;
+  g_ts3_minpts = disable == 2 ? (1LL << 20) : 8000000LL;
   g_ts3_zc = zc > 0 ? zc : -1;
   return 0;
 }

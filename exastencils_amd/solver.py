@@ -410,6 +410,10 @@ class SolverFromL4(_Program):
         cfg = self.cfg
         if not (cfg.fused_prolong_min_points > 0 and cfg.fused_rbgs and self._single_block() and cfg.n_smooth >= 1):
             return False
+        if cfg.n_smooth % 3 == 0 and self._three_colour_passes(l):
+            # where three sweeps run as two passes of three colour loops, the separate correction loop + those passes beat the folded
+            # first sweep + a pass per remaining sweep (tools/ab_post.py, 512^3, one process: cycle 4.875 -> 4.784 ms; same bits)
+            return False
         S = self.Solution[l]
         b, e = self.bounds(S)
         # the fold pays where the pass is bandwidth-bound and large (a read-modify-write loop less) and where the level is launch-bound

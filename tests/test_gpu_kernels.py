@@ -247,14 +247,27 @@ def test_two_stage_kernel_bit_exact(orc, two_stage_variant, kind, order, n, firs
     assert_same([hip.to_host(t) for t in g], c, "two-stage " + kind)
 
 
+@pytest.fixture
+def hip3(hipd):
+    """The debug build with the size bound of the three-stage pass lowered to 2^20 points (the product takes it from 8e6 points on): the
+    parity cases reach the kernel on boxes the oracle sweeps in a moment."""
+    import ctypes as C
+
+    hipd.L.examg_debug_three_stage.argtypes = [C.c_int] * 2
+    hipd.L.examg_debug_three_stage(2, -1)
+    yield hipd
+    hipd.L.examg_debug_three_stage(0, -1)
+
+
 @pytest.mark.parametrize("order", ["mp", "pm"])
 @pytest.mark.parametrize("shape,b,e", [((130, 130, 130), None, None), ((165, 150, 140), None, None), ((256, 256, 64), None, None),
                                        ((200, 72, 90), None, None), ((136, 120, 120), [0, 1, 0], [137, 120, 121]),
                                        ((150, 130, 110), [3, 2, 5], [148, 127, 108]), ((96, 96, 96), None, None)])
-def test_three_stage_kernel_bit_exact(hip, orc, shape, b, e, order):
+def test_three_stage_kernel_bit_exact(hip3, orc, shape, b, e, order):
+    hip = hip3
     """examg_jacobi3: three Jacobi steps in one pass (k_three_stage7_lds: 120-point x windows, 20-row groups, z chunks with three halo
     planes) == three loops one after the other, bit for bit; ragged windows, row groups and chunks; a box over the duplicate planes of a
-    block with neighbours (its input halo in the ghost layer) and a box inside the inner points; 96^3 is below the kernel's size bound
+    block with neighbours (its input halo in the ghost layer) and a box inside the inner points; 96^3 is below the (lowered) size bound
     and takes a step + a pair."""
     st = laplace_fd(3, tuple(1.0 / n for n in shape), order)
     if b is None:
@@ -278,7 +291,8 @@ def test_three_stage_kernel_bit_exact(hip, orc, shape, b, e, order):
 @pytest.mark.parametrize("shape,b,e", [((130, 130, 130), None, None), ((165, 150, 141), None, None), ((256, 256, 64), None, None),
                                        ((136, 120, 120), [0, 1, 0], [137, 120, 121]), ((150, 130, 110), [3, 2, 5], [148, 127, 108]),
                                        ((96, 96, 96), None, None)])
-def test_three_colour_loops_in_one_pass(hip, orc, shape, b, e, first, order):
+def test_three_colour_loops_in_one_pass(hip3, orc, shape, b, e, first, order):
+    hip = hip3
     """examg_rbgs_colours3: colour `first`, the other colour, `first` again in one pass (k_three_stage7_lds<COL>) == three coloured loops
     in place, bit for bit; both first colours (all tile / plane parities), odd and even box origins, ragged tiles and chunks; 96^3 takes
     the copy + three loops."""
@@ -320,7 +334,8 @@ def test_three_colour_loops_in_one_pass(hip, orc, shape, b, e, first, order):
         assert np.array_equal(got[1], want[1])
 
 
-def test_two_three_colour_passes_equal_three_sweeps(hip, orc):
+def test_two_three_colour_passes_equal_three_sweeps(hip3, orc):
+    hip = hip3
     """Two passes of three colour loops (first colour 0, then 1) == three fused red-black sweeps == six coloured loops of the oracle."""
     shape = (160, 140, 130)
     st = laplace_fd(3, tuple(1.0 / n for n in shape), "mp")
@@ -352,6 +367,31 @@ def test_two_three_colour_passes_equal_three_sweeps(hip, orc):
     assert np.array_equal(two, three) and np.array_equal(two, orc.to_host(u))
 
 
+@pytest.mark.parametrize("kind", ["jacobi3", "colours3_0", "colours3_1"])
+def test_three_stage_pass_on_the_product_library(hip, orc, kind):
+    """The product library takes the three-stage pass from 8e6 points on: 264 x 200 x 170 (three x windows, ten row groups, four chunks)
+    against the oracle's three loops."""
+    shape = (264, 200, 170)
+    st = laplace_fd(3, tuple(1.0 / n for n in shape), "mp")
+    b, e = [1, 1, 1], list(shape)
+    lu, lf = FieldLayout.node(3, shape, 1), FieldLayout.node(3, shape, 0)
+    assert hip.three_stage_eligible(lu.c_struct(), lf.c_struct(), st, b, e)
+
+    def f(ops):
+        u, fr, out, tmp = ops.new_array(lu.size), ops.new_array(lf.size), ops.new_array(lu.size), ops.new_array(lu.size)
+        ops.fill_random(u, 3)
+        ops.fill_random(fr, 4)
+        ops.fill_random(out, 5)
+        if kind == "jacobi3":
+            ops.jacobi3(lu.c_struct(), u, out, tmp, lf.c_struct(), fr, st, 0.8 / st.diag, b, e)
+        else:
+            ops.rbgs_colours3(lu.c_struct(), u, out, lf.c_struct(), fr, st, 0.8 / st.diag, int(kind[-1]), b, e)
+        return [out, u]
+
+    g, c = both(hip, orc, f)
+    assert_same(g, c, kind)
+
+
 def test_three_stage_kernel_chunk_lengths(hipd, orc):
     """The three-step pass with forced z chunks of 5, 8, 33 and 200 planes (debug build): partial last chunks, one chunk for the whole box."""
     import ctypes as C
@@ -373,7 +413,7 @@ def test_three_stage_kernel_chunk_lengths(hipd, orc):
     want = [orc.to_host(t) for t in f(orc)]
     try:
         for zc in (5, 8, 33, 200):
-            hipd.L.examg_debug_three_stage(0, zc)
+            hipd.L.examg_debug_three_stage(2, zc)
             got = f(hipd)
             hipd.synchronize()
             assert_same([hipd.to_host(t) for t in got], want, "jacobi3, chunks of %d planes" % zc)
