@@ -64,16 +64,21 @@ def _check_solution(hip, S, rec):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_config3_512_history_vs_own_oracle(hip, fused):
+@pytest.mark.parametrize("fused,three", [(False, False), (True, False), (True, True)], ids=["plain", "pass_per_sweep", "three_colour_passes"])
+def test_config3_512_history_vs_own_oracle(hip, fused, three):
     """BASELINE configs[2]: Benchmark/Poisson3D/3D_FD_Poisson_fromL4.exa4:121-249 at 512^3, levels 4..9, RBGS V(3,3),
-    CG coarse solve, stop at 1e-6: every residual of the Solve loop within 1e-10 of the oracle's."""
+    CG coarse solve, stop at 1e-6: every residual of the Solve loop within 1e-10 of the oracle's -- statement by statement, with one
+    pass per sweep, and with three sweeps as two passes of three colour loops (the product's default)."""
     rec = _fixture("config3_512")
-    cfg = ConfigL4(**rec["config"], fused_rbgs=fused, fused_residual_restrict=fused, fused_prolong_min_points=10_000_000 if fused else 0, fused_zero_start=fused, fused_residual_norm=fused)
+    cfg = ConfigL4(**rec["config"], fused_rbgs=fused, fused_residual_restrict=fused, fused_prolong_min_points=10_000_000 if fused else 0, fused_zero_start=fused,
+                   fused_residual_norm=fused, fused_rbgs3=three)
     P = SolverFromL4(cfg, hip)
     P.setup()
-    # folded where the pass is large (>= 10^7 points) and where the level is launch-bound (rows shorter than 64 points); not in between
-    assert P._folds_prolongation(cfg.max_level) == fused and P._folds_prolongation(cfg.max_level - 1) == fused and not P._folds_prolongation(cfg.max_level - 2)
+    # three colour loops per pass from 8e6 points on (levels 9 and 8): there the correction stays a loop of its own; otherwise it is folded
+    # where the pass is large (>= 10^7 points) and where the level is launch-bound (rows shorter than 64 points), not in between
+    big = fused and not three
+    assert P._three_colour_passes(cfg.max_level) == three and P._three_colour_passes(cfg.max_level - 1) == three and not P._three_colour_passes(cfg.max_level - 2)
+    assert P._folds_prolongation(cfg.max_level) == big and P._folds_prolongation(cfg.max_level - 1) == big and not P._folds_prolongation(cfg.max_level - 2)
     assert P._folds_prolongation(cfg.max_level - 3) == fused
     P.Solve()
     assert P.iterations == rec["iterations"]

@@ -528,13 +528,20 @@ def test_folded_prolongation_changes_no_bit(hip):
     hist, sols, folds = [], [], []
     for min_points in (0, 1):       # ... and (second run) `Solution@coarser = 0` left to the first sweep of the coarser level
         P = SolverFromL4(ConfigL4(nd=3, min_level=2, max_level=8, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True,
-                                  fused_prolong_min_points=min_points, fused_zero_start=bool(min_points)), hip)
+                                  fused_prolong_min_points=min_points, fused_zero_start=bool(min_points), fused_rbgs3=False), hip)
         P.setup()
         P.Solve()
         hist.append(P.res_history)
         sols.append(hip.to_host(P.Solution[8].data()).copy())
         folds.append([P._folds_prolongation(l) for l in range(3, 9)])
     assert folds == [[False] * 6, [True] * 6]       # rows of 64 points and more: the two-stage kernel; shorter rows: the small-level kernel
+    # the product's default on top: three sweeps of the 256^3 level as two passes of three colour loops, its correction a loop of its own
+    P = SolverFromL4(ConfigL4(nd=3, min_level=2, max_level=8, tol=1e-6, fused_rbgs=True, fused_residual_restrict=True, fused_prolong_min_points=1,
+                              fused_zero_start=True), hip)
+    P.setup()
+    P.Solve()
+    assert P._three_colour_passes(8) and not P._folds_prolongation(8) and P._folds_prolongation(7)
+    assert P.res_history == hist[0] and np.array_equal(hip.to_host(P.Solution[8].data()).view(np.uint64), sols[0].view(np.uint64))
     assert hist[0] == hist[1] and len(hist[0]) > 4
     assert np.array_equal(sols[0].view(np.uint64), sols[1].view(np.uint64))
     from exastencils_amd.solver import ConfigL3, SolverFromL3
