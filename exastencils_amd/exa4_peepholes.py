@@ -194,7 +194,8 @@ class Peepholes:
                     # three steps in one pass where they run on the same box (a block without neighbours: nothing is widened) --
                     # Testing/PolyExpl/Jac3Dcc.exa4:27's five steps are then a pass of three and a pass of two
                     b3, e3 = self._contract_bounds(U.layout, lb, le, expand - 2, pos, neg)
-                    if list(b1) == list(b2) == list(b3) and list(e1) == list(e2) == list(e3):
+                    if list(b1) == list(b2) == list(b3) and list(e1) == list(e2) == list(e3) and \
+                            (not hasattr(self.ops, "three_stage_eligible") or self.ops.three_stage_eligible(U.lc, F.lc, A, list(b1), list(e1))):
                         self.launches += 1
                         self.ops.jacobi3(U.lc, U.data(U.active), U.data(U.next), tmp.data(), F.lc, F.data(), A, w, b1, e1)
                         U.advance()

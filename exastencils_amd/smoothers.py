@@ -60,6 +60,8 @@ def jacobi_triple(ops, comm, domain, S, F, A, w: float, tmp_field) -> bool:
     if any(domain.neighbor(d, side) is not None for d in range(nd) for side in (-1, 1)) or not hasattr(ops, "jacobi3"):
         return False
     b, e = domain.loop_bounds(S.layout)
+    if hasattr(ops, "three_stage_eligible") and not ops.three_stage_eligible(S.lc, F.lc, A, list(b), list(e)):
+        return False        # the entry point would run a step through `tmp` (with a copy of the box) and a pair: the caller's pair + step is cheaper
     axis_only = all(sum(1 for c in o if c != 0) <= 1 for o in A.offsets)
     comm.exchange(S, S.active, "ghost", axis_only)      # empty on a single block
     ops.jacobi3(S.lc, S.data(S.active), S.data(S.next), tmp_field.data(), F.lc, F.data(), A, w, b, e)

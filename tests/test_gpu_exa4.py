@@ -251,6 +251,19 @@ def test_field_io_files_equal_the_cpu_run_byte_for_byte(hip, tmp_path):
         assert len(a) > 0 and a == b, "%s differs between the device run and the CPU run" % name
 
 
+def test_contracting_loop_three_plus_two_steps_on_gpu(hip):
+    """The same program on a 256^3 block (the three-stage pass applies from 8e6 points on): the five contracted steps of a Smoother call run
+    as a pass of three (examg_jacobi3) and a pass of two -- two launches instead of five, the printed norms bit-identical."""
+    from test_exa4 import example
+
+    P = example("jacobi3d_contraction.exa4", 8, 8, ops=hip)
+    P.run()
+    plain = example("jacobi3d_contraction.exa4", 8, 8, ops=hip, fuse=False)
+    plain.run()
+    assert P.printed_values == plain.printed_values and len(P.printed_values) > 0
+    assert plain.launches - P.launches >= 9      # three Smoother calls: 2 instead of 5 launches each (pairs alone would save 6)
+
+
 def test_contracting_loop_on_gpu(hip):
     """`repeat 5 times with contraction [1, 1, 1]` (node-grid reduction of the reference's Testing/PolyExpl/Jac3Dcc.exa4:1-33) on the
     device: two two-step passes + one step per Smoother call, same bits as five plain launches, norms as the CPU ops print them."""
