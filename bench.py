@@ -812,8 +812,9 @@ def vcycle(ops, dom, comm, L, world, align=0, check_dups=True, deep_halo=True):
     solve_s = time.perf_counter() - t0
     if hasattr(comm, "check"):
         comm.check()
-    # compulsory bytes of one cycle as the driver runs it, per level above the coarsest: 6 sweeps x 24 B per point (16 B for a first
-    # sweep that takes the zero field as a constant), residual + restriction (16 B per point + 8 B per coarse point), zeroing the
+    # compulsory bytes of one cycle as the driver runs it, per level above the coarsest: 24 B per point for every pass of the smoother
+    # (6 sweeps = 6 passes, or 4 where three sweeps run as two passes of three colour loops; 16 B for a first sweep that takes the zero
+    # field as a constant), residual + restriction (16 B per point + 8 B per coarse point), zeroing the
     # coarse solution (8 B per coarse point, unless left to that sweep), prolongation + correction (16 B per point + 8 B per coarse
     # point; folded into the first post-smoothing sweep: the 8 B per coarse point only)
     comp = 0.0
@@ -822,7 +823,13 @@ def vcycle(ops, dom, comm, L, world, align=0, check_dups=True, deep_halo=True):
         lcb, lce = dom.loop_bounds(P.Solution[l - 1].layout)
         p = float((le[0] - lb[0]) * (le[1] - lb[1]) * (le[2] - lb[2]))
         c = float((lce[0] - lcb[0]) * (lce[1] - lcb[1]) * (lce[2] - lcb[2]))
-        comp += 6 * 24.0 * p - (8.0 * p if P._starts_from_zero(l) else 0.0)
+        # passes of the smoother: a sweep (two colour loops) per pass, or -- where the kernel layer takes three colour loops per pass
+        # (solver.py: _three_colour_passes) -- three plain sweeps as two passes
+        three = bool(getattr(P, "_three_colour_passes", lambda _l: False)(l))
+        zero = P._starts_from_zero(l)
+        pre = (16.0 + 2 * 24.0) if zero else (2 * 24.0 if three else 3 * 24.0)
+        post = 2 * 24.0 if (three and not P._folds_prolongation(l)) else 3 * 24.0
+        comp += (pre + post) * p
         comp += 16.0 * p + 8.0 * c
         comp += 0.0 if P._starts_from_zero(l - 1) else 8.0 * c
         comp += 8.0 * c if P._folds_prolongation(l) else 16.0 * p + 8.0 * c
