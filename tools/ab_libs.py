@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""A/B of two builds of libexamg in ONE process, steady state, interleaved rounds: python tools/ab_libs.py libA.so libB.so [n]"""
+"""A/B of two builds of libexamg in ONE process, steady state, interleaved rounds: python tools/ab_libs.py libA.so libB.so [n]
+(tools/build_round_start_lib.sh builds tools/lab/libexamg_r4a.so, the two-stage kernels as they stood before the plane loops ran in groups of four)"""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
