@@ -63,6 +63,42 @@ def test_folded_prolongation_in_the_host_driver():
     assert hist[0] == hist[1] and len(hist[0]) > 3
 
 
+def test_three_sweeps_as_two_passes_of_three_colour_loops_in_the_host_driver():
+    """mgCycle with three plain sweeps issued as two examg_rbgs_colours3 calls (first colour 0, then 1) and the correction as a loop of its
+    own where those passes apply -- the host logic of SolverFromL4._smooth / _folds_prolongation, with the oracle's coloured loops standing
+    in for the one-pass kernel: the same history, to the last bit, as a call per sweep; the pass count per cycle and level is odd on the
+    levels that start from the zero field (zero sweep + two sweeps + two passes), which is what capture_cycle's two recordings are for."""
+    class Ops(OracleOps):
+        calls = 0
+
+        def three_stage_eligible(self, lu, lf, st, begin, end):      # the kernel layer's answer: levels 4 and 3 of this small hierarchy
+            return (end[0] - begin[0]) >= 7
+
+        def rbgs_colours3(self, *a):
+            Ops.calls += 1
+            return OracleOps.rbgs_colours3(self, *a)
+
+    hist = []
+    for three in (False, True):
+        P = SolverFromL4(ConfigL4(nd=3, min_level=1, max_level=4, tol=1e-8, fused_coarse=False, fused_rbgs=True, fused_prolong_min_points=1,
+                                  fused_zero_start=True, fused_residual_restrict=True, fused_residual_norm=True, fused_rbgs3=three), Ops())
+        P.setup()
+        assert P._three_colour_passes(4) == three and P._three_colour_passes(3) == three and not P._three_colour_passes(2)
+        # the correction is folded where a sweep takes one pass each; a loop of its own where three sweeps are two passes
+        assert P._folds_prolongation(4) == (not three) and P._folds_prolongation(3) == (not three) and P._folds_prolongation(2)
+        roles = [(P.Solution[l].slots[0].data_ptr(), P._sol_alt[l].data_ptr()) for l in (3, 4)]
+        P.mgCycle(4)
+        after = [(P.Solution[l].slots[0].data_ptr(), P._sol_alt[l].data_ptr()) for l in (3, 4)]
+        if three:       # level 4: 2 + 2 passes (even); level 3: zero sweep + 2 sweeps + 2 passes (odd: its arrays have changed roles)
+            assert after[1] == roles[1] and after[0] == (roles[0][1], roles[0][0])
+        else:
+            assert after == roles
+        P.reset()
+        P.Solve()
+        hist.append(P.res_history)
+    assert Ops.calls > 0 and hist[0] == hist[1] and len(hist[0]) > 3
+
+
 def test_fmg_driver_with_one_pass_forms():
     """The layer-3 style driver (FMG start of Testing/FMG/3D_Trigonometric.exa4:189-242 with the red-black smoother of
     Testing/Smoothers/RBGS.exa4:125-133) with every one-pass form switched on -- correction folded into the first post-smoothing sweep,
